@@ -1,0 +1,11 @@
+"""bbbp-multi-modal-deep-ensemble-framework_amd: MI355X (gfx950) implementation of the neural hot path of
+FengDushuo/BBBP-Multi-Modal-Deep-Ensemble-Framework (import it as ``bbbp_amd``).
+
+Layout:  csrc/ (HIP kernels + the C ABI of include/bbbp_hip.h), _lib.py (ctypes binding), ops.py (tensor
+front end), models.py (the reference's nn.Module interface), optim.py (fused AdamW), ensemble.py (stacked
+predict surface), distributed.py (one process per GPU, RCCL gradient all-reduce).
+"""
+from .models import MixedDataset, MixedInputModel, MultiHeadAttentionFusion, flatten_parameters, reference_nhead  # noqa: F401
+from . import ops  # noqa: F401
+
+__all__ = ["MixedDataset", "MixedInputModel", "MultiHeadAttentionFusion", "flatten_parameters", "reference_nhead", "ops"]

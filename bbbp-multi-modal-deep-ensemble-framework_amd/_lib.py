@@ -1,0 +1,97 @@
+"""ctypes binding of libbbbp_hip.so (the C ABI declared in include/bbbp_hip.h).
+
+The product path has NO fallback: if the library is missing, or a call fails, a RuntimeError is
+raised.  Nothing here imports torch; device pointers arrive as integers.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_long, c_size_t, c_uint8, c_uint64, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbbbp_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bbbp_hip.h")
+
+_lib = None
+
+
+class MixedDesc(Structure):
+    """bbbp_mixed_desc (include/bbbp_hip.h)."""
+    _fields_ = [("batch", c_int), ("fingerprint_size", c_int), ("nhead", c_int), ("num_layers", c_int),
+                ("dim_feedforward", c_int), ("training", c_int), ("dropout_p", c_float), ("seed", c_uint64),
+                ("need_input_grad", c_int)]
+
+
+_FP = c_void_p          # device float*
+_PP = POINTER(c_void_p)  # host array of device pointers
+
+_SIGNATURES = {
+    "bbbp_abi_version": (c_int, []),
+    "bbbp_last_error": (c_char_p, []),
+    "bbbp_gemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "bbbp_gemm_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, _FP, c_int, _FP, c_int, _FP, c_int,
+                              _FP, _FP, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_void_p, c_size_t]),
+    "bbbp_conv3x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "bbbp_conv3x3_relu_pool_fwd": (c_int, [c_void_p, _FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                           c_void_p, c_size_t]),
+    "bbbp_conv3x3_relu_pool_bwd_data": (c_int, [c_void_p, _FP, c_void_p, _FP, _FP, c_int, c_int, c_int, c_int, c_int,
+                                                c_void_p, c_size_t]),
+    "bbbp_conv3x3_relu_pool_bwd_weight": (c_int, [c_void_p, _FP, _FP, c_void_p, _FP, _FP, c_int, c_int, c_int, c_int,
+                                                  c_int, c_void_p, c_size_t]),
+    "bbbp_layernorm_fwd": (c_int, [c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_float, c_float, c_uint64]),
+    "bbbp_layernorm_bwd": (c_int, [c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_float, c_uint64]),
+    "bbbp_softmax_fwd": (c_int, [c_void_p, _FP, _FP, c_long, c_int, c_float, c_uint64]),
+    "bbbp_softmax_bwd": (c_int, [c_void_p, _FP, _FP, c_long, c_int, c_float, c_uint64]),
+    "bbbp_dropout": (c_int, [c_void_p, _FP, _FP, c_long, c_float, c_uint64]),
+    "bbbp_batchnorm1d_fwd": (c_int, [c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_float, c_float, c_int]),
+    "bbbp_batchnorm1d_bwd": (c_int, [c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int]),
+    "bbbp_bias_act_bwd": (c_int, [c_void_p, _FP, c_int, _FP, c_int, _FP, c_int, c_int, c_int, c_float]),
+    "bbbp_fusion_combine_fwd": (c_int, [c_void_p, _FP, _FP, _PP, _PP, _FP, _FP, c_int, c_int, c_int, c_int]),
+    "bbbp_fusion_combine_bwd": (c_int, [c_void_p, _FP, _FP, _FP, _FP, _PP, _FP, _FP, _FP, c_int, c_int, c_int, c_int]),
+    "bbbp_mse": (c_int, [c_void_p, _FP, _FP, _FP, _FP, c_int, c_float]),
+    "bbbp_adamw_step": (c_int, [c_void_p, _FP, _FP, _FP, _FP, c_long, c_float, c_float, c_float, c_float, c_float, c_int,
+                                c_float]),
+    "bbbp_scale": (c_int, [c_void_p, _FP, c_long, c_float]),
+    "bbbp_mixed_num_params": (c_int, [POINTER(MixedDesc)]),
+    "bbbp_mixed_workspace_bytes": (c_size_t, [POINTER(MixedDesc)]),
+    "bbbp_mixed_forward": (c_int, [c_void_p, POINTER(MixedDesc), _PP, _PP, _FP, _FP, _FP, c_void_p, c_size_t]),
+    "bbbp_mixed_backward": (c_int, [c_void_p, POINTER(MixedDesc), _PP, _PP, _FP, _FP, _FP, c_void_p, c_size_t]),
+}
+
+
+def declared_symbols():
+    """Every function name declared in include/bbbp_hip.h (used by the ABI test)."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bbbp_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib() -> ctypes.CDLL:
+    """Load the HIP library, or fail loudly (there is no CPU fallback on the product path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  The BBBP hot path has no CPU fallback.")
+    l = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(l, name)       # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = l
+    return l
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().bbbp_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr_array(ptrs):
+    arr = (c_void_p * len(ptrs))(*ptrs)
+    return arr

@@ -1,0 +1,74 @@
+// Shared helpers for the gfx950 kernels of the BBBP hot path.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define BBBP_OK 0
+#define BBBP_ERR_ARG 1
+#define BBBP_ERR_HIP 2
+#define BBBP_ERR_WORKSPACE 3
+
+// last-error string, one per host thread (never throws across the C ABI)
+void bbbp_set_error(const char* fmt, ...);
+
+#define BBBP_CHECK_ARG(cond, ...)                 \
+    do {                                          \
+        if (!(cond)) {                            \
+            bbbp_set_error(__VA_ARGS__);          \
+            return BBBP_ERR_ARG;                  \
+        }                                         \
+    } while (0)
+
+#define BBBP_CHECK_HIP(expr)                                                            \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            bbbp_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return BBBP_ERR_HIP;                                                        \
+        }                                                                               \
+    } while (0)
+
+#define BBBP_CHECK_LAUNCH() BBBP_CHECK_HIP(hipGetLastError())
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int bbbp_num_cus();   // cached multiProcessorCount of the current device
+
+// exact f32 MFMA: D[32x32] += A[32x2] * B[2x32]; lane l holds A[l&31][l>>5], B[l>>5][l&31];
+// D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5) for register r of 16.
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// Philox-4x32-10 counter RNG for dropout masks (recomputed, never stored)
+__device__ __forceinline__ uint4 philox4(uint64_t seed, uint64_t ctr) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x9E3779B9u, c3 = 0xBB67AE85u;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+// keep-scale for element `idx` of dropout stream `seed`: 0 or 1/(1-p)
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
+    uint4 r = philox4(seed, idx >> 2);
+    uint32_t v = (idx & 3) == 0 ? r.x : (idx & 3) == 1 ? r.y : (idx & 3) == 2 ? r.z : r.w;
+    // uniform in [0,1): top 24 bits
+    float u = (float)(v >> 8) * (1.0f / 16777216.0f);
+    return u >= p ? inv_keep : 0.0f;
+}

@@ -1,0 +1,751 @@
+// 3x3 / stride 1 / pad 1 convolution fused with ReLU and 2x2 max-pool, forward and backward, as
+// implicit GEMMs on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32) for gfx950.
+//
+// Replaces `nn.Conv2d(k=3,s=1,p=1) -> nn.ReLU -> nn.MaxPool2d(2,2)` of the reference's image branch
+// (Models/multi_input_data_regression_opt_transformer_cnn_20250113.py:84-90) and
+// their autograd backward (a12).  NCHW fp32 in and out, exactly the reference's tensor layout.
+//
+// Forward / data-gradient kernel (one template):
+//   GEMM view  D[co][pixel] = sum_{tap,ci} Wt[tap][ci][co] * X[ci][pixel shifted by tap]
+//   M = output channels (MFMA rows), N = 32 consecutive pixels of one image row (MFMA columns, so
+//   a half-wave reads 32 consecutive floats of the LDS strip: conflict-free), K = (tap, ci) with
+//   ci fastest, so the two k of one MFMA are two adjacent channel planes (a constant LDS delta).
+//   A work-group owns a strip of TH output rows x the full width of one image; each of its 8 waves
+//   owns 2 rows x 32 columns x all output channels, so the 2x2 pool partners are the wave's two
+//   accumulator tiles (rows) and the neighbouring lane (columns, one DPP shuffle).  Weights
+//   (pre-transposed to [tap][ci][co] by a prep kernel) stay resident in LDS; input channels stream
+//   through a double-buffered LDS strip in chunks of 8 (register-staged prefetch under the MFMAs).
+//   MODE_FWD:   + bias, ReLU, max-pool; writes pooled y and a u8 mask (argmax 0..3 in PyTorch's
+//               first-max order, 4 = ReLU inactive) that backward uses instead of the 4x larger
+//               pre-pool activation.
+//   MODE_DGRAD: the strip loader expands the pooled gradient through the mask on the fly
+//               (dYfull is never materialised); the prep kernel flips/transposes the weights.
+// Weight-gradient kernels: D[co][(tap,ci)] = sum_pixels dYfull[co][pixel] * X[ci][pixel + tap],
+//   K = pixels; each work-group reduces its waves' K-partials in LDS, writes one partial slab, and a
+//   second kernel sums the slabs in a fixed order (bit-reproducible; no float atomics).
+#include "common.h"
+#include "bbbp_hip.h"
+
+namespace {
+
+constexpr int MODE_FWD = 0;
+constexpr int MODE_DGRAD = 1;
+constexpr int PADL = 4;           // left halo column sits at index PADL-1 so data columns are 16-B aligned
+
+struct ConvParams {
+    const float* x;        // FWD: input [B][CIN][H][W];  DGRAD: pooled grad [B][CIN][H/2][W/2]
+    const uint8_t* xmask;  // DGRAD: mask of the pooled grad
+    const float* wt;       // prepped weights [9][CINP][COUT]
+    const float* bias;     // FWD: [COUT]
+    float* y;              // FWD: pooled [B][COUT][H/2][W/2];  DGRAD: [B][COUT][H][W]
+    uint8_t* ymask;        // FWD: [B][COUT][H/2][W/2]
+    int B, H;
+};
+
+template <int CIN, int COUT, int W, int MODE>
+struct ConvCfg {
+    static constexpr int CC = CIN >= 8 ? 8 : 4;              // channels per LDS chunk
+    static constexpr int NCH = (CIN + CC - 1) / CC;
+    static constexpr int CINP = NCH * CC;
+    static constexpr int TH = 512 / W;                       // strip rows: 8 wave tiles of 2 x 32
+    static constexpr int ROWS = TH + 2;
+    static constexpr int LDW = W + 8;
+    static constexpr int PLANE = ROWS * LDW;
+    static constexpr int CHUNK = CC * PLANE;                 // floats per strip buffer
+    static constexpr int WFLOATS = 9 * CINP * COUT;
+    static constexpr int MT = COUT / 32;
+    static constexpr size_t LDS_BYTES = (size_t)(WFLOATS + 2 * CHUNK) * sizeof(float);
+    static_assert(COUT % 32 == 0 && MT <= 2, "output channels: 32 or 64 per pass");
+    static_assert(W == 64 || W == 128 || W == 32, "row width");
+    static_assert(CC % 2 == 0, "k pairs are adjacent channel planes");
+};
+
+template <int CIN, int COUT, int W, int MODE>
+__global__ __launch_bounds__(512) void conv3x3_kernel(ConvParams p) {
+    using C = ConvCfg<CIN, COUT, W, MODE>;
+    constexpr int CC = C::CC, NCH = C::NCH, CINP = C::CINP, TH = C::TH, ROWS = C::ROWS, LDW = C::LDW,
+                  PLANE = C::PLANE, CHUNK = C::CHUNK, MT = C::MT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ws = smem;
+    float* Xs = smem + C::WFLOATS;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int H = p.H;
+    const int strips_per_img = H / TH;
+    const int nstrips = p.B * strips_per_img;
+
+    // resident weights + zero both strip buffers (halo columns / padded channel planes stay zero)
+    for (int i = t * 4; i < C::WFLOATS; i += 512 * 4)
+        *reinterpret_cast<float4*>(Ws + i) = *reinterpret_cast<const float4*>(p.wt + i);
+    for (int i = t * 4; i < 2 * CHUNK; i += 512 * 4)
+        *reinterpret_cast<float4*>(Xs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    // ---- strip loader (register staged) ----
+    constexpr int QW = (MODE == MODE_FWD) ? W / 4 : W / 8;      // work items per row
+    constexpr int ITEMS = CC * ROWS * QW;
+    constexpr int NIT = (ITEMS + 511) / 512;
+    float4 rg[NIT];
+    uint32_t rm[NIT];
+    auto load_stage = [&](int strip, int chunk) {
+        const int b = strip / strips_per_img, h0 = (strip % strips_per_img) * TH;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            int idx = t + i * 512;
+            int q = idx % QW, row = (idx / QW) % ROWS, ci = idx / (QW * ROWS);
+            int c = chunk * CC + ci, hh = h0 - 1 + row;
+            bool ok = idx < ITEMS && c < CIN && hh >= 0 && hh < H;
+            rg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rm[i] = 0x04040404u;
+            if (ok) {
+                if (MODE == MODE_FWD) {
+                    rg[i] = *reinterpret_cast<const float4*>(p.x + (((long)b * CIN + c) * H + hh) * W + q * 4);
+                } else {
+                    long off = (((long)b * CIN + c) * (H / 2) + (hh >> 1)) * (W / 2) + q * 4;
+                    rg[i] = *reinterpret_cast<const float4*>(p.x + off);
+                    rm[i] = *reinterpret_cast<const uint32_t*>(p.xmask + off);
+                }
+            }
+        }
+    };
+    auto store_stage = [&](int strip, int buf) {
+        const int h0 = (strip % strips_per_img) * TH;
+        float* xs = Xs + buf * CHUNK;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            int idx = t + i * 512;
+            if (idx >= ITEMS) continue;
+            int q = idx % QW, row = (idx / QW) % ROWS, ci = idx / (QW * ROWS);
+            if (MODE == MODE_FWD) {
+                *reinterpret_cast<float4*>(xs + ci * PLANE + row * LDW + PADL + q * 4) = rg[i];
+            } else {
+                // expand 4 pooled gradients to the 8 full-resolution columns of image row hh
+                int pr = ((h0 - 1 + row) & 1) * 2;     // (hh & 1) also for hh = -1 (two's complement)
+                uint32_t m = rm[i];
+                float4 lo, hi;
+                lo.x = ((m & 0xff) == (uint32_t)pr) ? rg[i].x : 0.f;
+                lo.y = ((m & 0xff) == (uint32_t)pr + 1) ? rg[i].x : 0.f;
+                lo.z = (((m >> 8) & 0xff) == (uint32_t)pr) ? rg[i].y : 0.f;
+                lo.w = (((m >> 8) & 0xff) == (uint32_t)pr + 1) ? rg[i].y : 0.f;
+                hi.x = (((m >> 16) & 0xff) == (uint32_t)pr) ? rg[i].z : 0.f;
+                hi.y = (((m >> 16) & 0xff) == (uint32_t)pr + 1) ? rg[i].z : 0.f;
+                hi.z = ((m >> 24) == (uint32_t)pr) ? rg[i].w : 0.f;
+                hi.w = ((m >> 24) == (uint32_t)pr + 1) ? rg[i].w : 0.f;
+                float* d = xs + ci * PLANE + row * LDW + PADL + q * 8;
+                *reinterpret_cast<float4*>(d) = lo;
+                *reinterpret_cast<float4*>(d + 4) = hi;
+            }
+        }
+    };
+
+    // wave tile: row pair rp, 32-column segment seg
+    constexpr int SEGS = W / 32;
+    const int rp = wave / SEGS, seg = wave % SEGS;
+    const int r0 = 2 * rp, c0 = seg * 32;
+    const int j = lane & 31, kh2 = lane >> 5;
+    const int xbase = kh2 * PLANE + r0 * LDW + c0 + j + PADL - 1;
+    const int wbase = kh2 * COUT + j;
+
+    f32x16 acc[MT][2];
+
+    int strip = blockIdx.x;
+    if (strip < nstrips) {
+        load_stage(strip, 0);
+        store_stage(strip, 0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (; strip < nstrips; strip += gridDim.x) {
+        const int b = strip / strips_per_img, h0 = (strip % strips_per_img) * TH;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float bv = 0.f;
+                if (MODE == MODE_FWD) bv = p.bias[mt * 32 + mfma_row(r, lane)];
+                acc[mt][0][r] = bv;
+                acc[mt][1][r] = bv;
+            }
+        }
+        for (int chunk = 0; chunk < NCH; ++chunk) {
+            // prefetch the next stage into registers
+            int nstrip = strip, nchunk = chunk + 1;
+            if (nchunk == NCH) { nchunk = 0; nstrip = strip + gridDim.x; }
+            const bool have_next = nstrip < nstrips;
+            if (have_next) load_stage(nstrip, nchunk);
+
+            const float* xs = Xs + buf * CHUNK + xbase;
+            const float* ws = Ws + (chunk * CC) * COUT + wbase;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap % 3;
+#pragma unroll
+                for (int cp = 0; cp < CC / 2; ++cp) {
+                    float a[MT], bb[2];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) a[mt] = ws[(tap * CINP + 2 * cp) * COUT + mt * 32];
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) bb[n] = xs[(2 * cp) * PLANE + (n + kh) * LDW + kw];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) acc[mt][n] = mfma32(a[mt], bb[n], acc[mt][n]);
+                }
+            }
+            if (have_next) store_stage(nstrip, buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        // ---- epilogue ----
+        if (MODE == MODE_FWD) {
+            const int ph = (h0 + r0) >> 1, Hp = H / 2, Wp = W / 2;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v00 = acc[mt][0][r], v10 = acc[mt][1][r];
+                    float v01 = __shfl_xor(v00, 1), v11 = __shfl_xor(v10, 1);
+                    // PyTorch max-pool keeps the FIRST maximum in (h, w) scan order
+                    float m = v00; int am = 0;
+                    if (v01 > m) { m = v01; am = 1; }
+                    if (v10 > m) { m = v10; am = 2; }
+                    if (v11 > m) { m = v11; am = 3; }
+                    if ((j & 1) == 0) {
+                        int co = mt * 32 + mfma_row(r, lane);
+                        long o = (((long)b * COUT + co) * Hp + ph) * Wp + ((c0 + j) >> 1);
+                        p.y[o] = m > 0.f ? m : 0.f;
+                        p.ymask[o] = m > 0.f ? (uint8_t)am : (uint8_t)4;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int co = mt * 32 + mfma_row(r, lane);
+                        p.y[(((long)b * COUT + co) * H + h0 + r0 + n) * W + c0 + j] = acc[mt][n][r];
+                    }
+        }
+    }
+}
+
+// Wt[tap][ci][co] from the reference layout W[co][ci][kh][kw].
+//  FWD   : Wt[tap][ci][co]      = W[co][ci][tap]                       (CINP >= CIN zero padded)
+//  DGRAD : Wt[tap][c=co][o=ci]  = W[co][ci][8 - tap]   (kernel flipped, channel roles swapped)
+__global__ void conv_prep_weights_kernel(const float* w, float* wt, int cin, int cout, int cinp_fwd, int mode) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mode == MODE_FWD) {
+        int total = 9 * cinp_fwd * cout;
+        if (idx >= total) return;
+        int co = idx % cout, ci = (idx / cout) % cinp_fwd, tap = idx / (cout * cinp_fwd);
+        wt[idx] = ci < cin ? w[((long)co * cin + ci) * 9 + tap] : 0.f;
+    } else {
+        int total = 9 * cout * cin;     // [tap][cout as input channel][cin as output channel]
+        if (idx >= total) return;
+        int o = idx % cin, c = (idx / cin) % cout, tap = idx / (cin * cout);
+        wt[idx] = w[((long)c * cin + o) * 9 + (8 - tap)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient, CIN = 32: M = co (COUT/32 tiles), N = (tap, ci) 9 tiles of 32, K = pixels.
+// waves: mt = wave % MT, kg = wave / MT; a strip is 2 output rows; each k-group owns 256/KG... pixels
+// ------------------------------------------------------------------------------------------------
+struct WgradParams {
+    const float* x;        // layer input [B][CIN][H][W]
+    const float* gy;       // pooled output gradient [B][COUT][H/2][W/2]
+    const uint8_t* mask;   // [B][COUT][H/2][W/2]
+    float* slab;           // [grid][COUT][9*32]  (CIN = 32)  or [grid][32][32] (CIN = 3)
+    float* bslab;          // [grid][COUT] bias-gradient partials
+    int B, H;
+};
+
+template <int COUT, int W>
+struct WgCfg {
+    static constexpr int CIN = 32;
+    static constexpr int MT = COUT / 32;
+    static constexpr int KG = 8 / MT;                // k-groups of waves
+    static constexpr int NPIX = 2 * W;               // pixels per strip (2 rows)
+    static constexpr int LDP = NPIX + 1;             // dY row stride: = 1 mod 32 -> conflict-free
+    static constexpr int LDW = W + 8;
+    static constexpr int PLANE = 4 * LDW + 1;        // odd: lanes = channels hit distinct banks
+    static constexpr int DYF = COUT * LDP;
+    static constexpr int XF = CIN * PLANE;
+    static constexpr int BUF = DYF + XF;
+    static constexpr size_t LDS_BYTES = (size_t)2 * BUF * sizeof(float);
+    static constexpr int PIX_PER_KG = NPIX / KG;
+    static_assert(NPIX % KG == 0 && PIX_PER_KG % 2 == 0 && W % PIX_PER_KG == 0, "k-group split");
+};
+
+template <int COUT, int W>
+__global__ __launch_bounds__(512) void conv_wgrad32_kernel(WgradParams p) {
+    using C = WgCfg<COUT, W>;
+    constexpr int CIN = 32, MT = C::MT, KG = C::KG, LDP = C::LDP, LDW = C::LDW, PLANE = C::PLANE;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int H = p.H, Hp = H / 2, Wp = W / 2;
+    const int strips_per_img = H / 2;
+    const int nstrips = p.B * strips_per_img;
+
+    for (int i = t; i < 2 * C::BUF; i += 512) smem[i] = 0.f;
+    __syncthreads();
+
+    // loader: dY items (co, q4): COUT * (Wp/4); X items (ci, row, q): 32 * 4 * (W/4)
+    constexpr int DY_ITEMS = COUT * (Wp / 4);
+    constexpr int DY_NIT = (DY_ITEMS + 511) / 512;
+    constexpr int X_ITEMS = CIN * 4 * (W / 4);
+    constexpr int X_NIT = (X_ITEMS + 511) / 512;
+    float4 gq[DY_NIT]; uint32_t mq[DY_NIT]; float4 xq[X_NIT];
+    float bsum[DY_NIT];      // bias-gradient partial of this thread's fixed channel
+#pragma unroll
+    for (int i = 0; i < DY_NIT; ++i) bsum[i] = 0.f;
+    auto load_stage = [&](int strip) {
+        const int b = strip / strips_per_img, ph = strip % strips_per_img, h0 = ph * 2;
+#pragma unroll
+        for (int i = 0; i < DY_NIT; ++i) {
+            int idx = t + i * 512;
+            gq[i] = make_float4(0.f, 0.f, 0.f, 0.f); mq[i] = 0x04040404u;
+            if (idx < DY_ITEMS) {
+                int q = idx % (Wp / 4), co = idx / (Wp / 4);
+                long off = (((long)b * COUT + co) * Hp + ph) * Wp + q * 4;
+                gq[i] = *reinterpret_cast<const float4*>(p.gy + off);
+                mq[i] = *reinterpret_cast<const uint32_t*>(p.mask + off);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < X_NIT; ++i) {
+            int idx = t + i * 512;
+            xq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < X_ITEMS) {
+                int q = idx % (W / 4), row = (idx / (W / 4)) % 4, ci = idx / (W / 4 * 4);
+                int hh = h0 - 1 + row;
+                if (hh >= 0 && hh < H)
+                    xq[i] = *reinterpret_cast<const float4*>(p.x + (((long)b * CIN + ci) * H + hh) * W + q * 4);
+            }
+        }
+    };
+    auto store_stage = [&](int buf) {
+        float* dys = smem + buf * C::BUF;
+        float* xs = dys + C::DYF;
+#pragma unroll
+        for (int i = 0; i < DY_NIT; ++i) {
+            int idx = t + i * 512;
+            if (idx >= DY_ITEMS) continue;
+            int q = idx % (Wp / 4), co = idx / (Wp / 4);
+            float* d = dys + co * LDP + q * 8;
+            float g[4] = {gq[i].x, gq[i].y, gq[i].z, gq[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t m = (mq[i] >> (8 * e)) & 0xff;
+                bsum[i] += m < 4 ? g[e] : 0.f;
+                d[2 * e] = m == 0 ? g[e] : 0.f;
+                d[2 * e + 1] = m == 1 ? g[e] : 0.f;
+                d[W + 2 * e] = m == 2 ? g[e] : 0.f;
+                d[W + 2 * e + 1] = m == 3 ? g[e] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < X_NIT; ++i) {
+            int idx = t + i * 512;
+            if (idx >= X_ITEMS) continue;
+            int q = idx % (W / 4), row = (idx / (W / 4)) % 4, ci = idx / (W / 4 * 4);
+            float* d = xs + ci * PLANE + row * LDW + PADL + q * 4;
+            d[0] = xq[i].x; d[1] = xq[i].y; d[2] = xq[i].z; d[3] = xq[i].w;
+        }
+    };
+
+    const int mt = wave % MT, kg = wave / MT;
+    const int pix0 = kg * C::PIX_PER_KG;                 // first pixel of this k-group in the strip
+    const int prow = pix0 / W, pcol = pix0 % W;
+    const int j = lane & 31, k2 = lane >> 5;
+    const int abase = (mt * 32 + j) * LDP + pix0 + k2;
+    const int bbase = j * PLANE + prow * LDW + pcol + k2 + PADL - 1;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    int strip = blockIdx.x;
+    if (strip < nstrips) { load_stage(strip); store_stage(0); }
+    __syncthreads();
+    int buf = 0;
+    for (; strip < nstrips; strip += gridDim.x) {
+        const int nstrip = strip + gridDim.x;
+        if (nstrip < nstrips) load_stage(nstrip);
+        const float* dys = smem + buf * C::BUF + abase;
+        const float* xs = smem + buf * C::BUF + C::DYF + bbase;
+#pragma unroll 4
+        for (int pp = 0; pp < C::PIX_PER_KG; pp += 2) {
+            float a = dys[pp];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                float bv = xs[(tap / 3) * LDW + (tap % 3) + pp];
+                acc[tap] = mfma32(a, bv, acc[tap]);
+            }
+        }
+        if (nstrip < nstrips) store_stage(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // reduce the k-groups through LDS (staging buffers are free now): group g -> LDS, group 0 adds
+    float* red = smem;     // MT * 9 * 1024 floats <= 2*BUF
+    for (int g = 1; g < KG; ++g) {
+        if (kg == g) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((mt * 9 + tap) * 16 + r) * 64 + lane] = acc[tap][r];
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tap][r] += red[((mt * 9 + tap) * 16 + r) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    // bias-gradient partials: the Wp/4 consecutive lanes of one channel reduce by shuffles
+#pragma unroll
+    for (int i = 0; i < DY_NIT; ++i) {
+        float v = bsum[i];
+#pragma unroll
+        for (int o = 1; o < Wp / 4; o <<= 1) v += __shfl_xor(v, o);
+        int idx = t + i * 512;
+        if (idx < DY_ITEMS && idx % (Wp / 4) == 0) p.bslab[(long)blockIdx.x * COUT + idx / (Wp / 4)] = v;
+    }
+    if (kg == 0) {
+        float* s = p.slab + (long)blockIdx.x * COUT * 288;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int co = mt * 32 + mfma_row(r, lane);
+                s[co * 288 + tap * 32 + j] = acc[tap][r];
+            }
+    }
+}
+
+// dW[co][ci][tap] = sum_g slab[g][co][tap*32+ci], db[co] = sum_g bslab[g][co]   (fixed order)
+__global__ __launch_bounds__(256) void conv_wgrad32_reduce_kernel(const float* slab, const float* bslab, float* dw,
+                                                                 float* db, int nslab, int cout) {
+    __shared__ float part[256];
+    const int total = cout * 288;
+    const int nl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + nl;          // [0, total) weights, [total, total + cout) biases
+    float s = 0.f;
+    int per = (nslab + 3) / 4;
+    int g0 = grp * per, g1 = min(nslab, g0 + per);
+    if (n < total) {
+        for (int g = g0; g < g1; ++g) s += slab[(long)g * total + n];
+    } else if (n < total + cout) {
+        for (int g = g0; g < g1; ++g) s += bslab[(long)g * cout + (n - total)];
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (grp == 0 && n < total + cout) {
+        float v = part[nl] + part[64 + nl] + part[128 + nl] + part[192 + nl];
+        if (n < total) {
+            int co = n / 288, rem = n % 288, tap = rem / 32, ci = rem % 32;
+            dw[((long)co * 32 + ci) * 9 + tap] = v;
+        } else {
+            db[n - total] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient, CIN = 3, COUT = 32: one 32 x 32 MFMA tile (27 of 32 columns used), K = pixels.
+// ------------------------------------------------------------------------------------------------
+template <int W>
+struct Wg3Cfg {
+    static constexpr int COUT = 32, CIN = 3;
+    static constexpr int NPIX = 2 * W;
+    static constexpr int LDP = NPIX + 1;
+    static constexpr int LDW = W + 8 + 3;            // 139 for W=128: = 11 mod 32 (taps spread over banks)
+    static constexpr int PLANE = 4 * LDW + 5;
+    static constexpr int DYF = COUT * LDP;
+    static constexpr int XF = CIN * PLANE + 8;
+    static constexpr int BUF = DYF + XF;
+    static constexpr size_t LDS_BYTES = (size_t)2 * BUF * sizeof(float);
+};
+
+template <int W>
+__global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradParams p) {
+    using C = Wg3Cfg<W>;
+    constexpr int COUT = 32, CIN = 3, LDP = C::LDP, LDW = C::LDW, PLANE = C::PLANE;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int H = p.H, Hp = H / 2, Wp = W / 2;
+    const int strips_per_img = H / 2;
+    const int nstrips = p.B * strips_per_img;
+    for (int i = t; i < 2 * C::BUF; i += 512) smem[i] = 0.f;
+    __syncthreads();
+
+    constexpr int DY_ITEMS = COUT * (Wp / 4);
+    constexpr int DY_NIT = (DY_ITEMS + 511) / 512;
+    constexpr int X_ITEMS = CIN * 4 * (W / 4);
+    constexpr int X_NIT = (X_ITEMS + 511) / 512;
+    float4 gq[DY_NIT]; uint32_t mq[DY_NIT]; float4 xq[X_NIT];
+    float bsum[DY_NIT];      // bias-gradient partial of this thread's fixed channel
+#pragma unroll
+    for (int i = 0; i < DY_NIT; ++i) bsum[i] = 0.f;
+    auto load_stage = [&](int strip) {
+        const int b = strip / strips_per_img, ph = strip % strips_per_img, h0 = ph * 2;
+#pragma unroll
+        for (int i = 0; i < DY_NIT; ++i) {
+            int idx = t + i * 512;
+            gq[i] = make_float4(0.f, 0.f, 0.f, 0.f); mq[i] = 0x04040404u;
+            if (idx < DY_ITEMS) {
+                int q = idx % (Wp / 4), co = idx / (Wp / 4);
+                long off = (((long)b * COUT + co) * Hp + ph) * Wp + q * 4;
+                gq[i] = *reinterpret_cast<const float4*>(p.gy + off);
+                mq[i] = *reinterpret_cast<const uint32_t*>(p.mask + off);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < X_NIT; ++i) {
+            int idx = t + i * 512;
+            xq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < X_ITEMS) {
+                int q = idx % (W / 4), row = (idx / (W / 4)) % 4, ci = idx / (W / 4 * 4);
+                int hh = h0 - 1 + row;
+                if (hh >= 0 && hh < H)
+                    xq[i] = *reinterpret_cast<const float4*>(p.x + (((long)b * CIN + ci) * H + hh) * W + q * 4);
+            }
+        }
+    };
+    auto store_stage = [&](int buf) {
+        float* dys = smem + buf * C::BUF;
+        float* xs = dys + C::DYF;
+#pragma unroll
+        for (int i = 0; i < DY_NIT; ++i) {
+            int idx = t + i * 512;
+            if (idx >= DY_ITEMS) continue;
+            int q = idx % (Wp / 4), co = idx / (Wp / 4);
+            float* d = dys + co * LDP + q * 8;
+            float g[4] = {gq[i].x, gq[i].y, gq[i].z, gq[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t m = (mq[i] >> (8 * e)) & 0xff;
+                bsum[i] += m < 4 ? g[e] : 0.f;
+                d[2 * e] = m == 0 ? g[e] : 0.f;
+                d[2 * e + 1] = m == 1 ? g[e] : 0.f;
+                d[W + 2 * e] = m == 2 ? g[e] : 0.f;
+                d[W + 2 * e + 1] = m == 3 ? g[e] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < X_NIT; ++i) {
+            int idx = t + i * 512;
+            if (idx >= X_ITEMS) continue;
+            int q = idx % (W / 4), row = (idx / (W / 4)) % 4, ci = idx / (W / 4 * 4);
+            float* d = xs + ci * PLANE + row * LDW + PADL + q * 4;
+            d[0] = xq[i].x; d[1] = xq[i].y; d[2] = xq[i].z; d[3] = xq[i].w;
+        }
+    };
+
+    constexpr int PIX_PER_W = C::NPIX / 8;             // pixels per wave per strip
+    const int pix0 = wave * PIX_PER_W;
+    const int prow = pix0 / W, pcol = pix0 % W;
+    const int j = lane & 31, k2 = lane >> 5;
+    // column j <-> (ci, kh, kw) = (j / 9, (j % 9) / 3, j % 3) for j < 27
+    const int jj = j < 27 ? j : 0;
+    const int boff = (jj / 9) * PLANE + ((jj % 9) / 3) * LDW + (jj % 3);
+    const int abase = j * LDP + pix0 + k2;
+    const int bbase = boff + prow * LDW + pcol + k2 + PADL - 1;
+    const float bsel = j < 27 ? 1.f : 0.f;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    int strip = blockIdx.x;
+    if (strip < nstrips) { load_stage(strip); store_stage(0); }
+    __syncthreads();
+    int buf = 0;
+    for (; strip < nstrips; strip += gridDim.x) {
+        const int nstrip = strip + gridDim.x;
+        if (nstrip < nstrips) load_stage(nstrip);
+        const float* dys = smem + buf * C::BUF + abase;
+        const float* xs = smem + buf * C::BUF + C::DYF + bbase;
+#pragma unroll
+        for (int pp = 0; pp < PIX_PER_W; pp += 2) acc = mfma32(dys[pp], xs[pp] * bsel, acc);
+        if (nstrip < nstrips) store_stage(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    float* red = smem;
+    for (int g = 1; g < 8; ++g) {
+        if (wave == g) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[r * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += red[r * 64 + lane];
+        }
+        __syncthreads();
+    }
+    // bias-gradient partials: the Wp/4 consecutive lanes of one channel reduce by shuffles
+#pragma unroll
+    for (int i = 0; i < DY_NIT; ++i) {
+        float v = bsum[i];
+#pragma unroll
+        for (int o = 1; o < Wp / 4; o <<= 1) v += __shfl_xor(v, o);
+        int idx = t + i * 512;
+        if (idx < DY_ITEMS && idx % (Wp / 4) == 0) p.bslab[(long)blockIdx.x * COUT + idx / (Wp / 4)] = v;
+    }
+    if (wave == 0) {
+        float* s = p.slab + (long)blockIdx.x * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[mfma_row(r, lane) * 32 + j] = acc[r];
+    }
+}
+
+// dW[co][ci][kh][kw] (= [co][27]) = sum_g slab[g][co][j], j = ci*9 + tap; db[co] = sum_g bslab[g][co]
+__global__ __launch_bounds__(256) void conv_wgrad3_reduce_kernel(const float* slab, const float* bslab, float* dw,
+                                                                float* db, int nslab) {
+    int n = blockIdx.x * 256 + threadIdx.x;     // 0..1023 weights, 1024..1055 biases
+    float s = 0.f;
+    if (n < 1024) {
+        for (int g = 0; g < nslab; ++g) s += slab[(long)g * 1024 + n];
+        int co = n / 32, jx = n % 32;
+        if (jx < 27) dw[co * 27 + jx] = s;
+    } else if (n < 1024 + 32) {
+        for (int g = 0; g < nslab; ++g) s += bslab[(long)g * 32 + (n - 1024)];
+        db[n - 1024] = s;
+    }
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        bbbp_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", bytes, hipGetErrorString(e));
+        return BBBP_ERR_HIP;
+    }
+    return BBBP_OK;
+}
+
+template <int CIN, int COUT, int W, int MODE>
+int launch_conv(const ConvParams& p, hipStream_t st) {
+    using C = ConvCfg<CIN, COUT, W, MODE>;
+    int rc = set_lds(conv3x3_kernel<CIN, COUT, W, MODE>, C::LDS_BYTES);
+    if (rc) return rc;
+    int nstrips = p.B * (p.H / C::TH);
+    int per_cu = (int)((160 * 1024) / C::LDS_BYTES);
+    if (per_cu > 2) per_cu = 2;
+    if (per_cu < 1) per_cu = 1;
+    int grid = bbbp_num_cus() * per_cu;
+    if (grid > nstrips) grid = nstrips;
+    hipLaunchKernelGGL((conv3x3_kernel<CIN, COUT, W, MODE>), dim3(grid), dim3(512), C::LDS_BYTES, st, p);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+struct Shape { int cin, cout, w; };
+inline bool supported(int cin, int cout, int h, int w) {
+    return h == w && ((cin == 3 && cout == 32 && w == 128) || (cin == 32 && cout == 64 && w == 64));
+}
+
+}  // namespace
+
+// workspace: prepped weights (fwd / dgrad) or partial slabs (wgrad)
+extern "C" size_t bbbp_conv3x3_workspace_bytes(int B, int cin, int cout, int H, int W) {
+    (void)B; (void)H; (void)W;
+    size_t prep = (size_t)9 * (cin < 8 ? 4 : cin) * cout * sizeof(float);
+    size_t prep_d = (size_t)9 * cout * cin * sizeof(float);
+    size_t slab = (size_t)2 * 256 * ((cin == 3 ? 1024 : (size_t)cout * 288) + cout) * sizeof(float);
+    size_t m = prep > prep_d ? prep : prep_d;
+    return align_up(m > slab ? m : slab, 256);
+}
+
+extern "C" int bbbp_conv3x3_relu_pool_fwd(void* stream, const float* x, const float* w, const float* bias,
+                                          float* y, uint8_t* mask, int B, int cin, int cout, int H, int W,
+                                          void* workspace, size_t workspace_bytes) {
+    BBBP_CHECK_ARG(supported(cin, cout, H, W), "conv fwd: unsupported shape cin=%d cout=%d H=%d W=%d", cin, cout, H, W);
+    BBBP_CHECK_ARG(x && w && bias && y && mask && workspace, "conv fwd: null pointer");
+    if (B == 0) return BBBP_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int cinp = cin < 8 ? 4 : cin;
+    size_t need = (size_t)9 * cinp * cout * sizeof(float);
+    BBBP_CHECK_ARG(workspace_bytes >= need, "conv fwd: workspace %zu < %zu", workspace_bytes, need);
+    float* wt = static_cast<float*>(workspace);
+    int total = 9 * cinp * cout;
+    hipLaunchKernelGGL(conv_prep_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, wt, cin, cout, cinp, MODE_FWD);
+    BBBP_CHECK_LAUNCH();
+    ConvParams p{x, nullptr, wt, bias, y, mask, B, H};
+    if (cin == 3) return launch_conv<3, 32, 128, MODE_FWD>(p, st);
+    return launch_conv<32, 64, 64, MODE_FWD>(p, st);
+}
+
+// dx[B][cin][H][W] from the pooled output gradient gy[B][cout][H/2][W/2] and the forward mask
+extern "C" int bbbp_conv3x3_relu_pool_bwd_data(void* stream, const float* gy, const uint8_t* mask, const float* w,
+                                               float* dx, int B, int cin, int cout, int H, int W,
+                                               void* workspace, size_t workspace_bytes) {
+    BBBP_CHECK_ARG(cin == 32 && cout == 64 && H == 64 && W == 64,
+                   "conv bwd_data: unsupported shape cin=%d cout=%d H=%d W=%d", cin, cout, H, W);
+    BBBP_CHECK_ARG(gy && mask && w && dx && workspace, "conv bwd_data: null pointer");
+    if (B == 0) return BBBP_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    size_t need = (size_t)9 * cout * cin * sizeof(float);
+    BBBP_CHECK_ARG(workspace_bytes >= need, "conv bwd_data: workspace %zu < %zu", workspace_bytes, need);
+    float* wt = static_cast<float*>(workspace);
+    int total = 9 * cout * cin;
+    hipLaunchKernelGGL(conv_prep_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, wt, cin, cout, 0, MODE_DGRAD);
+    BBBP_CHECK_LAUNCH();
+    // the data-gradient conv reads cout channels and writes cin channels
+    ConvParams p{gy, mask, wt, nullptr, dx, nullptr, B, H};
+    return launch_conv<64, 32, 64, MODE_DGRAD>(p, st);
+}
+
+// dw[cout][cin][3][3], db[cout] from the layer input x, the pooled output gradient and the mask
+extern "C" int bbbp_conv3x3_relu_pool_bwd_weight(void* stream, const float* x, const float* gy, const uint8_t* mask,
+                                                 float* dw, float* db, int B, int cin, int cout, int H, int W,
+                                                 void* workspace, size_t workspace_bytes) {
+    BBBP_CHECK_ARG(supported(cin, cout, H, W), "conv bwd_weight: unsupported shape cin=%d cout=%d H=%d W=%d", cin, cout, H, W);
+    BBBP_CHECK_ARG(x && gy && mask && dw && db && workspace, "conv bwd_weight: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (B == 0) {
+        BBBP_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)cout * cin * 9 * sizeof(float), st));
+        BBBP_CHECK_HIP(hipMemsetAsync(db, 0, (size_t)cout * sizeof(float), st));
+        return BBBP_OK;
+    }
+    int nstrips = B * (H / 2);
+    int grid = bbbp_num_cus();
+    if (grid > nstrips) grid = nstrips;
+    float* slab = static_cast<float*>(workspace);
+    WgradParams p{x, gy, mask, slab, nullptr, B, H};
+    if (cin == 3) {
+        using C = Wg3Cfg<128>;
+        grid = bbbp_num_cus() * 2;
+        if (grid > nstrips) grid = nstrips;
+        BBBP_CHECK_ARG(workspace_bytes >= (size_t)grid * (1024 + 32) * sizeof(float), "conv bwd_weight: workspace too small");
+        p.bslab = slab + (size_t)grid * 1024;
+        int rc = set_lds(conv_wgrad3_kernel<128>, C::LDS_BYTES);
+        if (rc) return rc;
+        hipLaunchKernelGGL((conv_wgrad3_kernel<128>), dim3(grid), dim3(512), C::LDS_BYTES, st, p);
+        BBBP_CHECK_LAUNCH();
+        hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3(5), dim3(256), 0, st, slab, p.bslab, dw, db, grid);
+        BBBP_CHECK_LAUNCH();
+    } else {
+        using C = WgCfg<64, 64>;
+        BBBP_CHECK_ARG(workspace_bytes >= (size_t)grid * cout * 289 * sizeof(float), "conv bwd_weight: workspace too small");
+        p.bslab = slab + (size_t)grid * cout * 288;
+        int rc = set_lds(conv_wgrad32_kernel<64, 64>, C::LDS_BYTES);
+        if (rc) return rc;
+        hipLaunchKernelGGL((conv_wgrad32_kernel<64, 64>), dim3(grid), dim3(512), C::LDS_BYTES, st, p);
+        BBBP_CHECK_LAUNCH();
+        hipLaunchKernelGGL(conv_wgrad32_reduce_kernel, dim3(cdiv(cout * 289, 64)), dim3(256), 0, st, slab, p.bslab, dw, db, grid, cout);
+        BBBP_CHECK_LAUNCH();
+    }
+    return BBBP_OK;
+}

@@ -1,0 +1,361 @@
+// Whole-model orchestration of MixedInputModel forward / backward on one MI355X: the host-side
+// schedule that strings the gfx950 kernels (gemm.hip, conv.hip, rowops.hip) together on one HIP stream
+// with a single caller-provided workspace (no allocation, no synchronisation: graph-capturable).
+//
+// Reference: MixedInputModel.forward, Models/multi_input_data_regression_opt_transformer_cnn_20250113.py:109-119
+// (R below) and its autograd under loss.backward() (R:190).  The encoder is called with a [B,1,F]
+// tensor and batch_first=False (R:110-111), so self-attention runs ACROSS the mini-batch: S = B, N = 1.
+#include "common.h"
+#include "bbbp_hip.h"
+
+namespace {
+
+constexpr int IMG = 128, C1 = 32, C2 = 64, FC = 128, NHEADS_FUSION = 4, FUS_HID = 128;
+constexpr int H1 = 256, H2 = 128, H3 = 64;
+constexpr int COMB = 2 * FC;          // 256
+constexpr int IMG_FLAT = C2 * (IMG / 4) * (IMG / 4);   // 65536
+
+// parameter indices in named_parameters() order
+enum { L_INW = 0, L_INB, L_OUTW, L_OUTB, L_W1, L_B1, L_W2, L_B2, L_N1W, L_N1B, L_N2W, L_N2B, L_COUNT };
+struct PIdx {
+    int L;
+    explicit PIdx(int layers) : L(layers) {}
+    int layer(int l, int k) const { return l * L_COUNT + k; }
+    int base() const { return L * L_COUNT; }
+    int fpfc_w() const { return base() + 0; }
+    int fpfc_b() const { return base() + 1; }
+    int c1_w() const { return base() + 2; }
+    int c1_b() const { return base() + 3; }
+    int c2_w() const { return base() + 4; }
+    int c2_b() const { return base() + 5; }
+    int ifc_w() const { return base() + 6; }
+    int ifc_b() const { return base() + 7; }
+    int fus(int h, int k) const { return base() + 8 + h * 4 + k; }     // k: 0 W1, 1 b1, 2 w2, 3 b2
+    int fc0_w() const { return base() + 24; }
+    int fc0_b() const { return base() + 25; }
+    int bn_w() const { return base() + 26; }
+    int bn_b() const { return base() + 27; }
+    int fc3_w() const { return base() + 28; }
+    int fc3_b() const { return base() + 29; }
+    int fc5_w() const { return base() + 30; }
+    int fc5_b() const { return base() + 31; }
+    int fc7_w() const { return base() + 32; }
+    int fc7_b() const { return base() + 33; }
+    int count() const { return base() + 34; }
+};
+
+struct Bump {
+    size_t off = 0;
+    size_t take(size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; }
+    size_t f(size_t n) { return take(n * sizeof(float)); }
+};
+
+struct LayerOff { size_t qkv, prob, ctx, z1, y1, hff, z2, y2, mean1, rstd1, mean2, rstd2; };
+
+struct Plan {
+    int B, F, NH, D, L, DFF;
+    bool drop;
+    LayerOff layer[32];
+    size_t pool1, mask1, pool2, mask2;
+    size_t combined, hid, attn, fused, h, hb, bn_mean, bn_rstd, h2, h3;
+    // temporaries
+    size_t pd, scratch, scratch_bytes;
+    size_t dA, dB, dqkv, dprob, dctx, dhff, dpool2, dpool1, dcomb, dfused, dlogit, dpre, dh, dhb, dh2, dh3;
+    size_t total;
+};
+
+int make_plan(const bbbp_mixed_desc* d, Plan* p) {
+    BBBP_CHECK_ARG(d, "null desc");
+    BBBP_CHECK_ARG(d->batch >= 1, "batch %d < 1", d->batch);
+    BBBP_CHECK_ARG(d->fingerprint_size >= 1 && d->nhead >= 1 && d->fingerprint_size % d->nhead == 0,
+                   "fingerprint_size %d not divisible by nhead %d", d->fingerprint_size, d->nhead);
+    BBBP_CHECK_ARG(d->num_layers >= 0 && d->num_layers <= 32, "num_layers %d not in [0, 32]", d->num_layers);
+    BBBP_CHECK_ARG(d->dim_feedforward >= 1, "dim_feedforward");
+    BBBP_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f, "dropout_p %f", d->dropout_p);
+    p->B = d->batch; p->F = d->fingerprint_size; p->NH = d->nhead; p->D = p->F / p->NH; p->L = d->num_layers;
+    p->DFF = d->dim_feedforward;
+    p->drop = d->training && d->dropout_p > 0.f;
+    const size_t B = p->B, F = p->F, NH = p->NH, DFF = p->DFF;
+    Bump b;
+    for (int l = 0; l < p->L; ++l) {
+        LayerOff& o = p->layer[l];
+        o.qkv = b.f(B * 3 * F); o.prob = b.f(NH * B * B); o.ctx = b.f(B * F);
+        o.z1 = b.f(B * F); o.y1 = b.f(B * F); o.hff = b.f(B * DFF); o.z2 = b.f(B * F); o.y2 = b.f(B * F);
+        o.mean1 = b.f(B); o.rstd1 = b.f(B); o.mean2 = b.f(B); o.rstd2 = b.f(B);
+    }
+    p->pool1 = b.f(B * C1 * (IMG / 2) * (IMG / 2)); p->mask1 = b.take(B * C1 * (IMG / 2) * (IMG / 2));
+    p->pool2 = b.f(B * IMG_FLAT); p->mask2 = b.take(B * IMG_FLAT);
+    p->combined = b.f(B * COMB); p->hid = b.f(NHEADS_FUSION * B * FUS_HID); p->attn = b.f(B * NHEADS_FUSION);
+    p->fused = b.f(B * COMB); p->h = b.f(B * H1); p->hb = b.f(B * H1); p->bn_mean = b.f(H1); p->bn_rstd = b.f(H1);
+    p->h2 = b.f(B * H2); p->h3 = b.f(B * H3);
+    p->pd = p->drop ? b.f(NH * B * B) : 0;
+    size_t cw = bbbp_conv3x3_workspace_bytes(p->B, 32, 64, 64, 64);
+    size_t cw1 = bbbp_conv3x3_workspace_bytes(p->B, 3, 32, 128, 128);
+    size_t sb = cw > cw1 ? cw : cw1;
+    size_t gw = bbbp_gemm_workspace_bytes(p->B, FC, IMG_FLAT, 1);
+    if (gw > sb) sb = gw;
+    if (sb < ((size_t)32 << 20)) sb = (size_t)32 << 20;
+    p->scratch_bytes = sb;
+    p->scratch = b.take(sb);
+    // backward temporaries
+    p->dA = b.f(B * F); p->dB = b.f(B * F); p->dqkv = b.f(B * 3 * F); p->dprob = b.f(NH * B * B); p->dctx = b.f(B * F);
+    p->dhff = b.f(B * DFF); p->dpool2 = b.f(B * IMG_FLAT); p->dpool1 = b.f(B * C1 * (IMG / 2) * (IMG / 2));
+    p->dcomb = b.f(B * COMB); p->dfused = b.f(B * COMB); p->dlogit = b.f(NHEADS_FUSION * B);
+    p->dpre = b.f(NHEADS_FUSION * B * FUS_HID); p->dh = b.f(B * H1); p->dhb = b.f(B * H1); p->dh2 = b.f(B * H2);
+    p->dh3 = b.f(B * H3);
+    p->total = b.off;
+    return BBBP_OK;
+}
+
+struct Ctx {
+    hipStream_t st;
+    char* ws;
+    const Plan* p;
+    float* f(size_t off) const { return reinterpret_cast<float*>(ws + off); }
+    uint8_t* u8(size_t off) const { return reinterpret_cast<uint8_t*>(ws + off); }
+    void* scratch() const { return ws + p->scratch; }
+    size_t scratch_bytes() const { return p->scratch_bytes; }
+};
+
+#define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+// y[M,N] = act(x[M,K] W[N,K]^T + b) + res
+int linear_fwd(const Ctx& c, const float* x, int ldx, const float* W, const float* b, float* y, int ldy, int M, int N, int K,
+               int act, const float* res = nullptr, int ldr = 0) {
+    return bbbp_gemm_f32(c.st, 0, 1, M, N, K, 1.f, x, ldx, W, K, y, ldy, b, res, ldr, act, 1, 0, 0, 0, 0, c.scratch(),
+                         c.scratch_bytes());
+}
+// dx[M,K] = dy[M,N] W[N,K] + res
+int linear_bwd_input(const Ctx& c, const float* dy, int lddy, const float* W, float* dx, int lddx, int M, int N, int K,
+                     const float* res = nullptr, int ldr = 0) {
+    return bbbp_gemm_f32(c.st, 0, 0, M, K, N, 1.f, dy, lddy, W, K, dx, lddx, nullptr, res, ldr, 0, 1, 0, 0, 0, 0, c.scratch(),
+                         c.scratch_bytes());
+}
+// dW[N,K] = dy[M,N]^T x[M,K]
+int linear_bwd_weight(const Ctx& c, const float* dy, int lddy, const float* x, int ldx, float* dW, int M, int N, int K) {
+    return bbbp_gemm_f32(c.st, 1, 0, N, K, M, 1.f, dy, lddy, x, ldx, dW, K, nullptr, nullptr, 0, 0, 1, 0, 0, 0, 0, c.scratch(),
+                         c.scratch_bytes());
+}
+
+uint64_t site_seed(uint64_t seed, int layer, int site) { return seed * 0x9E3779B97F4A7C15ull + (uint64_t)(layer * 8 + site + 1); }
+
+}  // namespace
+
+extern "C" int bbbp_mixed_num_params(const bbbp_mixed_desc* d) {
+    if (!d) return -1;
+    return PIdx(d->num_layers).count();
+}
+
+extern "C" size_t bbbp_mixed_workspace_bytes(const bbbp_mixed_desc* d) {
+    Plan p;
+    if (make_plan(d, &p)) return 0;
+    return p.total;
+}
+
+extern "C" int bbbp_mixed_forward(void* stream, const bbbp_mixed_desc* d, const float* const* P, float* const* bn_running,
+                                  const float* fingerprint, const float* image, float* out, void* workspace,
+                                  size_t workspace_bytes) {
+    Plan plan;
+    TRY(make_plan(d, &plan));
+    BBBP_CHECK_ARG(P && fingerprint && image && out && workspace && bn_running, "mixed_forward: null pointer");
+    if (workspace_bytes < plan.total) {
+        bbbp_set_error("mixed_forward: workspace %zu < %zu bytes", workspace_bytes, plan.total);
+        return BBBP_ERR_WORKSPACE;
+    }
+    Ctx c{static_cast<hipStream_t>(stream), static_cast<char*>(workspace), &plan};
+    const PIdx ix(plan.L);
+    const int B = plan.B, F = plan.F, NH = plan.NH, D = plan.D, DFF = plan.DFF;
+    const float p_drop = plan.drop ? d->dropout_p : 0.f;
+    const float scale = 1.0f / sqrtf((float)D);
+
+    // ---- fingerprint branch: encoder (R:75-78, 110-111) --------------------------------------
+    const float* x = fingerprint;
+    for (int l = 0; l < plan.L; ++l) {
+        const LayerOff& o = plan.layer[l];
+        float* qkv = c.f(o.qkv); float* prob = c.f(o.prob); float* ctx = c.f(o.ctx);
+        TRY(linear_fwd(c, x, F, P[ix.layer(l, L_INW)], P[ix.layer(l, L_INB)], qkv, 3 * F, B, 3 * F, F, 0));
+        // scores_h = scale * Q_h K_h^T
+        TRY(bbbp_gemm_f32(c.st, 0, 1, B, B, D, scale, qkv, 3 * F, qkv + F, 3 * F, prob, B, nullptr, nullptr, 0, 0, NH, D, D,
+                          (long)B * B, 0, c.scratch(), c.scratch_bytes()));
+        float* pd = plan.drop ? c.f(plan.pd) : prob;
+        TRY(bbbp_softmax_fwd(c.st, prob, pd, (long)NH * B, B, p_drop, site_seed(d->seed, l, 0)));
+        // ctx_h = Pd_h V_h
+        TRY(bbbp_gemm_f32(c.st, 0, 0, B, D, B, 1.f, pd, B, qkv + 2 * F, 3 * F, ctx, F, nullptr, nullptr, 0, 0, NH, (long)B * B,
+                          D, D, 0, c.scratch(), c.scratch_bytes()));
+        float* z1 = c.f(o.z1); float* y1 = c.f(o.y1);
+        TRY(linear_fwd(c, ctx, F, P[ix.layer(l, L_OUTW)], P[ix.layer(l, L_OUTB)], z1, F, B, F, F, 0));
+        TRY(bbbp_layernorm_fwd(c.st, z1, x, y1, P[ix.layer(l, L_N1W)], P[ix.layer(l, L_N1B)], c.f(o.mean1), c.f(o.rstd1), B, F,
+                               1e-5f, p_drop, site_seed(d->seed, l, 1)));
+        float* hff = c.f(o.hff); float* z2 = c.f(o.z2); float* y2 = c.f(o.y2);
+        TRY(linear_fwd(c, y1, F, P[ix.layer(l, L_W1)], P[ix.layer(l, L_B1)], hff, DFF, B, DFF, F, BBBP_ACT_RELU));
+        if (plan.drop) TRY(bbbp_dropout(c.st, hff, hff, (long)B * DFF, p_drop, site_seed(d->seed, l, 2)));
+        TRY(linear_fwd(c, hff, DFF, P[ix.layer(l, L_W2)], P[ix.layer(l, L_B2)], z2, F, B, F, DFF, 0));
+        TRY(bbbp_layernorm_fwd(c.st, z2, y1, y2, P[ix.layer(l, L_N2W)], P[ix.layer(l, L_N2B)], c.f(o.mean2), c.f(o.rstd2), B, F,
+                               1e-5f, p_drop, site_seed(d->seed, l, 3)));
+        x = y2;
+    }
+    float* comb = c.f(plan.combined);
+    // fingerprint_fc (R:79-82, 112) -> combined[:, 0:128]
+    TRY(linear_fwd(c, x, F, P[ix.fpfc_w()], P[ix.fpfc_b()], comb, COMB, B, FC, F, BBBP_ACT_RELU));
+
+    // ---- image branch (R:84-94, 114-115) -------------------------------------------------------
+    float* pool1 = c.f(plan.pool1); float* pool2 = c.f(plan.pool2);
+    TRY(bbbp_conv3x3_relu_pool_fwd(c.st, image, P[ix.c1_w()], P[ix.c1_b()], pool1, c.u8(plan.mask1), B, 3, C1, IMG, IMG,
+                                   c.scratch(), c.scratch_bytes()));
+    TRY(bbbp_conv3x3_relu_pool_fwd(c.st, pool1, P[ix.c2_w()], P[ix.c2_b()], pool2, c.u8(plan.mask2), B, C1, C2, IMG / 2, IMG / 2,
+                                   c.scratch(), c.scratch_bytes()));
+    TRY(linear_fwd(c, pool2, IMG_FLAT, P[ix.ifc_w()], P[ix.ifc_b()], comb + FC, COMB, B, FC, IMG_FLAT, BBBP_ACT_RELU));
+
+    // ---- attention fusion (R:60-65, 117) -------------------------------------------------------
+    float* hid = c.f(plan.hid);
+    const float* w2[NHEADS_FUSION]; const float* b2[NHEADS_FUSION];
+    for (int h = 0; h < NHEADS_FUSION; ++h) {
+        TRY(linear_fwd(c, comb, COMB, P[ix.fus(h, 0)], P[ix.fus(h, 1)], hid + (size_t)h * B * FUS_HID, FUS_HID, B, FUS_HID, COMB,
+                       BBBP_ACT_TANH));
+        w2[h] = P[ix.fus(h, 2)]; b2[h] = P[ix.fus(h, 3)];
+    }
+    float* fused = c.f(plan.fused);
+    TRY(bbbp_fusion_combine_fwd(c.st, comb, hid, w2, b2, fused, c.f(plan.attn), B, COMB, FUS_HID, NHEADS_FUSION));
+
+    // ---- regression head (R:98-107, 118) -------------------------------------------------------
+    float* h = c.f(plan.h); float* hb = c.f(plan.hb); float* h2 = c.f(plan.h2); float* h3 = c.f(plan.h3);
+    TRY(linear_fwd(c, fused, COMB, P[ix.fc0_w()], P[ix.fc0_b()], h, H1, B, H1, COMB, BBBP_ACT_RELU));
+    TRY(bbbp_batchnorm1d_fwd(c.st, h, hb, P[ix.bn_w()], P[ix.bn_b()], bn_running[0], bn_running[1], c.f(plan.bn_mean),
+                             c.f(plan.bn_rstd), B, H1, 1e-5f, 0.1f, d->training));
+    TRY(linear_fwd(c, hb, H1, P[ix.fc3_w()], P[ix.fc3_b()], h2, H2, B, H2, H1, BBBP_ACT_RELU));
+    TRY(linear_fwd(c, h2, H2, P[ix.fc5_w()], P[ix.fc5_b()], h3, H3, B, H3, H2, BBBP_ACT_RELU));
+    TRY(linear_fwd(c, h3, H3, P[ix.fc7_w()], P[ix.fc7_b()], out, 1, B, 1, H3, 0));
+    return BBBP_OK;
+}
+
+extern "C" int bbbp_mixed_backward(void* stream, const bbbp_mixed_desc* d, const float* const* P, float* const* G,
+                                   const float* fingerprint, const float* image, const float* dout, void* workspace,
+                                   size_t workspace_bytes) {
+    Plan plan;
+    TRY(make_plan(d, &plan));
+    BBBP_CHECK_ARG(P && G && fingerprint && image && dout && workspace, "mixed_backward: null pointer");
+    if (workspace_bytes < plan.total) {
+        bbbp_set_error("mixed_backward: workspace %zu < %zu bytes", workspace_bytes, plan.total);
+        return BBBP_ERR_WORKSPACE;
+    }
+    Ctx c{static_cast<hipStream_t>(stream), static_cast<char*>(workspace), &plan};
+    const PIdx ix(plan.L);
+    const int B = plan.B, F = plan.F, NH = plan.NH, D = plan.D, DFF = plan.DFF;
+    const float p_drop = plan.drop ? d->dropout_p : 0.f;
+    const float inv_keep = plan.drop ? 1.f / (1.f - p_drop) : 1.f;
+    const float scale = 1.0f / sqrtf((float)D);
+
+    float* comb = c.f(plan.combined); float* hid = c.f(plan.hid); float* fused = c.f(plan.fused);
+    float* h = c.f(plan.h); float* hb = c.f(plan.hb); float* h2 = c.f(plan.h2); float* h3 = c.f(plan.h3);
+    float* dh3 = c.f(plan.dh3); float* dh2 = c.f(plan.dh2); float* dhb = c.f(plan.dhb); float* dh = c.f(plan.dh);
+    float* dfused = c.f(plan.dfused); float* dcomb = c.f(plan.dcomb);
+
+    // ---- head ------------------------------------------------------------------------------------
+    // fc.7: out = h3 W7^T + b7
+    TRY(linear_bwd_weight(c, dout, 1, h3, H3, G[ix.fc7_w()], B, 1, H3));
+    // db7 = sum(dout) (act = 0 leaves dy untouched, so the const_cast is safe)
+    TRY(bbbp_bias_act_bwd(c.st, const_cast<float*>(dout), 1, nullptr, 0, G[ix.fc7_b()], B, 1, 0, 1.f));
+    TRY(linear_bwd_input(c, dout, 1, P[ix.fc7_w()], dh3, H3, B, 1, H3));
+    TRY(bbbp_bias_act_bwd(c.st, dh3, H3, h3, H3, G[ix.fc5_b()], B, H3, BBBP_ACT_RELU, 1.f));
+    TRY(linear_bwd_weight(c, dh3, H3, h2, H2, G[ix.fc5_w()], B, H3, H2));
+    TRY(linear_bwd_input(c, dh3, H3, P[ix.fc5_w()], dh2, H2, B, H3, H2));
+    TRY(bbbp_bias_act_bwd(c.st, dh2, H2, h2, H2, G[ix.fc3_b()], B, H2, BBBP_ACT_RELU, 1.f));
+    TRY(linear_bwd_weight(c, dh2, H2, hb, H1, G[ix.fc3_w()], B, H2, H1));
+    TRY(linear_bwd_input(c, dh2, H2, P[ix.fc3_w()], dhb, H1, B, H2, H1));
+    TRY(bbbp_batchnorm1d_bwd(c.st, dhb, h, P[ix.bn_w()], c.f(plan.bn_mean), c.f(plan.bn_rstd), dh, G[ix.bn_w()], G[ix.bn_b()], B,
+                             H1, d->training));
+    TRY(bbbp_bias_act_bwd(c.st, dh, H1, h, H1, G[ix.fc0_b()], B, H1, BBBP_ACT_RELU, 1.f));
+    TRY(linear_bwd_weight(c, dh, H1, fused, COMB, G[ix.fc0_w()], B, H1, COMB));
+    TRY(linear_bwd_input(c, dh, H1, P[ix.fc0_w()], dfused, COMB, B, H1, COMB));
+
+    // ---- attention fusion ------------------------------------------------------------------------
+    float* dlogit = c.f(plan.dlogit); float* dpre = c.f(plan.dpre);
+    const float* w2[NHEADS_FUSION];
+    for (int hh = 0; hh < NHEADS_FUSION; ++hh) w2[hh] = P[ix.fus(hh, 2)];
+    TRY(bbbp_fusion_combine_bwd(c.st, dfused, comb, hid, c.f(plan.attn), w2, dcomb, dlogit, dpre, B, COMB, FUS_HID, NHEADS_FUSION));
+    for (int hh = 0; hh < NHEADS_FUSION; ++hh) {
+        float* dl = dlogit + (size_t)hh * B;
+        float* dp = dpre + (size_t)hh * B * FUS_HID;
+        const float* hd = hid + (size_t)hh * B * FUS_HID;
+        TRY(linear_bwd_weight(c, dl, 1, hd, FUS_HID, G[ix.fus(hh, 2)], B, 1, FUS_HID));
+        TRY(bbbp_bias_act_bwd(c.st, dl, 1, nullptr, 0, G[ix.fus(hh, 3)], B, 1, 0, 1.f));
+        TRY(linear_bwd_weight(c, dp, FUS_HID, comb, COMB, G[ix.fus(hh, 0)], B, FUS_HID, COMB));
+        TRY(bbbp_bias_act_bwd(c.st, dp, FUS_HID, nullptr, 0, G[ix.fus(hh, 1)], B, FUS_HID, 0, 1.f));
+        TRY(linear_bwd_input(c, dp, FUS_HID, P[ix.fus(hh, 0)], dcomb, COMB, B, FUS_HID, COMB, dcomb, COMB));
+    }
+    // ReLU of both branch outputs + their bias gradients (combined = [fp_out | img_out])
+    TRY(bbbp_bias_act_bwd(c.st, dcomb, COMB, comb, COMB, G[ix.fpfc_b()], B, FC, BBBP_ACT_RELU, 1.f));
+    TRY(bbbp_bias_act_bwd(c.st, dcomb + FC, COMB, comb + FC, COMB, G[ix.ifc_b()], B, FC, BBBP_ACT_RELU, 1.f));
+
+    // ---- image branch ----------------------------------------------------------------------------
+    float* pool1 = c.f(plan.pool1); float* pool2 = c.f(plan.pool2);
+    float* dpool2 = c.f(plan.dpool2); float* dpool1 = c.f(plan.dpool1);
+    TRY(linear_bwd_weight(c, dcomb + FC, COMB, pool2, IMG_FLAT, G[ix.ifc_w()], B, FC, IMG_FLAT));
+    TRY(linear_bwd_input(c, dcomb + FC, COMB, P[ix.ifc_w()], dpool2, IMG_FLAT, B, FC, IMG_FLAT));
+    TRY(bbbp_conv3x3_relu_pool_bwd_weight(c.st, pool1, dpool2, c.u8(plan.mask2), G[ix.c2_w()], G[ix.c2_b()], B, C1, C2, IMG / 2,
+                                          IMG / 2, c.scratch(), c.scratch_bytes()));
+    TRY(bbbp_conv3x3_relu_pool_bwd_data(c.st, dpool2, c.u8(plan.mask2), P[ix.c2_w()], dpool1, B, C1, C2, IMG / 2, IMG / 2,
+                                        c.scratch(), c.scratch_bytes()));
+    TRY(bbbp_conv3x3_relu_pool_bwd_weight(c.st, image, dpool1, c.u8(plan.mask1), G[ix.c1_w()], G[ix.c1_b()], B, 3, C1, IMG, IMG,
+                                          c.scratch(), c.scratch_bytes()));
+
+    // ---- fingerprint branch ----------------------------------------------------------------------
+    const float* enc_out = plan.L > 0 ? c.f(plan.layer[plan.L - 1].y2) : fingerprint;
+    TRY(linear_bwd_weight(c, dcomb, COMB, enc_out, F, G[ix.fpfc_w()], B, FC, F));
+    float* dy = c.f(plan.dA);       // gradient wrt the current layer's output
+    float* dtmp = c.f(plan.dB);
+    if (plan.L > 0 || d->need_input_grad) TRY(linear_bwd_input(c, dcomb, COMB, P[ix.fpfc_w()], dy, F, B, FC, F));
+    float* dqkv = c.f(plan.dqkv); float* dprob = c.f(plan.dprob); float* dctx = c.f(plan.dctx); float* dhff = c.f(plan.dhff);
+    for (int l = plan.L - 1; l >= 0; --l) {
+        const LayerOff& o = plan.layer[l];
+        const float* xin = l > 0 ? c.f(plan.layer[l - 1].y2) : fingerprint;
+        float* qkv = c.f(o.qkv); float* prob = c.f(o.prob); float* ctx = c.f(o.ctx);
+        float* z1 = c.f(o.z1); float* y1 = c.f(o.y1); float* hff = c.f(o.hff); float* z2 = c.f(o.z2);
+        // norm2: dz2 -> dtmp (residual grad, flows to y1), dropped copy -> dctx (reused as d(ff out))
+        float* dff = plan.drop ? dctx : dtmp;
+        TRY(bbbp_layernorm_bwd(c.st, dy, z2, P[ix.layer(l, L_N2W)], c.f(o.mean2), c.f(o.rstd2), dtmp, plan.drop ? dff : nullptr,
+                               G[ix.layer(l, L_N2W)], G[ix.layer(l, L_N2B)], B, F, p_drop, site_seed(d->seed, l, 3)));
+        // linear2
+        TRY(linear_bwd_weight(c, dff, F, hff, DFF, G[ix.layer(l, L_W2)], B, F, DFF));
+        TRY(bbbp_bias_act_bwd(c.st, dff, F, nullptr, 0, G[ix.layer(l, L_B2)], B, F, 0, 1.f));
+        TRY(linear_bwd_input(c, dff, F, P[ix.layer(l, L_W2)], dhff, DFF, B, F, DFF));
+        // relu (+ dropout: hff is the post-dropout value, so hff > 0 <=> relu active and kept)
+        TRY(bbbp_bias_act_bwd(c.st, dhff, DFF, hff, DFF, G[ix.layer(l, L_B1)], B, DFF, BBBP_ACT_RELU, inv_keep));
+        TRY(linear_bwd_weight(c, dhff, DFF, y1, F, G[ix.layer(l, L_W1)], B, DFF, F));
+        // dy1 = dhff W1 + dz2  -> dy
+        TRY(linear_bwd_input(c, dhff, DFF, P[ix.layer(l, L_W1)], dy, F, B, DFF, F, dtmp, F));
+        // norm1: dz1 -> dtmp (flows to the layer input), dropped copy -> dsa
+        float* dsa = plan.drop ? dctx : dtmp;
+        TRY(bbbp_layernorm_bwd(c.st, dy, z1, P[ix.layer(l, L_N1W)], c.f(o.mean1), c.f(o.rstd1), dtmp, plan.drop ? dsa : nullptr,
+                               G[ix.layer(l, L_N1W)], G[ix.layer(l, L_N1B)], B, F, p_drop, site_seed(d->seed, l, 1)));
+        // out_proj
+        TRY(linear_bwd_weight(c, dsa, F, ctx, F, G[ix.layer(l, L_OUTW)], B, F, F));
+        TRY(bbbp_bias_act_bwd(c.st, dsa, F, nullptr, 0, G[ix.layer(l, L_OUTB)], B, F, 0, 1.f));
+        float* dctx2 = dy;     // dy is free now (its value was consumed by norm1 backward)
+        TRY(linear_bwd_input(c, dsa, F, P[ix.layer(l, L_OUTW)], dctx2, F, B, F, F));
+        // attention: Pd (dropped probabilities) is recomputed when dropout is on
+        const float* pdp = prob;
+        if (plan.drop) {
+            float* pd = c.f(plan.pd);
+            TRY(bbbp_dropout(c.st, prob, pd, (long)NH * B * B, p_drop, site_seed(d->seed, l, 0)));
+            pdp = pd;
+        }
+        // dV_h = Pd_h^T dctx_h  -> dqkv[:, 2F + hD]
+        TRY(bbbp_gemm_f32(c.st, 1, 0, B, D, B, 1.f, pdp, B, dctx2, F, dqkv + 2 * F, 3 * F, nullptr, nullptr, 0, 0, NH, (long)B * B,
+                          D, D, 0, c.scratch(), c.scratch_bytes()));
+        // dPd_h = dctx_h V_h^T
+        TRY(bbbp_gemm_f32(c.st, 0, 1, B, B, D, 1.f, dctx2, F, qkv + 2 * F, 3 * F, dprob, B, nullptr, nullptr, 0, 0, NH, D, D,
+                          (long)B * B, 0, c.scratch(), c.scratch_bytes()));
+        TRY(bbbp_softmax_bwd(c.st, dprob, prob, (long)NH * B, B, p_drop, site_seed(d->seed, l, 0)));
+        // dQ_h = scale dS_h K_h ; dK_h = scale dS_h^T Q_h
+        TRY(bbbp_gemm_f32(c.st, 0, 0, B, D, B, scale, dprob, B, qkv + F, 3 * F, dqkv, 3 * F, nullptr, nullptr, 0, 0, NH,
+                          (long)B * B, D, D, 0, c.scratch(), c.scratch_bytes()));
+        TRY(bbbp_gemm_f32(c.st, 1, 0, B, D, B, scale, dprob, B, qkv, 3 * F, dqkv + F, 3 * F, nullptr, nullptr, 0, 0, NH,
+                          (long)B * B, D, D, 0, c.scratch(), c.scratch_bytes()));
+        // in_proj
+        TRY(linear_bwd_weight(c, dqkv, 3 * F, xin, F, G[ix.layer(l, L_INW)], B, 3 * F, F));
+        TRY(bbbp_bias_act_bwd(c.st, dqkv, 3 * F, nullptr, 0, G[ix.layer(l, L_INB)], B, 3 * F, 0, 1.f));
+        if (l > 0 || d->need_input_grad) TRY(linear_bwd_input(c, dqkv, 3 * F, P[ix.layer(l, L_INW)], dy, F, B, 3 * F, F, dtmp, F));
+    }
+    return BBBP_OK;
+}

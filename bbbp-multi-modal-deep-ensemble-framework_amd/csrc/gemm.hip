@@ -1,0 +1,321 @@
+// fp32 GEMM on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32) for gfx950, with fused epilogues.
+//
+//   C[M,N] = act(alpha * op(A) * op(B) + bias[n]) (+ R[M,N])          row-major everywhere
+//
+// Replaces the ATen/oneDNN calls behind nn.Linear / F.linear and the attention matmuls of
+// nn.TransformerEncoderLayer on the reference's hot path (a3, a4, a8, a9, a10 and
+// their autograd counterparts a12).  Three storage layouts cover forward and backward:
+//   NT: A[M][K], B[N][K]   y = x W^T (Linear forward), S = Q K^T, dP = dO V^T
+//   NN: A[M][K], B[K][N]   dx = dy W, O = P V, dQ = dS K
+//   TN: A[K][M], B[K][N]   dW = dy^T x, dV = P^T dO, dK = dS^T Q
+// Both LDS tiles are k-major ([BK][BM], [BK][BN]) so that the MFMA operand fetch
+// (lane l: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]) is a conflict-free ds_read_b32 of 32 consecutive
+// floats per half-wave.  m-major global tiles are transposed on the way into LDS (row stride
+// = 2 mod 8 keeps those ds_write_b32 conflict-free).  Arbitrary M, N, K and leading dimensions
+// (the MACCS width is the prime 167): 16-byte loads when alignment allows, predicated scalar loads
+// otherwise, zero fill out of range.  Split-K writes raw partial slabs that a second kernel sums
+// in a fixed order (bit-reproducible; no float atomics).
+#include "common.h"
+#include "bbbp_hip.h"
+
+namespace {
+
+constexpr int BK = 16;
+
+struct GemmParams {
+    const float* A; const float* B; float* C;
+    const float* bias; const float* R;
+    int M, N, K;
+    int lda, ldb, ldc, ldr;
+    long sA, sB, sC, sR;     // batch strides (elements)
+    float alpha;
+    int act;                 // 0 none, 1 relu, 2 tanh
+    int splits, kchunk;      // split-K: K range per split (multiple of BK)
+    float* slab;             // [batch][split][M][N] when splits > 1
+    int vecA, vecB;          // 16-byte global loads allowed
+};
+
+__device__ __forceinline__ float4 ld4(const float* p, bool vec, int valid) {
+    if (vec && valid >= 4) return *reinterpret_cast<const float4*>(p);
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid > 0) r.x = p[0];
+    if (valid > 1) r.y = p[1];
+    if (valid > 2) r.z = p[2];
+    if (valid > 3) r.w = p[3];
+    return r;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == 1) return v > 0.f ? v : 0.f;
+    if (act == 2) return tanhf(v);
+    return v;
+}
+
+// LAYOUT 0: NT, 1: NN, 2: TN
+template <int BM, int BN, int LAYOUT>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+    constexpr bool A_KMAJ = (LAYOUT == 2);
+    constexpr bool B_KMAJ = (LAYOUT != 0);
+    constexpr int LDAS = BM + (A_KMAJ ? 4 : 2);
+    constexpr int LDBS = BN + (B_KMAJ ? 4 : 2);
+    constexpr int WM = BM / 2, WN = BN / 2;      // 2 x 2 waves
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int NA = BM * BK / 256 / 4;         // float4 per thread per operand tile
+    constexpr int NB = BN * BK / 256 / 4;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDAS + 2 * BK * LDBS];
+    float* As = smem;
+    float* Bs = smem + 2 * BK * LDAS;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int batch = blockIdx.z / p.splits, split = blockIdx.z % p.splits;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = split * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const float* A = p.A + (long)batch * p.sA;
+    const float* B = p.B + (long)batch * p.sB;
+
+    float4 ra[NA], rb[NB];
+
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (A_KMAJ) {       // global [K][M]: quads along m
+                constexpr int QPR = BM / 4;
+                int q = t % QPR, kr = t / QPR + i * (256 / QPR);
+                int k = k0 + kr, m = m0 + q * 4;
+                int valid = (k < kend) ? min(4, p.M - m) : 0;
+                ra[i] = ld4(A + (long)k * p.lda + m, p.vecA, valid);
+            } else {            // global [M][K]: quads along k
+                int row = (t >> 2) + i * 64, kq = t & 3;
+                int m = m0 + row, k = k0 + kq * 4;
+                int valid = (m < p.M) ? min(4, kend - k) : 0;
+                ra[i] = ld4(A + (long)m * p.lda + k, p.vecA, valid);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (B_KMAJ) {       // global [K][N]
+                constexpr int QPR = BN / 4;
+                int q = t % QPR, kr = t / QPR + i * (256 / QPR);
+                int k = k0 + kr, n = n0 + q * 4;
+                int valid = (k < kend) ? min(4, p.N - n) : 0;
+                rb[i] = ld4(B + (long)k * p.ldb + n, p.vecB, valid);
+            } else {            // global [N][K]
+                int row = (t >> 2) + i * 64, kq = t & 3;
+                int n = n0 + row, k = k0 + kq * 4;
+                int valid = (n < p.N) ? min(4, kend - k) : 0;
+                rb[i] = ld4(B + (long)n * p.ldb + k, p.vecB, valid);
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        float* as = As + buf * BK * LDAS;
+        float* bs = Bs + buf * BK * LDBS;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (A_KMAJ) {
+                constexpr int QPR = BM / 4;
+                int q = t % QPR, kr = t / QPR + i * (256 / QPR);
+                *reinterpret_cast<float4*>(as + kr * LDAS + q * 4) = ra[i];
+            } else {
+                int row = (t >> 2) + i * 64, kq = t & 3;
+                as[(kq * 4 + 0) * LDAS + row] = ra[i].x;
+                as[(kq * 4 + 1) * LDAS + row] = ra[i].y;
+                as[(kq * 4 + 2) * LDAS + row] = ra[i].z;
+                as[(kq * 4 + 3) * LDAS + row] = ra[i].w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (B_KMAJ) {
+                constexpr int QPR = BN / 4;
+                int q = t % QPR, kr = t / QPR + i * (256 / QPR);
+                *reinterpret_cast<float4*>(bs + kr * LDBS + q * 4) = rb[i];
+            } else {
+                int row = (t >> 2) + i * 64, kq = t & 3;
+                bs[(kq * 4 + 0) * LDBS + row] = rb[i].x;
+                bs[(kq * 4 + 1) * LDBS + row] = rb[i].y;
+                bs[(kq * 4 + 2) * LDBS + row] = rb[i].z;
+                bs[(kq * 4 + 3) * LDBS + row] = rb[i].w;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nt = (kend - kbeg + BK - 1) / BK;
+    if (nt > 0) {
+        load_tiles(kbeg);
+        store_tiles(0);
+    }
+    __syncthreads();
+    const int aoff = (lane >> 5) * LDAS + wm * WM + (lane & 31);
+    const int boff = (lane >> 5) * LDBS + wn * WN + (lane & 31);
+    for (int it = 0; it < nt; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nt) load_tiles(kbeg + (it + 1) * BK);
+        const float* as = As + buf * BK * LDAS + aoff;
+        const float* bs = Bs + buf * BK * LDBS + boff;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = as[kk * LDAS + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bs[kk * LDBS + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+        }
+        if (it + 1 < nt) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue
+    if (p.splits > 1) {
+        float* S = p.slab + ((long)batch * p.splits + split) * (long)p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int n = n0 + wn * WN + j * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int m = m0 + wm * WM + i * 32 + mfma_row(r, lane);
+                    if (m < p.M && n < p.N) S[(long)m * p.N + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+    float* C = p.C + (long)batch * p.sC;
+    const float* R = p.R ? p.R + (long)batch * p.sR : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int n = n0 + wn * WN + j * 32 + (lane & 31);
+            float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m0 + wm * WM + i * 32 + mfma_row(r, lane);
+                if (m < p.M && n < p.N) {
+                    float v = apply_act(p.alpha * acc[i][j][r] + bv, p.act);
+                    if (R) v += R[(long)m * p.ldr + n];
+                    C[(long)m * p.ldc + n] = v;
+                }
+            }
+        }
+}
+
+// sums the split-K slabs in split order and applies the epilogue
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
+    const long mn = (long)p.M * p.N;
+    const int batch = blockIdx.y;
+    const float* S = p.slab + (long)batch * p.splits * mn;
+    float* C = p.C + (long)batch * p.sC;
+    const float* R = p.R ? p.R + (long)batch * p.sR : nullptr;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < mn; idx += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < p.splits; ++k) s += S[(long)k * mn + idx];
+        int m = (int)(idx / p.N), n = (int)(idx % p.N);
+        float v = apply_act(p.alpha * s + (p.bias ? p.bias[n] : 0.f), p.act);
+        if (R) v += R[(long)m * p.ldr + n];
+        C[(long)m * p.ldc + n] = v;
+    }
+}
+
+template <int BM, int BN>
+void launch_tile(const GemmParams& p, int layout, dim3 grid, hipStream_t st) {
+    if (layout == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0>), grid, dim3(256), 0, st, p);
+    else if (layout == 1) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 2>), grid, dim3(256), 0, st, p);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// Split-K plan shared by the launcher and bbbp_gemm_workspace_bytes.
+static void gemm_plan(int M, int N, int K, int batch, int* tile, int* splits, int* kchunk) {
+    long t128 = (long)cdiv(M, 128) * cdiv(N, 128) * batch;
+    long t64 = (long)cdiv(M, 64) * cdiv(N, 64) * batch;
+    int ncu = bbbp_num_cus();
+    *tile = (t128 >= (long)ncu * 3 / 4) ? 128 : 64;
+    long tiles = (*tile == 128) ? t128 : t64;
+    int s = 1;
+    if (tiles < ncu && K >= 1024) {
+        s = (int)((2L * ncu + tiles - 1) / tiles);
+        int maxs = K / 256;
+        if (s > maxs) s = maxs;
+        if (s < 1) s = 1;
+    }
+    int kc = cdiv(cdiv(K, s), BK) * BK;
+    s = cdiv(K, kc);
+    *splits = s;
+    *kchunk = kc;
+}
+
+extern "C" size_t bbbp_gemm_workspace_bytes(int M, int N, int K, int batch) {
+    int tile, splits, kchunk;
+    gemm_plan(M, N, K, batch, &tile, &splits, &kchunk);
+    return splits > 1 ? (size_t)batch * splits * M * N * sizeof(float) : 0;
+}
+
+extern "C" int bbbp_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float alpha,
+                             const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                             const float* bias, const float* residual, int ldr, int act,
+                             int batch, long strideA, long strideB, long strideC, long strideR,
+                             void* workspace, size_t workspace_bytes) {
+    BBBP_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && batch >= 1, "gemm: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
+    BBBP_CHECK_ARG(act >= 0 && act <= 2, "gemm: bad act %d", act);
+    BBBP_CHECK_ARG(!(transA && transB), "gemm: layout TT (A^T B^T) is not on the hot path");
+    if (M == 0 || N == 0) return BBBP_OK;
+    BBBP_CHECK_ARG(A && B && C, "gemm: null operand");
+    // layout: NT = (transA 0, transB 1); NN = (0, 0); TN = (1, 0)
+    int layout = transA ? 2 : (transB ? 0 : 1);
+    BBBP_CHECK_ARG(lda >= (transA ? M : K), "gemm: lda %d too small", lda);
+    BBBP_CHECK_ARG(ldb >= (transB ? K : N), "gemm: ldb %d too small", ldb);
+    BBBP_CHECK_ARG(ldc >= N, "gemm: ldc %d too small", ldc);
+    GemmParams p;
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.R = residual;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
+    p.sA = strideA; p.sB = strideB; p.sC = strideC; p.sR = strideR;
+    p.alpha = alpha; p.act = act;
+    p.vecA = aligned16(A) && (lda % 4 == 0) && (strideA % 4 == 0);
+    p.vecB = aligned16(B) && (ldb % 4 == 0) && (strideB % 4 == 0);
+    int tile;
+    gemm_plan(M, N, K, batch, &tile, &p.splits, &p.kchunk);
+    p.slab = nullptr;
+    if (p.splits > 1) {
+        size_t need = (size_t)batch * p.splits * M * N * sizeof(float);
+        if (!workspace || workspace_bytes < need) {   // no room: fall back to a single pass
+            p.splits = 1;
+            p.kchunk = cdiv(K, BK) * BK;
+        } else {
+            p.slab = static_cast<float*>(workspace);
+        }
+    }
+    if (K == 0) { p.splits = 1; p.kchunk = BK; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid(cdiv(N, tile), cdiv(M, tile), batch * p.splits);
+    BBBP_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
+    if (tile == 128) launch_tile<128, 128>(p, layout, grid, st);
+    else launch_tile<64, 64>(p, layout, grid, st);
+    BBBP_CHECK_LAUNCH();
+    if (p.splits > 1) {
+        long mn = (long)M * N;
+        int gx = (int)((mn + 255) / 256);
+        if (gx > 4096) gx = 4096;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(gx, batch), dim3(256), 0, st, p);
+        BBBP_CHECK_LAUNCH();
+    }
+    return BBBP_OK;
+}

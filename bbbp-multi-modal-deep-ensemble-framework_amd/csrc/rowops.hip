@@ -1,0 +1,524 @@
+// HBM-bound row / column kernels of the BBBP hot path for gfx950: LayerNorm (+residual, +dropout),
+// row softmax (+dropout), BatchNorm1d, bias/activation backward, the attention-fusion combine,
+// dropout, MSE and AdamW.  They replace the ATen elementwise / reduction ops behind
+// nn.LayerNorm, softmax, nn.BatchNorm1d, nn.Dropout, nn.MSELoss and optim.AdamW on the path
+// (a3, a9, a10, a11, a13).  One wave (64 lanes) owns a row and reduces with DPP
+// shuffles; column statistics use 64-column x 16-row-lane blocks with a fixed-order LDS tree, so every
+// result is bit-reproducible run to run (no float atomics).
+#include "common.h"
+#include "bbbp_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dim.  z = dropout(x) + r is written back over x (saved for backward);
+// y = (z - mean) * rstd * gamma + beta.  One wave per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(float* x, const float* r, float* y, const float* gamma,
+                                                           const float* beta, float* mean_out, float* rstd_out,
+                                                           int rows, int cols, float eps, float p, uint64_t seed) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* xr = x + (long)row * cols;
+    const float* rr = r ? r + (long)row * cols : nullptr;
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+        float v = xr[c];
+        if (p > 0.f) v *= dropout_scale(seed, (uint64_t)row * cols + c, p, inv_keep);
+        if (rr) v += rr[c];
+        xr[c] = v;
+        s += v;
+    }
+    const float mean = wave_sum(s) / cols;
+    float q = 0.f;
+    for (int c = lane; c < cols; c += 64) { float d = xr[c] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / cols + eps);
+    float* yr = y + (long)row * cols;
+    for (int c = lane; c < cols; c += 64) yr[c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+// dz = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma.  dz is the gradient of the
+// residual input; dx (optional, when dropout was applied to x) = dz * keep-scale.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dy, const float* z, const float* gamma,
+                                                           const float* mean, const float* rstd, float* dz, float* dx,
+                                                           int rows, int cols, float p, uint64_t seed) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* dyr = dy + (long)row * cols;
+    const float* zr = z + (long)row * cols;
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+        float g = dyr[c] * gamma[c];
+        s1 += g;
+        s2 += g * (zr[c] - mu) * rs;
+    }
+    s1 = wave_sum(s1) / cols;
+    s2 = wave_sum(s2) / cols;
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    for (int c = lane; c < cols; c += 64) {
+        float g = dyr[c] * gamma[c];
+        float v = rs * (g - s1 - (zr[c] - mu) * rs * s2);
+        dz[(long)row * cols + c] = v;
+        if (dx) dx[(long)row * cols + c] = p > 0.f ? v * dropout_scale(seed, (uint64_t)row * cols + c, p, inv_keep) : v;
+    }
+}
+
+// column sums over rows of (a) dy * xhat and (b) dy:  LayerNorm dgamma / dbeta.
+__global__ __launch_bounds__(1024) void layernorm_param_grad_kernel(const float* dy, const float* z, const float* mean,
+                                                                   const float* rstd, float* dgamma, float* dbeta,
+                                                                   int rows, int cols) {
+    __shared__ float s1[16][64], s2[16][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float a = 0.f, b = 0.f;
+    if (c < cols)
+        for (int r = rl; r < rows; r += 16) {
+            float g = dy[(long)r * cols + c];
+            a += g * (z[(long)r * cols + c] - mean[r]) * rstd[r];
+            b += g;
+        }
+    s1[rl][cl] = a; s2[rl][cl] = b;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { ta += s1[i][cl]; tb += s2[i][cl]; }
+        dgamma[c] = ta; dbeta[c] = tb;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// softmax over the last dim, one wave per row, in place; optional dropout copy pd = dropout(p).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(float* x, float* pd, long rows, int cols, float p, uint64_t seed) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* xr = x + row * cols;
+    float m = -INFINITY;
+    for (int c = lane; c < cols; c += 64) m = fmaxf(m, xr[c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) { float e = __expf(xr[c] - m); xr[c] = e; s += e; }
+    const float inv = 1.f / wave_sum(s);
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    for (int c = lane; c < cols; c += 64) {
+        float v = xr[c] * inv;
+        xr[c] = v;
+        if (pd) pd[row * cols + c] = v * dropout_scale(seed, (uint64_t)row * cols + c, p, inv_keep);
+    }
+}
+
+// ds = P * (dP - sum(dP * P)), dP = dpd * keep-scale.  In place over dpd.
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(float* dpd, const float* prob, long rows, int cols, float p, uint64_t seed) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* dr = dpd + row * cols;
+    const float* pr = prob + row * cols;
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+        float d = dr[c];
+        if (p > 0.f) { d *= dropout_scale(seed, (uint64_t)row * cols + c, p, inv_keep); dr[c] = d; }
+        s += d * pr[c];
+    }
+    s = wave_sum(s);
+    for (int c = lane; c < cols; c += 64) dr[c] = pr[c] * (dr[c] - s);
+}
+
+// y = x * keep-scale (forward and backward of nn.Dropout share this kernel and the seed)
+__global__ __launch_bounds__(256) void dropout_kernel(const float* x, float* y, long n, float p, uint64_t seed) {
+    const float inv_keep = 1.f / (1.f - p);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        y[i] = x[i] * dropout_scale(seed, (uint64_t)i, p, inv_keep);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm1d over [rows, cols]; a block owns 64 columns and all rows.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void batchnorm_fwd_kernel(const float* x, float* y, const float* gamma, const float* beta,
+                                                            float* running_mean, float* running_var, float* save_mean,
+                                                            float* save_rstd, int rows, int cols, float eps, float momentum,
+                                                            int training) {
+    __shared__ float red[16][64];
+    __shared__ float smean[64], srstd[64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    if (training) {
+        float a = 0.f;
+        if (c < cols) for (int r = rl; r < rows; r += 16) a += x[(long)r * cols + c];
+        red[rl][cl] = a;
+        __syncthreads();
+        if (rl == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t += red[i][cl];
+            smean[cl] = t / rows;
+        }
+        __syncthreads();
+        const float mu = smean[cl];
+        float q = 0.f;
+        if (c < cols) for (int r = rl; r < rows; r += 16) { float d = x[(long)r * cols + c] - mu; q += d * d; }
+        __syncthreads();
+        red[rl][cl] = q;
+        __syncthreads();
+        if (rl == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t += red[i][cl];
+            float var = t / rows;
+            srstd[cl] = rsqrtf(var + eps);
+            if (c < cols) {
+                save_mean[c] = mu; save_rstd[c] = srstd[cl];
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * ((float)rows / (float)(rows - 1));
+            }
+        }
+        __syncthreads();
+    } else {
+        if (rl == 0 && c < cols) {
+            smean[cl] = running_mean[c];
+            srstd[cl] = rsqrtf(running_var[c] + eps);
+            save_mean[c] = smean[cl]; save_rstd[c] = srstd[cl];
+        }
+        __syncthreads();
+    }
+    if (c < cols) {
+        const float mu = smean[cl], rs = srstd[cl], g = gamma[c], b = beta[c];
+        for (int r = rl; r < rows; r += 16) y[(long)r * cols + c] = (x[(long)r * cols + c] - mu) * rs * g + b;
+    }
+}
+
+__global__ __launch_bounds__(1024) void batchnorm_bwd_kernel(const float* dy, const float* x, const float* gamma,
+                                                            const float* save_mean, const float* save_rstd, float* dx,
+                                                            float* dgamma, float* dbeta, int rows, int cols, int training) {
+    __shared__ float r1[16][64], r2[16][64];
+    __shared__ float t1[64], t2[64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const float mu = c < cols ? save_mean[c] : 0.f, rs = c < cols ? save_rstd[c] : 0.f;
+    float a = 0.f, b = 0.f;
+    if (c < cols)
+        for (int r = rl; r < rows; r += 16) {
+            float g = dy[(long)r * cols + c];
+            a += g * (x[(long)r * cols + c] - mu) * rs;
+            b += g;
+        }
+    r1[rl][cl] = a; r2[rl][cl] = b;
+    __syncthreads();
+    if (rl == 0) {
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { ta += r1[i][cl]; tb += r2[i][cl]; }
+        t1[cl] = ta; t2[cl] = tb;
+        if (c < cols) { dgamma[c] = ta; dbeta[c] = tb; }
+    }
+    __syncthreads();
+    if (c < cols) {
+        const float g = gamma[c], sa = t1[cl] / rows, sb = t2[cl] / rows;
+        for (int r = rl; r < rows; r += 16) {
+            float d = dy[(long)r * cols + c];
+            float v = training ? g * rs * (d - sb - (x[(long)r * cols + c] - mu) * rs * sa) : d * g * rs;
+            dx[(long)r * cols + c] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dy <- dy * act'(y) in place (y = the activation's OUTPUT), db[n] = column sums of the result.
+// act: 0 none, 1 relu (y > 0), 2 tanh (1 - y^2).  Leading dims allow column slices.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bias_act_bwd_kernel(float* dy, int lddy, const float* y, int ldy, float* db,
+                                                           int rows, int cols, int act, float scale) {
+    __shared__ float red[16][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float a = 0.f;
+    if (c < cols)
+        for (int r = rl; r < rows; r += 16) {
+            float g = dy[(long)r * lddy + c];
+            if (act == 1) g = y[(long)r * ldy + c] > 0.f ? g * scale : 0.f;
+            else if (act == 2) { float t = y[(long)r * ldy + c]; g *= (1.f - t * t) * scale; }
+            if (act) dy[(long)r * lddy + c] = g;
+            a += g;
+        }
+    red[rl][cl] = a;
+    __syncthreads();
+    if (rl == 0 && c < cols && db) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][cl];
+        db[c] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention fusion combine (reference MultiHeadAttentionFusion.forward, ...20250113.py:60-65):
+// logits_h = hid_h . w2_h + b2_h ; a = softmax_h(logits) ; out = sum_h a_h * combined.
+// hid: [NH][rows][HD] (tanh outputs), w2: NH pointers.  One wave per row; NH <= 8.
+// ---------------------------------------------------------------------------------------------
+struct FusionPtrs { const float* w2[8]; const float* b2[8]; };
+
+__global__ __launch_bounds__(256) void fusion_combine_fwd_kernel(const float* combined, const float* hid, FusionPtrs fp,
+                                                                float* out, float* attn, int rows, int dim, int hd, int nh) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float a[8];
+    float m = -INFINITY;
+    for (int h = 0; h < nh; ++h) {
+        const float* hr = hid + ((long)h * rows + row) * hd;
+        float s = 0.f;
+        for (int c = lane; c < hd; c += 64) s += hr[c] * fp.w2[h][c];
+        a[h] = wave_sum(s) + fp.b2[h][0];
+        m = fmaxf(m, a[h]);
+    }
+    float den = 0.f;
+    for (int h = 0; h < nh; ++h) { a[h] = __expf(a[h] - m); den += a[h]; }
+    for (int h = 0; h < nh; ++h) { a[h] /= den; if (lane == 0) attn[(long)row * nh + h] = a[h]; }
+    for (int c = lane; c < dim; c += 64) {
+        float x = combined[(long)row * dim + c], s = 0.f;
+        for (int h = 0; h < nh; ++h) s += a[h] * x;
+        out[(long)row * dim + c] = s;
+    }
+}
+
+// dcombined = dout * sum_h a_h ; dlogit_h = a_h * (t - sum_k a_k t), t = dout . combined ;
+// dpre[h][row][:] = dlogit_h * w2_h * (1 - hid^2)   (through the Tanh)
+__global__ __launch_bounds__(256) void fusion_combine_bwd_kernel(const float* dout, const float* combined, const float* hid,
+                                                                const float* attn, FusionPtrs fp, float* dcombined,
+                                                                float* dlogit, float* dpre, int rows, int dim, int hd, int nh) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float a[8], asum = 0.f;
+    for (int h = 0; h < nh; ++h) { a[h] = attn[(long)row * nh + h]; asum += a[h]; }
+    float t = 0.f;
+    for (int c = lane; c < dim; c += 64) {
+        float g = dout[(long)row * dim + c];
+        t += g * combined[(long)row * dim + c];
+        dcombined[(long)row * dim + c] = g * asum;
+    }
+    t = wave_sum(t);
+    // every head sees the same d(out)/d(a_h) . dout = t, so sum_k a_k t = t * asum
+    for (int h = 0; h < nh; ++h) {
+        float dl = a[h] * (t - t * asum);
+        if (lane == 0) dlogit[(long)h * rows + row] = dl;
+        const float* hr = hid + ((long)h * rows + row) * hd;
+        float* dp = dpre + ((long)h * rows + row) * hd;
+        for (int c = lane; c < hd; c += 64) { float y = hr[c]; dp[c] = dl * fp.w2[h][c] * (1.f - y * y); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MSE: loss = mean((pred - y)^2); dpred = 2 (pred - y) / n * gscale.  Single block, fixed order.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mse_kernel(const float* pred, const float* y, float* loss, float* dpred, int n, float gscale) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float d = pred[i] - y[i];
+        s += d * d;
+        if (dpred) dpred[i] = 2.f * d / n * gscale;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && loss) loss[0] = red[0] / n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// AdamW, torch.optim.AdamW arithmetic (decoupled decay, no amsgrad): one flat launch.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, long n, float decay,
+                                                   float omb1, float beta2, float omb2, float step_size, float bc2_sqrt,
+                                                   float eps, float gscale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float gi = g[i] * gscale;
+        float pi = p[i] * decay;
+        float mi = m[i] + omb1 * (gi - m[i]);
+        float vi = v[i] * beta2 + omb2 * gi * gi;
+        float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - step_size * (mi / denom);
+        m[i] = mi; v[i] = vi;
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float* x, long n, float s) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] *= s;
+}
+
+inline int grid_for(long n) {
+    long g = (n + 255) / 256;
+    long cap = (long)bbbp_num_cus() * 8;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+#define ST static_cast<hipStream_t>(stream)
+
+extern "C" int bbbp_layernorm_fwd(void* stream, float* x_inout_z, const float* residual, float* y, const float* gamma,
+                                  const float* beta, float* mean, float* rstd, int rows, int cols, float eps,
+                                  float dropout_p, uint64_t seed) {
+    BBBP_CHECK_ARG(rows >= 0 && cols > 0, "layernorm: bad shape %d x %d", rows, cols);
+    BBBP_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "layernorm: bad dropout %f", dropout_p);
+    if (rows == 0) return BBBP_OK;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, ST, x_inout_z, residual, y, gamma, beta,
+                       mean, rstd, rows, cols, eps, dropout_p, seed);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+extern "C" int bbbp_layernorm_bwd(void* stream, const float* dy, const float* z, const float* gamma, const float* mean,
+                                  const float* rstd, float* dz, float* dx, float* dgamma, float* dbeta, int rows, int cols,
+                                  float dropout_p, uint64_t seed) {
+    BBBP_CHECK_ARG(rows >= 0 && cols > 0, "layernorm bwd: bad shape %d x %d", rows, cols);
+    if (rows > 0) {
+        hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, ST, dy, z, gamma, mean, rstd, dz, dx,
+                           rows, cols, dropout_p, seed);
+        BBBP_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3(cdiv(cols, 64)), dim3(1024), 0, ST, dy, z, mean, rstd, dgamma,
+                       dbeta, rows, cols);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+extern "C" int bbbp_softmax_fwd(void* stream, float* x_inout, float* dropped_out, long rows, int cols, float dropout_p,
+                                uint64_t seed) {
+    BBBP_CHECK_ARG(rows >= 0 && cols > 0, "softmax: bad shape");
+    if (rows == 0) return BBBP_OK;
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST, x_inout,
+                       dropout_p > 0.f ? dropped_out : nullptr, rows, cols, dropout_p, seed);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+extern "C" int bbbp_softmax_bwd(void* stream, float* dprob_inout, const float* prob, long rows, int cols, float dropout_p,
+                                uint64_t seed) {
+    BBBP_CHECK_ARG(rows >= 0 && cols > 0, "softmax bwd: bad shape");
+    if (rows == 0) return BBBP_OK;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST, dprob_inout, prob, rows, cols,
+                       dropout_p, seed);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+extern "C" int bbbp_dropout(void* stream, const float* x, float* y, long n, float p, uint64_t seed) {
+    BBBP_CHECK_ARG(p >= 0.f && p < 1.f, "dropout: bad p %f", p);
+    if (n == 0) return BBBP_OK;
+    if (p == 0.f) {
+        if (x != y) BBBP_CHECK_HIP(hipMemcpyAsync(y, x, n * sizeof(float), hipMemcpyDeviceToDevice, ST));
+        return BBBP_OK;
+    }
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, ST, x, y, n, p, seed);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+extern "C" int bbbp_batchnorm1d_fwd(void* stream, const float* x, float* y, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float* save_mean, float* save_rstd, int rows,
+                                    int cols, float eps, float momentum, int training) {
+    BBBP_CHECK_ARG(cols > 0 && rows >= 0, "batchnorm: bad shape");
+    // same failure mode as nn.BatchNorm1d on a single-row training batch (tiny-batch tails)
+    BBBP_CHECK_ARG(!(training && rows <= 1), "Expected more than 1 value per channel when training, got input size [%d, %d]", rows, cols);
+    if (rows == 0) return BBBP_OK;
+    hipLaunchKernelGGL(batchnorm_fwd_kernel, dim3(cdiv(cols, 64)), dim3(1024), 0, ST, x, y, gamma, beta, running_mean,
+                       running_var, save_mean, save_rstd, rows, cols, eps, momentum, training);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+extern "C" int bbbp_batchnorm1d_bwd(void* stream, const float* dy, const float* x, const float* gamma, const float* save_mean,
+                                    const float* save_rstd, float* dx, float* dgamma, float* dbeta, int rows, int cols,
+                                    int training) {
+    BBBP_CHECK_ARG(cols > 0 && rows >= 0, "batchnorm bwd: bad shape");
+    hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3(cdiv(cols, 64)), dim3(1024), 0, ST, dy, x, gamma, save_mean, save_rstd, dx,
+                       dgamma, dbeta, rows, cols, training);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+extern "C" int bbbp_bias_act_bwd(void* stream, float* dy_inout, int lddy, const float* y, int ldy, float* dbias, int rows,
+                                 int cols, int act, float scale) {
+    BBBP_CHECK_ARG(cols > 0 && rows >= 0 && act >= 0 && act <= 2, "bias_act_bwd: bad args");
+    BBBP_CHECK_ARG(act == 0 || y, "bias_act_bwd: activation output required");
+    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(cdiv(cols, 64)), dim3(1024), 0, ST, dy_inout, lddy, y, ldy, dbias, rows, cols,
+                       act, scale);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+extern "C" int bbbp_fusion_combine_fwd(void* stream, const float* combined, const float* hid, const float* const* w2,
+                                       const float* const* b2, float* out, float* attn, int rows, int dim, int hidden,
+                                       int num_heads) {
+    BBBP_CHECK_ARG(num_heads >= 1 && num_heads <= 8, "fusion: num_heads %d not in [1, 8]", num_heads);
+    if (rows == 0) return BBBP_OK;
+    FusionPtrs fp;
+    for (int h = 0; h < 8; ++h) { fp.w2[h] = h < num_heads ? w2[h] : nullptr; fp.b2[h] = h < num_heads ? b2[h] : nullptr; }
+    hipLaunchKernelGGL(fusion_combine_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, ST, combined, hid, fp, out, attn, rows,
+                       dim, hidden, num_heads);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+extern "C" int bbbp_fusion_combine_bwd(void* stream, const float* dout, const float* combined, const float* hid,
+                                       const float* attn, const float* const* w2, float* dcombined, float* dlogit,
+                                       float* dpre, int rows, int dim, int hidden, int num_heads) {
+    BBBP_CHECK_ARG(num_heads >= 1 && num_heads <= 8, "fusion bwd: num_heads %d not in [1, 8]", num_heads);
+    if (rows == 0) return BBBP_OK;
+    FusionPtrs fp;
+    for (int h = 0; h < 8; ++h) { fp.w2[h] = h < num_heads ? w2[h] : nullptr; fp.b2[h] = nullptr; }
+    hipLaunchKernelGGL(fusion_combine_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, ST, dout, combined, hid, attn, fp,
+                       dcombined, dlogit, dpre, rows, dim, hidden, num_heads);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+extern "C" int bbbp_mse(void* stream, const float* pred, const float* target, float* loss, float* dpred, int n, float grad_scale) {
+    BBBP_CHECK_ARG(n > 0, "mse: empty input");
+    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(256), 0, ST, pred, target, loss, dpred, n, grad_scale);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+extern "C" int bbbp_adamw_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
+                               float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale) {
+    BBBP_CHECK_ARG(step >= 1, "adamw: step is 1-based, got %d", step);
+    if (n == 0) return BBBP_OK;
+    double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    float decay = (float)(1.0 - (double)lr * (double)weight_decay);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, ST, param, grad, exp_avg, exp_avg_sq, n, decay,
+                       (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), (float)((double)lr / bc1),
+                       (float)sqrt(bc2), eps, grad_scale);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+extern "C" int bbbp_scale(void* stream, float* x, long n, float s) {
+    if (n == 0) return BBBP_OK;
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, ST, x, n, s);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}

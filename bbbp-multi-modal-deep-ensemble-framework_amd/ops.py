@@ -1,0 +1,255 @@
+"""torch-tensor front end of the C ABI: one thin function per entry point of include/bbbp_hip.h.
+
+torch supplies device memory and the current HIP stream; all arithmetic happens in libbbbp_hip.so.
+Every function raises on non-CUDA / non-fp32 / non-contiguous operands, exactly like a torch op
+would, and there is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2, 0: 0, 1: 1, 2: 2}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a CUDA (HIP) tensor, got device {t.device}; the BBBP hot path has no CPU fallback")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _rowmajor_2d(t: torch.Tensor, name: str) -> Tuple[int, int, int]:
+    """(rows, cols, ld) of a 2-D tensor whose last dim is contiguous (column slices allowed)."""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise RuntimeError(f"{name}: expected a 2-D tensor with unit inner stride, got shape {tuple(t.shape)} strides {t.stride()}")
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    return t.shape[0], t.shape[1], ld
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False, alpha: float = 1.0,
+         bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act=None,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act(alpha * op(a) @ op(b) + bias) + residual  (2-D; or 3-D batched with equal batch dims)."""
+    _chk(a, "a"); _chk(b, "b")
+    batched = a.dim() == 3
+    if batched:
+        if not (a.is_contiguous() and b.is_contiguous()):
+            raise RuntimeError("batched gemm: operands must be contiguous")
+        nb = a.shape[0]
+        ar, ac = a.shape[1], a.shape[2]
+        br, bc = b.shape[1], b.shape[2]
+        lda, ldb = ac, bc
+        sa, sb = ar * ac, br * bc
+    else:
+        nb = 1
+        ar, ac, lda = _rowmajor_2d(a, "a")
+        br, bc, ldb = _rowmajor_2d(b, "b")
+        sa = sb = 0
+    M, K = (ac, ar) if trans_a else (ar, ac)
+    K2, N = (bc, br) if trans_b else (br, bc)
+    if K != K2:
+        raise RuntimeError(f"gemm: inner dimensions differ ({K} vs {K2})")
+    if out is None:
+        out = torch.empty((nb, M, N) if batched else (M, N), device=a.device, dtype=torch.float32)
+    _chk(out, "out")
+    ldc = N if batched else _rowmajor_2d(out, "out")[2]
+    sc = M * N if batched else 0
+    ldr, sr = 0, 0
+    if residual is not None:
+        _chk(residual, "residual")
+        ldr = N if batched else _rowmajor_2d(residual, "residual")[2]
+        sr = M * N if batched else 0
+    if bias is not None:
+        _chk(bias, "bias")
+        if bias.numel() != N:
+            raise RuntimeError(f"gemm: bias has {bias.numel()} elements, expected {N}")
+    L = _lib.lib()
+    wsb = L.bbbp_gemm_workspace_bytes(M, N, K, nb)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=a.device)
+    _lib.check(L.bbbp_gemm_f32(_stream(), int(trans_a), int(trans_b), M, N, K, float(alpha), a.data_ptr(), lda,
+                               b.data_ptr(), ldb, out.data_ptr(), ldc, _p(bias), _p(residual), ldr, ACT[act], nb, sa, sb,
+                               sc, sr, ws.data_ptr(), wsb), "bbbp_gemm_f32")
+    return out
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
+           residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """F.linear (+activation, +residual) on the MFMA GEMM."""
+    return gemm(x, weight, trans_b=True, bias=bias, act=act, residual=residual, out=out)
+
+
+def conv3x3_relu_pool_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    _chk(x, "x"); _chk(w, "weight"); _chk(b, "bias")
+    if not (x.is_contiguous() and w.is_contiguous() and b.is_contiguous()):
+        raise RuntimeError("conv3x3_relu_pool: operands must be contiguous (NCHW)")
+    B, cin, H, W = x.shape
+    cout = w.shape[0]
+    if tuple(w.shape) != (cout, cin, 3, 3):
+        raise RuntimeError(f"conv3x3_relu_pool: weight shape {tuple(w.shape)} does not match input channels {cin}")
+    y = torch.empty((B, cout, H // 2, W // 2), device=x.device, dtype=torch.float32)
+    mask = torch.empty((B, cout, H // 2, W // 2), device=x.device, dtype=torch.uint8)
+    L = _lib.lib()
+    wsb = L.bbbp_conv3x3_workspace_bytes(B, cin, cout, H, W)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    _lib.check(L.bbbp_conv3x3_relu_pool_fwd(_stream(), x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
+                                            mask.data_ptr(), B, cin, cout, H, W, ws.data_ptr(), wsb),
+               "bbbp_conv3x3_relu_pool_fwd")
+    return y, mask
+
+
+def conv3x3_relu_pool_bwd_data(gy: torch.Tensor, mask: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    _chk(gy, "gy"); _chk(mask, "mask", torch.uint8); _chk(w, "weight")
+    gy = gy.contiguous()
+    B, cout, Hp, Wp = gy.shape
+    cin = w.shape[1]
+    H, W = 2 * Hp, 2 * Wp
+    dx = torch.empty((B, cin, H, W), device=gy.device, dtype=torch.float32)
+    L = _lib.lib()
+    wsb = L.bbbp_conv3x3_workspace_bytes(B, cin, cout, H, W)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=gy.device)
+    _lib.check(L.bbbp_conv3x3_relu_pool_bwd_data(_stream(), gy.data_ptr(), mask.data_ptr(), w.data_ptr(), dx.data_ptr(),
+                                                 B, cin, cout, H, W, ws.data_ptr(), wsb), "bbbp_conv3x3_relu_pool_bwd_data")
+    return dx
+
+
+def conv3x3_relu_pool_bwd_weight(x: torch.Tensor, gy: torch.Tensor, mask: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    _chk(x, "x"); _chk(gy, "gy"); _chk(mask, "mask", torch.uint8)
+    gy = gy.contiguous()
+    B, cin, H, W = x.shape
+    cout = gy.shape[1]
+    dw = torch.empty((cout, cin, 3, 3), device=x.device, dtype=torch.float32)
+    db = torch.empty((cout,), device=x.device, dtype=torch.float32)
+    L = _lib.lib()
+    wsb = L.bbbp_conv3x3_workspace_bytes(B, cin, cout, H, W)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    _lib.check(L.bbbp_conv3x3_relu_pool_bwd_weight(_stream(), x.data_ptr(), gy.data_ptr(), mask.data_ptr(), dw.data_ptr(),
+                                                   db.data_ptr(), B, cin, cout, H, W, ws.data_ptr(), wsb),
+               "bbbp_conv3x3_relu_pool_bwd_weight")
+    return dw, db
+
+
+def layernorm_fwd(x: torch.Tensor, residual: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+                  eps: float = 1e-5, dropout_p: float = 0.0, seed: int = 0):
+    """Returns (y, z, mean, rstd) with z = dropout(x) + residual (x is NOT modified: it is cloned)."""
+    _chk(x, "x")
+    z = x.contiguous().clone()
+    rows, cols = z.shape
+    y = torch.empty_like(z)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().bbbp_layernorm_fwd(_stream(), z.data_ptr(), _p(residual), y.data_ptr(), gamma.data_ptr(),
+                                             beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, cols, eps,
+                                             dropout_p, seed), "bbbp_layernorm_fwd")
+    return y, z, mean, rstd
+
+
+def layernorm_bwd(dy, z, gamma, mean, rstd, dropout_p: float = 0.0, seed: int = 0):
+    """Returns (dz, dx, dgamma, dbeta); dx is dz when dropout_p == 0."""
+    rows, cols = z.shape
+    dz = torch.empty_like(z)
+    dx = torch.empty_like(z) if dropout_p > 0 else None
+    dg = torch.empty(cols, device=z.device, dtype=torch.float32)
+    db = torch.empty(cols, device=z.device, dtype=torch.float32)
+    _lib.check(_lib.lib().bbbp_layernorm_bwd(_stream(), dy.contiguous().data_ptr(), z.data_ptr(), gamma.data_ptr(),
+                                             mean.data_ptr(), rstd.data_ptr(), dz.data_ptr(), _p(dx), dg.data_ptr(),
+                                             db.data_ptr(), rows, cols, dropout_p, seed), "bbbp_layernorm_bwd")
+    return dz, (dx if dx is not None else dz), dg, db
+
+
+def softmax_fwd(x: torch.Tensor, dropout_p: float = 0.0, seed: int = 0):
+    """Row softmax over the last dim of a contiguous tensor. Returns (prob, dropped_prob)."""
+    p = _chk(x, "x").contiguous().clone()
+    cols = p.shape[-1]
+    rows = p.numel() // cols
+    pd = torch.empty_like(p) if dropout_p > 0 else None
+    _lib.check(_lib.lib().bbbp_softmax_fwd(_stream(), p.data_ptr(), _p(pd), rows, cols, dropout_p, seed), "bbbp_softmax_fwd")
+    return p, (pd if pd is not None else p)
+
+
+def softmax_bwd(dprob: torch.Tensor, prob: torch.Tensor, dropout_p: float = 0.0, seed: int = 0) -> torch.Tensor:
+    d = _chk(dprob, "dprob").contiguous().clone()
+    cols = d.shape[-1]
+    _lib.check(_lib.lib().bbbp_softmax_bwd(_stream(), d.data_ptr(), prob.data_ptr(), d.numel() // cols, cols, dropout_p, seed),
+               "bbbp_softmax_bwd")
+    return d
+
+
+def dropout(x: torch.Tensor, p: float, seed: int) -> torch.Tensor:
+    x = _chk(x, "x").contiguous()
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().bbbp_dropout(_stream(), x.data_ptr(), y.data_ptr(), x.numel(), p, seed), "bbbp_dropout")
+    return y
+
+
+def batchnorm1d_fwd(x, gamma, beta, running_mean, running_var, training: bool, eps: float = 1e-5, momentum: float = 0.1):
+    """Returns (y, save_mean, save_rstd); running stats are updated in place when training."""
+    x = _chk(x, "x").contiguous()
+    rows, cols = x.shape
+    y = torch.empty_like(x)
+    sm = torch.empty(cols, device=x.device, dtype=torch.float32)
+    sr = torch.empty(cols, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().bbbp_batchnorm1d_fwd(_stream(), x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                               running_mean.data_ptr(), running_var.data_ptr(), sm.data_ptr(), sr.data_ptr(),
+                                               rows, cols, eps, momentum, int(training)), "bbbp_batchnorm1d_fwd")
+    return y, sm, sr
+
+
+def batchnorm1d_bwd(dy, x, gamma, save_mean, save_rstd, training: bool):
+    x = x.contiguous(); dy = dy.contiguous()
+    rows, cols = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(cols, device=x.device, dtype=torch.float32)
+    db = torch.empty(cols, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().bbbp_batchnorm1d_bwd(_stream(), dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), save_mean.data_ptr(),
+                                               save_rstd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, cols,
+                                               int(training)), "bbbp_batchnorm1d_bwd")
+    return dx, dg, db
+
+
+def bias_act_bwd(dy: torch.Tensor, y: Optional[torch.Tensor], act=None, scale: float = 1.0):
+    """In place: dy *= act'(y) * scale.  Returns the column sums (bias gradient)."""
+    rows, cols, lddy = _rowmajor_2d(_chk(dy, "dy"), "dy")
+    ldy = 0
+    if y is not None:
+        ldy = _rowmajor_2d(_chk(y, "y"), "y")[2]
+    db = torch.empty(cols, device=dy.device, dtype=torch.float32)
+    _lib.check(_lib.lib().bbbp_bias_act_bwd(_stream(), dy.data_ptr(), lddy, _p(y), ldy, db.data_ptr(), rows, cols, ACT[act],
+                                            scale), "bbbp_bias_act_bwd")
+    return db
+
+
+def mse(pred: torch.Tensor, target: torch.Tensor, grad_scale: float = 1.0):
+    """Returns (loss[1], dpred) for loss = mean((pred - target)^2)."""
+    pred = _chk(pred, "pred").contiguous().view(-1)
+    target = _chk(target, "target").contiguous().view(-1)
+    loss = torch.empty(1, device=pred.device, dtype=torch.float32)
+    dpred = torch.empty_like(pred)
+    _lib.check(_lib.lib().bbbp_mse(_stream(), pred.data_ptr(), target.data_ptr(), loss.data_ptr(), dpred.data_ptr(),
+                                   pred.numel(), grad_scale), "bbbp_mse")
+    return loss, dpred
+
+
+def adamw_step_(param, grad, exp_avg, exp_avg_sq, step: int, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5,
+                grad_scale: float = 1.0) -> None:
+    for t, n in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _chk(t, n)
+        if not t.is_contiguous():
+            raise RuntimeError(f"adamw: {n} must be contiguous")
+    _lib.check(_lib.lib().bbbp_adamw_step(_stream(), param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(),
+                                          exp_avg_sq.data_ptr(), param.numel(), lr, betas[0], betas[1], eps, weight_decay,
+                                          step, grad_scale), "bbbp_adamw_step")

@@ -1,0 +1,144 @@
+/* bbbp_hip.h -- C ABI of libbbbp_hip.so, the MI355X (gfx950) implementation of the neural hot path of
+ * FengDushuo/BBBP-Multi-Modal-Deep-Ensemble-Framework.
+ *
+ * The reference has no FFI of its own: its hot path is stock torch.nn modules called from Python
+ * (SURVEY.md 8b).  These entry points are therefore what a binding for that path would call in
+ * place of ATen; each one cites the reference statement(s) it replaces, relative to /root/reference/,
+ * with R = Models/multi_input_data_regression_opt_transformer_cnn_20250113.py.
+ *
+ * Conventions: every pointer is a DEVICE pointer to fp32 data unless typed otherwise; tensors are
+ * row-major contiguous in the reference's own layouts (NCHW images, [out,in] Linear weights);
+ * `stream` is a hipStream_t (NULL = default stream); work is enqueued, never synchronised;
+ * scratch memory is caller-provided (`workspace`, sized by the *_workspace_bytes functions);
+ * every function returns 0 on success or a BBBP_ERR_* code, with text in bbbp_last_error();
+ * nothing throws across the ABI.  No torch types appear anywhere.
+ */
+#ifndef BBBP_HIP_H
+#define BBBP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BBBP_OK 0
+#define BBBP_ERR_ARG 1
+#define BBBP_ERR_HIP 2
+#define BBBP_ERR_WORKSPACE 3
+
+#define BBBP_ACT_NONE 0
+#define BBBP_ACT_RELU 1
+#define BBBP_ACT_TANH 2
+
+int bbbp_abi_version(void);
+const char* bbbp_last_error(void);
+
+/* ---- dense GEMM + bias + activation (+ residual) -------------------------------------------
+ * C[M,N] = act(alpha * op(A) op(B) + bias[n]) + residual[M,N]; op by transA/transB:
+ *   (0,1) A[M][K] B[N][K]: nn.Linear forward           R:79-82, 92, 98-107; nn.MultiheadAttention in/out proj R:75-78
+ *   (0,0) A[M][K] B[K][N]: input gradients, P.V        autograd of the above (loss.backward(), R:190)
+ *   (1,0) A[K][M] B[K][N]: weight gradients            idem
+ * batch > 1 runs `batch` independent products with the given element strides (attention heads). */
+size_t bbbp_gemm_workspace_bytes(int M, int N, int K, int batch);
+int bbbp_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float alpha,
+                  const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                  const float* bias, const float* residual, int ldr, int act,
+                  int batch, long strideA, long strideB, long strideC, long strideR,
+                  void* workspace, size_t workspace_bytes);
+
+/* ---- Conv2d(k3,s1,p1) + ReLU + MaxPool2d(2,2), NCHW ------------------------------------------
+ * forward: R:85-87 (3->32, 128x128) and R:88-90 (32->64, 64x64).  y is the pooled output,
+ * mask[B][cout][H/2][W/2] (u8) records the arg-max of each 2x2 window (0..3, PyTorch first-max order)
+ * or 4 where the ReLU is inactive; backward consumes it instead of the pre-pool activation.
+ * bwd_data / bwd_weight: autograd of the same statements under loss.backward() (R:190). */
+size_t bbbp_conv3x3_workspace_bytes(int B, int cin, int cout, int H, int W);
+int bbbp_conv3x3_relu_pool_fwd(void* stream, const float* x, const float* w, const float* bias,
+                               float* y, uint8_t* mask, int B, int cin, int cout, int H, int W,
+                               void* workspace, size_t workspace_bytes);
+int bbbp_conv3x3_relu_pool_bwd_data(void* stream, const float* gy, const uint8_t* mask, const float* w,
+                                    float* dx, int B, int cin, int cout, int H, int W,
+                                    void* workspace, size_t workspace_bytes);
+int bbbp_conv3x3_relu_pool_bwd_weight(void* stream, const float* x, const float* gy, const uint8_t* mask,
+                                      float* dw, float* db, int B, int cin, int cout, int H, int W,
+                                      void* workspace, size_t workspace_bytes);
+
+/* ---- LayerNorm(x_dropped + residual): nn.TransformerEncoderLayer.norm1/norm2 (R:75-78) ---------
+ * forward overwrites x with z = dropout(x) + residual (kept for backward) and writes y, mean, rstd.
+ * backward: dz (gradient of the residual input), dx (optional; dz times the dropout keep-scale). */
+int bbbp_layernorm_fwd(void* stream, float* x_inout_z, const float* residual, float* y, const float* gamma,
+                       const float* beta, float* mean, float* rstd, int rows, int cols, float eps,
+                       float dropout_p, uint64_t seed);
+int bbbp_layernorm_bwd(void* stream, const float* dy, const float* z, const float* gamma, const float* mean,
+                       const float* rstd, float* dz, float* dx, float* dgamma, float* dbeta, int rows, int cols,
+                       float dropout_p, uint64_t seed);
+
+/* ---- row softmax (attention probabilities, R:75-78 via F.scaled_dot_product_attention) --------- */
+int bbbp_softmax_fwd(void* stream, float* x_inout, float* dropped_out, long rows, int cols, float dropout_p,
+                     uint64_t seed);
+int bbbp_softmax_bwd(void* stream, float* dprob_inout, const float* prob, long rows, int cols, float dropout_p,
+                     uint64_t seed);
+
+/* ---- nn.Dropout: y = x * keep-scale; the same call with the same seed is its backward ---------- */
+int bbbp_dropout(void* stream, const float* x, float* y, long n, float p, uint64_t seed);
+
+/* ---- nn.BatchNorm1d (R:101): batch statistics + running-stat update when training ------------- */
+int bbbp_batchnorm1d_fwd(void* stream, const float* x, float* y, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float* save_mean, float* save_rstd, int rows,
+                         int cols, float eps, float momentum, int training);
+int bbbp_batchnorm1d_bwd(void* stream, const float* dy, const float* x, const float* gamma, const float* save_mean,
+                         const float* save_rstd, float* dx, float* dgamma, float* dbeta, int rows, int cols,
+                         int training);
+
+/* ---- backward of "+ bias, activation": dy *= act'(y) * scale in place, dbias = column sums ------ */
+int bbbp_bias_act_bwd(void* stream, float* dy_inout, int lddy, const float* y, int ldy, float* dbias, int rows,
+                      int cols, int act, float scale);
+
+/* ---- MultiHeadAttentionFusion.forward combine step (R:60-65) and its backward ------------------ */
+int bbbp_fusion_combine_fwd(void* stream, const float* combined, const float* hid, const float* const* w2,
+                            const float* const* b2, float* out, float* attn, int rows, int dim, int hidden,
+                            int num_heads);
+int bbbp_fusion_combine_bwd(void* stream, const float* dout, const float* combined, const float* hid,
+                            const float* attn, const float* const* w2, float* dcombined, float* dlogit,
+                            float* dpre, int rows, int dim, int hidden, int num_heads);
+
+/* ---- nn.MSELoss (R:143,189) and its gradient; optim.AdamW.step (R:172,191) -------------------- */
+int bbbp_mse(void* stream, const float* pred, const float* target, float* loss, float* dpred, int n, float grad_scale);
+int bbbp_adamw_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale);
+int bbbp_scale(void* stream, float* x, long n, float s);
+
+/* ---- whole-model entry points: MixedInputModel.forward (R:109-119) and its autograd ------------
+ * params[]: device pointers in the reference's named_parameters() order:
+ *   per encoder layer l (12): self_attn.in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias,
+ *        linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm1.weight, norm1.bias, norm2.weight, norm2.bias
+ *   fingerprint_fc.0.{weight,bias}; image_cnn.{0,3,7}.{weight,bias};
+ *   attention_fusion.attention_heads.h.{0.weight,0.bias,2.weight,2.bias} for h in 0..3;
+ *   fc.0.{w,b}, fc.2.{w,b} (BatchNorm affine), fc.3.{w,b}, fc.5.{w,b}, fc.7.{w,b}
+ * grads[]: same order, written (not accumulated).  bn_running: {running_mean, running_var} of fc.2.
+ * The workspace carries the saved activations from forward to backward. */
+typedef struct {
+    int batch;            /* B (also the attention sequence length: R:110-111, batch_first=False) */
+    int fingerprint_size; /* F = d_model */
+    int nhead;            /* R:71-73 */
+    int num_layers;       /* 6 */
+    int dim_feedforward;  /* 2048 */
+    int training;         /* BatchNorm batch statistics + dropout */
+    float dropout_p;      /* 0.1 in the encoder when training */
+    uint64_t seed;        /* dropout stream of this step */
+    int need_input_grad;  /* unused by the reference (inputs do not require grad) */
+} bbbp_mixed_desc;
+
+int bbbp_mixed_num_params(const bbbp_mixed_desc* d);
+size_t bbbp_mixed_workspace_bytes(const bbbp_mixed_desc* d);
+int bbbp_mixed_forward(void* stream, const bbbp_mixed_desc* d, const float* const* params, float* const* bn_running,
+                       const float* fingerprint, const float* image, float* out, void* workspace, size_t workspace_bytes);
+int bbbp_mixed_backward(void* stream, const bbbp_mixed_desc* d, const float* const* params, float* const* grads,
+                        const float* fingerprint, const float* image, const float* dout, void* workspace,
+                        size_t workspace_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BBBP_HIP_H */

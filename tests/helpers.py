@@ -1,0 +1,73 @@
+"""Shared test helpers: golden loading, seeded inputs, tolerant comparisons."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RTOL = 1e-4      # BASELINE.json north_star: predictions within 1e-4 relative of the reference CPU path
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def synth_inputs(seed, B, F, I):
+    """Same seeded inputs as tools/make_golden.py:synth_inputs."""
+    g = torch.Generator().manual_seed(seed)
+    fp = torch.randn(B, F, generator=g)
+    img = torch.randn(B, I, generator=g)
+    y = torch.randn(B, generator=g) * 0.8 - 0.1
+    return fp, img, y
+
+
+def check_param_checksums(g, state_dict):
+    assert list(g["meta/keys"]) == list(state_dict.keys())
+    for k, v in state_dict.items():
+        if v.dtype.is_floating_point:
+            s = g["param/" + k]
+            d = v.detach().double().cpu()
+            assert abs(float(d.sum()) - s[0]) <= 1e-9 * max(1.0, abs(s[0])), k
+            assert abs(float(d.abs().sum()) - s[1]) <= 1e-9 * max(1.0, s[1]), k
+
+
+def assert_close(actual, expected, rtol=RTOL, atol_frac=1e-5, what=""):
+    """|a - e| <= rtol * |e| + atol_frac * max|e| elementwise (the floor absorbs cancellation noise)."""
+    a = np.asarray(actual, dtype=np.float64)
+    e = np.asarray(expected, dtype=np.float64)
+    assert a.shape == e.shape, f"{what}: shape {a.shape} vs {e.shape}"
+    scale = float(np.max(np.abs(e))) if e.size else 0.0
+    err = np.abs(a - e)
+    tol = rtol * np.abs(e) + atol_frac * scale + 1e-30
+    bad = err > tol
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{e.size} elements out of tolerance; max err {err.max():.3e} "
+                           f"at scale {scale:.3e}; worst ratio {(err / tol).max():.2f}")
+
+
+def check_summary(g, prefix, tensor, rtol=RTOL, atol_frac=2e-5):
+    """Compare a tensor with the (stats, head, samp) summary stored by tools/make_golden.py."""
+    d = tensor.detach().double().cpu().flatten()
+    stats = g[prefix + "/stats"]
+    l2 = float(d.norm())
+    assert abs(l2 - stats[2]) <= 2 * rtol * max(stats[2], 1e-30) + 1e-12, f"{prefix}: l2 {l2} vs {stats[2]}"
+    scale = stats[2] / max(np.sqrt(d.numel()), 1.0)          # rms of the golden tensor
+    head = g[prefix + "/head"]
+    idx = g[prefix + "/idx"]
+    for got, exp, nm in ((d[:64].numpy(), head, "head"), (d[torch.from_numpy(idx)].numpy(), g[prefix + "/samp"], "samp")):
+        err = np.abs(got - exp)
+        tol = rtol * np.abs(exp) + atol_frac * max(scale, float(np.max(np.abs(exp)))) + 1e-30
+        assert (err <= tol).all(), f"{prefix}/{nm}: max err {err.max():.3e}, worst ratio {(err / tol).max():.2f}"
+
+
+def check_summary_adam(g, prefix, tensor, lr, steps, rtol=1e-5, min_frac=0.9, tight_lr_frac=0.02):
+    """Parameters after AdamW steps.  Where the exact gradient is ~0 (|g| <~ eps) AdamW turns rounding noise into
+    +-lr moves, so a minority of elements may differ by up to ~2*lr*steps between any two implementations; the
+    rest must agree tightly."""
+    d = tensor.detach().double().cpu().flatten()
+    idx = g[prefix + "/idx"]
+    got = np.concatenate([d[:64].numpy(), d[torch.from_numpy(idx)].numpy()])
+    exp = np.concatenate([g[prefix + "/head"], g[prefix + "/samp"]])
+    err = np.abs(got - exp)
+    assert (err <= 2.5 * lr * steps + rtol * np.abs(exp)).all(), f"{prefix}: max err {err.max():.3e}"
+    tight = err <= rtol * np.abs(exp) + tight_lr_frac * lr
+    assert tight.mean() >= min_frac, f"{prefix}: only {tight.mean():.2%} of sampled elements agree tightly"

@@ -1,0 +1,215 @@
+"""CPU: the oracle (oracle/reference_cpu.py) against the golden vectors produced from the reference's own
+classes (tools/make_golden.py), the shipped .pth state_dicts and the decoded stacked_model*.pkl coefficients."""
+import numpy as np
+import pytest
+import torch
+
+import bbbp_amd
+from oracle import reference_cpu as oracle
+from helpers import assert_close, check_param_checksums, check_summary, check_summary_adam, golden, synth_inputs
+
+FUSION = "attention_fusion."      # degenerate heads: gradients are rounding noise
+
+
+def adam_noise_amplified(k):
+    """Tensors whose exact gradient is (partly) ZERO, so AdamW divides rounding noise by (|noise| + eps):
+    the fusion heads, and the key-bias third of in_proj_bias (softmax is invariant to a per-query constant)."""
+    # ... and fc.0.bias: a unit whose ReLU is active for the whole batch feeds BatchNorm, which cancels bias shifts
+    return k.startswith(FUSION) or k.endswith("self_attn.in_proj_bias") or k == "fc.0.bias"
+
+
+def build(F, seed):
+    torch.manual_seed(seed)
+    m = bbbp_amd.MixedInputModel(F, 128)
+    return m
+
+
+def named(m, requires_grad=True):
+    p = {k: v.detach().clone().requires_grad_(requires_grad and v.dtype.is_floating_point and "running" not in k)
+         for k, v in m.state_dict().items()}
+    return p
+
+
+@pytest.mark.parametrize("name,F,seed", [("flagship_f167", 167, 20250113), ("flagship_f64", 64, 64),
+                                         ("flagship_f128", 128, 128), ("canonical_f167", 167, 20250113)])
+def test_init_and_eval_outputs(name, F, seed):
+    g = golden(name)
+    m = build(F, seed)
+    check_param_checksums(g, m.state_dict())          # drop-in init: same seed => same weights as the reference
+    p = named(m, False)
+    for key in [k for k in g.files if k.startswith("eval/")]:
+        B = int(key.split("/")[1][1:])
+        fp, img, _ = synth_inputs(1000 + B, B, F, 49152)
+        with torch.no_grad():
+            out = oracle.mixed_input_forward(p, fp, img, training=False)
+        assert_close(out.numpy(), g[key], rtol=1e-5, what=key)
+
+
+@pytest.mark.parametrize("name,F,seed,B", [("flagship_f167", 167, 20250113, 7), ("flagship_f64", 64, 64, 7),
+                                           ("flagship_f128", 128, 128, 5)])
+def test_train_mode_grads_and_bn(name, F, seed, B):
+    g = golden(name)
+    m = build(F, seed)
+    p = named(m)
+    fp, img, y = synth_inputs(1000 + B, B, F, 49152)
+    bn_state = {}
+    out = oracle.mixed_input_forward(p, fp, img, training=True, bn_state=bn_state)
+    loss = oracle.mse_loss(out, y)
+    loss.backward()
+    assert_close(out.detach().numpy(), g[f"train/B{B}/out"], rtol=1e-5, what="train out")
+    assert abs(float(loss.detach()) - float(g[f"train/B{B}/loss"])) <= 1e-5 * abs(float(g[f"train/B{B}/loss"]))
+    for k in ("fc.2.running_mean", "fc.2.running_var"):
+        assert_close(bn_state[k].numpy(), g[f"train/B{B}/bn/{k}"], rtol=1e-5, what=k)
+    for k, _ in m.named_parameters():
+        if k.startswith(FUSION):
+            continue
+        check_summary(g, f"train/B{B}/{k}", p[k].grad, rtol=2e-4)
+
+
+def test_eval_mode_grads_flagship():
+    g = golden("flagship_f167")
+    m = build(167, 20250113)
+    p = named(m)
+    fp, img, y = synth_inputs(1002, 2, 167, 49152)
+    loss = oracle.mse_loss(oracle.mixed_input_forward(p, fp, img, training=False), y)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["evalgrad/B2/loss"])) <= 1e-5 * abs(float(g["evalgrad/B2/loss"]))
+    for k, _ in m.named_parameters():
+        if not k.startswith(FUSION):
+            check_summary(g, f"evalgrad/B2/{k}", p[k].grad, rtol=2e-4)
+
+
+def test_adamw_three_steps():
+    g = golden("flagship_f167")
+    m = build(167, 20250113)
+    p = named(m)
+    B = 7
+    fp, img, y = synth_inputs(1000 + B, B, 167, 49152)
+    keys = [k for k, _ in m.named_parameters()]
+    state = {k: (torch.zeros_like(p[k]), torch.zeros_like(p[k])) for k in keys}
+    for step in range(1, 4):
+        for k in keys:
+            p[k].grad = None
+        bn_state = {}
+        loss = oracle.mse_loss(oracle.mixed_input_forward(p, fp, img, training=True, bn_state=bn_state), y)
+        loss.backward()
+        # step 1 sees identical weights; later steps inherit the +-lr moves AdamW makes out of rounding noise
+        ltol = 2e-5 if step == 1 else 3e-3
+        assert abs(float(loss.detach()) - float(g[f"adamw/B{B}/step{step}/loss"])) <= ltol * abs(float(g[f"adamw/B{B}/step{step}/loss"]))
+        with torch.no_grad():
+            for k in keys:
+                oracle.adamw_step(p[k], p[k].grad, state[k][0], state[k][1], step)
+            for k, v in bn_state.items():
+                p[k] = v
+        if step in (1, 3):
+            for k in keys:
+                if not adam_noise_amplified(k):
+                    check_summary_adam(g, f"adamw/B{B}/step{step}/{k}", p[k], lr=1e-4, steps=step,
+                                       tight_lr_frac=0.02 if step == 1 else 0.6, min_frac=0.9 if step == 1 else 0.75)
+
+
+@pytest.mark.parametrize("name,pth_F,pth_I", [("pca_mlp_maccs_pth", 64, 128), ("pca_mlp_pth", 128, 256)])
+def test_pca_mlp_shipped_weights(name, pth_F, pth_I):
+    """The shipped best_nn_model*.pth run through the oracle reproduce the reference class's outputs.  The
+    weights themselves are not committed; the golden holds per-tensor checksums and the outputs."""
+    g = golden(name)
+    keys, shapes = list(g["meta/keys"]), list(g["meta/shapes"])
+    assert len(keys) == 26 and keys[0] == "fingerprint_fc.0.weight" and "image_fc.0.weight" in keys
+    assert shapes[keys.index("fingerprint_fc.0.weight")] == f"128,{pth_F}"
+    assert shapes[keys.index("image_fc.0.weight")] == f"128,{pth_I}"
+    import os
+    pth = {"pca_mlp_maccs_pth": "/root/reference/Models/best_nn_model_maccs.pth",
+           "pca_mlp_pth": "/root/reference/Models/best_nn_model.pth"}[name]
+    if not os.path.exists(pth):
+        pytest.skip("reference .pth not present on this machine (data file of the reference, never copied)")
+    sd = torch.load(pth, map_location="cpu", weights_only=True)
+    check_param_checksums(g, sd)
+    for B in (1, 9):
+        fp, img, _ = synth_inputs(1000 + B, B, pth_F, pth_I)
+        with torch.no_grad():
+            out = oracle.pca_mlp_forward(sd, fp, img)
+        assert_close(out.numpy(), g[f"eval/B{B}/out"], rtol=1e-5, what=f"{name} B{B}")
+
+
+def test_ops_goldens():
+    g = golden("ops")
+    for name in ("conv1", "conv2"):
+        x = torch.from_numpy(g[f"{name}/x"]).requires_grad_(True)
+        w = torch.from_numpy(g[f"{name}/w"]).requires_grad_(True)
+        b = torch.from_numpy(g[f"{name}/b"]).requires_grad_(True)
+        y = oracle.conv3x3_relu_pool(x, w, b)
+        y.backward(torch.from_numpy(g[f"{name}/gy"]))
+        assert_close(y.detach().numpy(), g[f"{name}/y"], rtol=1e-6, what=name)
+        assert_close(x.grad.numpy(), g[f"{name}/gx"], rtol=1e-5, what=name + " gx")
+        assert_close(w.grad.numpy(), g[f"{name}/gw"], rtol=1e-5, what=name + " gw")
+        assert_close(b.grad.numpy(), g[f"{name}/gb"], rtol=1e-5, what=name + " gb")
+    for name, nh in (("enc_e12h3", 3), ("enc_e7h1", 1)):
+        p = {"l." + k[len(name) + 3:]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith(name + "/p/")}
+        x = torch.from_numpy(g[f"{name}/x"]).requires_grad_(True)
+        y = oracle.encoder_layer(x, p, "l.", nh)
+        y.backward(torch.from_numpy(g[f"{name}/gy"]))
+        assert_close(y.detach().numpy(), g[f"{name}/y"], rtol=1e-5, what=name)
+        assert_close(x.grad.numpy(), g[f"{name}/gx"], rtol=1e-4, what=name + " gx")
+        for k, v in p.items():
+            assert_close(v.grad.numpy(), g[f"{name}/g/{k[2:]}"], rtol=1e-4, atol_frac=1e-4, what=f"{name} grad {k}")
+    # BatchNorm1d
+    p = {"bn.weight": torch.from_numpy(g["bn/w"]), "bn.bias": torch.from_numpy(g["bn/b"]),
+         "bn.running_mean": torch.zeros(6), "bn.running_var": torch.ones(6), "bn.num_batches_tracked": torch.tensor(0)}
+    st = {}
+    y = oracle.batchnorm1d(torch.from_numpy(g["bn/x"]), p, "bn.", True, st)
+    assert_close(y.numpy(), g["bn/y_train"], rtol=1e-5, what="bn train")
+    assert_close(st["bn.running_mean"].numpy(), g["bn/running_mean"], rtol=1e-6, what="bn rm")
+    assert_close(st["bn.running_var"].numpy(), g["bn/running_var"], rtol=1e-6, what="bn rv")
+    p.update(st)
+    assert_close(oracle.batchnorm1d(torch.from_numpy(g["bn/x"]), p, "bn.", False).numpy(), g["bn/y_eval"], rtol=1e-5, what="bn eval")
+
+
+def test_dense_mlp_golden():
+    g = golden("dense_mlp")
+    keys = list(g["meta/keys"])
+    # rebuild the reference init: same module order as Models/multi_input_data_regression_opt.py:45-78
+    import torch.nn as nn
+    torch.manual_seed(5)
+    fpb = nn.Sequential(nn.Linear(167, 512), nn.ReLU(), nn.BatchNorm1d(512), nn.Dropout(0.2), nn.Linear(512, 256), nn.ReLU(),
+                        nn.BatchNorm1d(256), nn.Linear(256, 128), nn.ReLU())
+    imb = nn.Sequential(nn.Linear(768, 1024), nn.ReLU(), nn.BatchNorm1d(1024), nn.Dropout(0.2), nn.Linear(1024, 256), nn.ReLU(),
+                        nn.BatchNorm1d(256), nn.Linear(256, 128), nn.ReLU())
+    fc = nn.Sequential(nn.Linear(256, 256), nn.ReLU(), nn.BatchNorm1d(256), nn.Linear(256, 128), nn.ReLU(), nn.Linear(128, 64),
+                       nn.ReLU(), nn.Linear(64, 1))
+    sd = {}
+    for pre, mod in (("fingerprint_fc.", fpb), ("image_fc.", imb), ("fc.", fc)):
+        sd.update({pre + k: v for k, v in mod.state_dict().items()})
+    assert list(sd.keys()) == keys
+    check_param_checksums(g, sd)
+    fp, img, _ = synth_inputs(1004, 4, 167, 768)
+    with torch.no_grad():
+        out = oracle.dense_mlp_forward(sd, fp, img, training=False)
+    assert_close(out.numpy(), g["eval/B4/out"], rtol=1e-5, what="dense eval")
+    fp, img, y = synth_inputs(1006, 6, 167, 768)
+    with torch.no_grad():
+        out = oracle.dense_mlp_forward(sd, fp, img, training=True, bn_state={})
+    assert_close(out.numpy(), g["train/B6/out"], rtol=1e-5, what="dense train")
+
+
+def test_stacked_known_answers():
+    """Shipped meta-learners (Models/stacked_model*.pkl, decoded without unpickling): predict = X c + b."""
+    X = np.array([[-0.5, -0.3, -0.7], [0.2, 0.1, 0.4], [1.1, 0.9, 1.0]])
+    for name, (coef, icpt) in oracle.STACKED_KNOWN.items():
+        want = X[:, 0] * coef[0] + X[:, 1] * coef[1] + X[:, 2] * coef[2] + icpt
+        np.testing.assert_allclose(oracle.linear_predict(X, coef, icpt), want, rtol=1e-15)
+    # fit/predict round trip against scikit-learn (third-party arithmetic of the reference's stack surface)
+    from sklearn.linear_model import LinearRegression, Ridge
+    rng = np.random.default_rng(0)
+    Xf = rng.normal(size=(200, 3)); yf = Xf @ np.array([0.2, 0.7, 0.1]) + 0.03 + 0.05 * rng.normal(size=200)
+    for alpha, sk in ((0.0, LinearRegression()), (1.0, Ridge(alpha=1.0))):
+        sk.fit(Xf, yf)
+        coef, icpt = oracle.linear_fit(Xf, yf, alpha)
+        np.testing.assert_allclose(coef, sk.coef_, rtol=1e-9)
+        np.testing.assert_allclose(icpt, sk.intercept_, rtol=1e-9)
+    np.testing.assert_allclose(oracle.weighted_ensemble([1.0], [2.0], [3.0]), [0.4 + 0.6 + 0.9])
+
+
+def test_nhead_rule():
+    assert [oracle.nhead_rule(f) for f in (167, 64, 128, 2048)] == [1, 8, 16, 256]
+    assert [bbbp_amd.reference_nhead(f) for f in (167, 64, 128, 2048)] == [1, 8, 16, 256]
+    assert oracle.nhead_rule(167, start=8) == 1 and oracle.nhead_rule(2048, start=8) == 8

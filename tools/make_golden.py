@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the reference's OWN classes.
+
+Runs only in the build container (needs /root/reference).  The reference scripts cannot be
+imported (top-level ``pickle.load`` of absent files, ``xgboost``/``catboost`` imports), so the
+class definitions (``ClassDef`` nodes only) are pulled out of the source text with ``ast`` and
+exec'd in a namespace holding ``torch``/``nn``/``Dataset``.  Nothing of the reference's text is
+written anywhere: the fixtures hold seeds, tensor checksums, small slices and outputs only.
+
+Weights are NOT stored (the flagship state_dict is 54 MB): every case records the
+``torch.manual_seed`` used before the constructor plus a float64 (sum, abs-sum) per tensor, so a
+test rebuilds the identical initial weights from the seed and proves it with the checksums.
+
+Usage:  python tools/make_golden.py            (writes tests/golden/*.npz)
+"""
+from __future__ import annotations
+
+import ast
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.utils.data import Dataset
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def load_classes(relpath: str, names):
+    src = open(os.path.join(REF, relpath), encoding="utf-8").read()
+    tree = ast.parse(src)
+    ns = {"torch": torch, "nn": nn, "Dataset": Dataset}
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name in names:
+            exec(compile(ast.Module([node], []), relpath, "exec"), ns)
+    return ns
+
+
+def zero_dropout(model: nn.Module):
+    for m in model.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, nn.MultiheadAttention):
+            m.dropout = 0.0
+
+
+def tensor_summary(t: torch.Tensor):
+    d = t.detach().double().flatten()
+    n = d.numel()
+    idx = torch.linspace(0, n - 1, steps=min(n, 64)).long()
+    return dict(sum=float(d.sum()), abssum=float(d.abs().sum()), l2=float(d.norm()),
+                head=d[:64].numpy().copy(), idx=idx.numpy().copy(), samp=d[idx].numpy().copy())
+
+
+def pack(prefix: str, summ: dict, out: dict):
+    out[prefix + "/stats"] = np.array([summ["sum"], summ["abssum"], summ["l2"]], dtype=np.float64)
+    out[prefix + "/head"] = summ["head"]
+    out[prefix + "/idx"] = summ["idx"]
+    out[prefix + "/samp"] = summ["samp"]
+
+
+def synth_inputs(seed: int, B: int, F: int, I: int):
+    g = torch.Generator().manual_seed(seed)
+    fp = torch.randn(B, F, generator=g)
+    img = torch.randn(B, I, generator=g)
+    y = torch.randn(B, generator=g) * 0.8 - 0.1
+    return fp, img, y
+
+
+def case_model(tag, relpath, F, I_ctor, I_flat, Bs, init_seed, train_Bs=(), adam_B=None,
+               state_dict_path=None, extra_classes=()):
+    ns = load_classes(relpath, {"MixedDataset", "MultiHeadAttentionFusion", "MixedInputModel",
+                                "AttentionFusion", "MultiModalAttentionFusion", *extra_classes})
+    torch.manual_seed(init_seed)
+    model = ns["MixedInputModel"](F, I_ctor)
+    if state_dict_path is not None:
+        sd = torch.load(os.path.join(REF, state_dict_path), map_location="cpu", weights_only=True)
+        model.load_state_dict(sd, strict=True)
+    zero_dropout(model)
+    out = {"meta/init_seed": np.array(init_seed), "meta/F": np.array(F), "meta/I_ctor": np.array(I_ctor),
+           "meta/I_flat": np.array(I_flat),
+           "meta/keys": np.array(list(model.state_dict().keys())),
+           "meta/shapes": np.array([",".join(map(str, v.shape)) for v in model.state_dict().values()])}
+    for k, v in model.state_dict().items():
+        if v.dtype.is_floating_point:
+            out[f"param/{k}"] = np.array([float(v.double().sum()), float(v.double().abs().sum())])
+    crit = nn.MSELoss()
+    for B in Bs:
+        fp, img, y = synth_inputs(1000 + B, B, F, I_flat)
+        model.eval()
+        with torch.no_grad():
+            out[f"eval/B{B}/out"] = model(fp, img).numpy().copy()
+        # eval-mode gradients (BN uses running stats; what the published loop does in epochs 2-50)
+        model.zero_grad()
+        pred = model(fp, img).squeeze()
+        loss = crit(pred, y) if B > 1 else ((pred - y.squeeze()) ** 2).mean()
+        loss.backward()
+        out[f"evalgrad/B{B}/loss"] = np.array(float(loss))
+        for k, p in model.named_parameters():
+            pack(f"evalgrad/B{B}/{k}", tensor_summary(p.grad), out)
+    for B in train_Bs:
+        fp, img, y = synth_inputs(1000 + B, B, F, I_flat)
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        model.train()
+        model.zero_grad()
+        o = model(fp, img)
+        loss = crit(o.squeeze(), y)
+        loss.backward()
+        out[f"train/B{B}/out"] = o.detach().numpy().copy()
+        out[f"train/B{B}/loss"] = np.array(float(loss))
+        for k, p in model.named_parameters():
+            pack(f"train/B{B}/{k}", tensor_summary(p.grad), out)
+        for k, v in model.state_dict().items():
+            if "running_" in k or "num_batches" in k:
+                out[f"train/B{B}/bn/{k}"] = v.numpy().copy()
+        model.load_state_dict(sd0)
+    if adam_B is not None:
+        B = adam_B
+        fp, img, y = synth_inputs(1000 + B, B, F, I_flat)
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5)
+        model.train()
+        for step in range(1, 4):
+            opt.zero_grad()
+            loss = crit(model(fp, img).squeeze(), y)
+            loss.backward()
+            opt.step()
+            out[f"adamw/B{B}/step{step}/loss"] = np.array(float(loss))
+            if step in (1, 3):
+                for k, p in model.named_parameters():
+                    pack(f"adamw/B{B}/step{step}/{k}", tensor_summary(p), out)
+                for k, v in model.state_dict().items():
+                    if "running_" in k:
+                        out[f"adamw/B{B}/step{step}/bn/{k}"] = v.numpy().copy()
+        model.load_state_dict(sd0)
+    path = os.path.join(OUT, tag + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def case_ops():
+    """Per-op goldens with explicit small tensors (all data stored)."""
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    # conv+relu+pool, both channel configs, small spatial size
+    for name, cin, cout, hw in (("conv1", 3, 32, 16), ("conv2", 32, 64, 8)):
+        x = torch.randn(2, cin, hw, hw, generator=g)
+        conv = nn.Conv2d(cin, cout, 3, 1, 1)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.2)
+            conv.bias.copy_(torch.randn(conv.bias.shape, generator=g) * 0.1)
+        seq = nn.Sequential(conv, nn.ReLU(), nn.MaxPool2d(2, 2))
+        x.requires_grad_(True)
+        y = seq(x)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        out.update({f"{name}/x": x.detach().numpy(), f"{name}/w": conv.weight.detach().numpy(),
+                    f"{name}/b": conv.bias.detach().numpy(), f"{name}/y": y.detach().numpy(),
+                    f"{name}/gy": gy.numpy(), f"{name}/gx": x.grad.numpy(),
+                    f"{name}/gw": conv.weight.grad.numpy(), f"{name}/gb": conv.bias.grad.numpy()})
+    # one encoder layer, E=12 nhead=3 and E=7 nhead=1 (prime, like MACCS-167), dropout 0
+    for name, E, nh, S in (("enc_e12h3", 12, 3, 9), ("enc_e7h1", 7, 1, 5)):
+        torch.manual_seed(11)
+        layer = nn.TransformerEncoderLayer(d_model=E, nhead=nh, dropout=0.0)
+        with torch.no_grad():
+            for p_ in layer.parameters():
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.3)
+        x = torch.randn(S, 1, E, generator=g, requires_grad=True)
+        layer.train()
+        y = layer(x)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        out[f"{name}/x"] = x.detach().numpy()[:, 0]
+        out[f"{name}/y"] = y.detach().numpy()[:, 0]
+        out[f"{name}/gy"] = gy.numpy()[:, 0]
+        out[f"{name}/gx"] = x.grad.numpy()[:, 0]
+        for k, p_ in layer.named_parameters():
+            out[f"{name}/p/{k}"] = p_.detach().numpy()
+            out[f"{name}/g/{k}"] = p_.grad.numpy()
+    # BatchNorm1d train/eval incl. running stats
+    bn = nn.BatchNorm1d(6)
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(6, generator=g)); bn.bias.copy_(torch.randn(6, generator=g))
+    x = torch.randn(5, 6, generator=g, requires_grad=True)
+    bn.train(); y = bn(x); gy = torch.randn(5, 6, generator=g); y.backward(gy)
+    out.update({"bn/x": x.detach().numpy(), "bn/w": bn.weight.detach().numpy(), "bn/b": bn.bias.detach().numpy(),
+                "bn/y_train": y.detach().numpy(), "bn/gy": gy.numpy(), "bn/gx": x.grad.numpy(),
+                "bn/gw": bn.weight.grad.numpy(), "bn/gb": bn.bias.grad.numpy(),
+                "bn/running_mean": bn.running_mean.numpy().copy(), "bn/running_var": bn.running_var.numpy().copy()})
+    bn.eval()
+    with torch.no_grad():
+        out["bn/y_eval"] = bn(x).numpy()
+    path = os.path.join(OUT, "ops.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("needs /root/reference (build container only)")
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    M = "Models/"
+    # flagship (published variant), MACCS width; nhead = 1, head_dim = 167
+    case_model("flagship_f167", M + "multi_input_data_regression_opt_transformer_cnn_20250113.py",
+               167, 128, 49152, Bs=(1, 2, 7, 32), init_seed=20250113, train_Bs=(7, 32), adam_B=7)
+    # same classes, widths that exercise multi-head attention (nhead 8 / 16, head_dim 8)
+    case_model("flagship_f64", M + "multi_input_data_regression_opt_transformer_cnn_20250113.py",
+               64, 128, 49152, Bs=(2, 7), init_seed=64, train_Bs=(7,))
+    case_model("flagship_f128", M + "multi_input_data_regression_opt_transformer_cnn_20250113.py",
+               128, 128, 49152, Bs=(5,), init_seed=128, train_Bs=(5,))
+    # canonical variant #1: same architecture, must give the same numbers for the same seed
+    case_model("canonical_f167", M + "multi_input_data_regression_opt_transformer_cnn.py",
+               167, 128, 49152, Bs=(2,), init_seed=20250113)
+    # PCA-MLP fusion model with the two shipped state_dicts
+    case_model("pca_mlp_maccs_pth", M + "multi_input_data_regression_opt_transformer_cnn_opt.py",
+               64, 128, 128, Bs=(1, 9), init_seed=1, state_dict_path="Models/best_nn_model_maccs.pth")
+    case_model("pca_mlp_pth", M + "multi_input_data_regression_opt_transformer_cnn_opt.py",
+               128, 256, 256, Bs=(1, 9), init_seed=1, state_dict_path="Models/best_nn_model.pth")
+    # dense raw-feature MLP, image width shrunk to 3*16*16 for size
+    case_model("dense_mlp", M + "multi_input_data_regression_opt.py",
+               167, 768, 768, Bs=(4,), init_seed=5, train_Bs=(6,))
+    case_ops()
+
+
+if __name__ == "__main__":
+    main()
