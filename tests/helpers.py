@@ -49,7 +49,7 @@ def check_summary(g, prefix, tensor, rtol=RTOL, atol_frac=2e-5):
     d = tensor.detach().double().cpu().flatten()
     stats = g[prefix + "/stats"]
     l2 = float(d.norm())
-    assert abs(l2 - stats[2]) <= 2 * rtol * max(stats[2], 1e-30) + 1e-12, f"{prefix}: l2 {l2} vs {stats[2]}"
+    assert abs(l2 - stats[2]) <= (2 * rtol + atol_frac) * max(stats[2], 1e-30) + 1e-12, f"{prefix}: l2 {l2} vs {stats[2]}"
     scale = stats[2] / max(np.sqrt(d.numel()), 1.0)          # rms of the golden tensor
     head = g[prefix + "/head"]
     idx = g[prefix + "/idx"]

@@ -1,0 +1,208 @@
+"""GPU: every op-level C-ABI entry point against the CPU oracle / float64 torch on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from bbbp_amd import ops
+from oracle import reference_cpu as oracle
+from helpers import assert_close, golden
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+GEMM_SHAPES = [(512, 501, 167), (512, 167, 167), (512, 2048, 167), (512, 167, 2048), (7, 128, 167), (1, 1, 64),
+               (33, 65, 17), (512, 128, 4096), (256, 256, 256), (130, 70, 9), (64, 64, 1)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_gemm_layouts(dev, M, N, K, layout):
+    a = rnd(M, K, seed=M + K); b = rnd(K, N, seed=N + 7)
+    want = (a.double() @ b.double())
+    scale = (a.abs().double() @ b.abs().double())
+    if layout == "nt":
+        got = ops.gemm(a.to(dev), b.t().contiguous().to(dev), trans_b=True)
+    elif layout == "nn":
+        got = ops.gemm(a.to(dev), b.to(dev))
+    else:
+        got = ops.gemm(a.t().contiguous().to(dev), b.to(dev), trans_a=True)
+    err = (got.cpu().double() - want).abs()
+    assert (err <= 2e-6 * scale + 1e-30).all(), f"max err ratio {(err / (scale + 1e-30)).max():.3e}"
+
+
+def test_gemm_epilogues_and_slices(dev):
+    M, N, K = 100, 70, 50
+    a, w, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
+    for act, fn in (("relu", torch.relu), ("tanh", torch.tanh), (None, lambda x: x)):
+        want = fn(0.5 * (a.double() @ w.double().t()) + bias.double()) + res.double()
+        got = ops.gemm(a.to(dev), w.to(dev), trans_b=True, alpha=0.5, bias=bias.to(dev), residual=res.to(dev), act=act)
+        assert_close(got.cpu().numpy(), want.numpy(), rtol=1e-5, what=f"epilogue {act}")
+    # write into a column slice of a wider buffer (how the branches fill `combined`)
+    buf = torch.zeros(M, 2 * N, device=dev)
+    ops.gemm(a.to(dev), w.to(dev), trans_b=True, out=buf[:, N:])
+    assert_close(buf[:, N:].cpu().numpy(), (a.double() @ w.double().t()).numpy(), rtol=1e-5, what="slice out")
+    assert float(buf[:, :N].abs().max()) == 0.0
+    # batched (attention heads)
+    qa, kb = rnd(5, 40, 8, seed=5), rnd(5, 40, 8, seed=6)
+    got = ops.gemm(qa.to(dev), kb.to(dev), trans_b=True, alpha=0.25)
+    assert_close(got.cpu().numpy(), (0.25 * qa.double() @ kb.double().transpose(1, 2)).numpy(), rtol=1e-5, what="batched")
+
+
+def test_gemm_errors(dev):
+    with pytest.raises(RuntimeError):
+        ops.gemm(torch.zeros(4, 5), torch.zeros(5, 6))                    # CPU tensors: no fallback
+    with pytest.raises(RuntimeError):
+        ops.gemm(torch.zeros(4, 5, device=dev), torch.zeros(6, 6, device=dev))
+    with pytest.raises(RuntimeError):
+        ops.gemm(torch.zeros(4, 5, device=dev, dtype=torch.float64), torch.zeros(5, 6, device=dev, dtype=torch.float64))
+    out = ops.gemm(torch.zeros(0, 5, device=dev), torch.zeros(5, 6, device=dev))   # empty batch
+    assert out.shape == (0, 6)
+
+
+def _conv_case(dev, B, cin, cout, hw, seed, uniform_patches=False):
+    x = rnd(B, cin, hw, hw, seed=seed)
+    if uniform_patches:        # flat regions => exact ties inside pooling windows (white image background)
+        x[:, :, : hw // 2, :] = 1.0
+    w = rnd(cout, cin, 3, 3, seed=seed + 1, scale=0.2)
+    b = rnd(cout, seed=seed + 2, scale=0.1)
+    # float64 oracle: torch's own fp32 CPU weight-gradient carries ~2e-3 (of max) summation error at these sizes
+    xr, wr, br = (t_.double().clone().requires_grad_(True) for t_ in (x, w, b))
+    yr = oracle.conv3x3_relu_pool(xr, wr, br)
+    gy = rnd(*yr.shape, seed=seed + 3)
+    yr.backward(gy.double())
+    y, mask = ops.conv3x3_relu_pool_fwd(x.to(dev), w.to(dev), b.to(dev))
+    assert_close(y.cpu().numpy(), yr.detach().numpy(), rtol=1e-5, atol_frac=1e-6, what="conv fwd")
+    assert int(mask.max()) <= 4
+    # mask 4 <=> ReLU inactive; a pre-activation within rounding of 0 may legitimately fall either way
+    disagree = (mask == 4).cpu() != (yr.detach() == 0)
+    assert float(torch.maximum(y.cpu().abs(), yr.detach().abs())[disagree].max() if disagree.any() else 0.0) < 1e-5
+    assert float(disagree.float().mean()) < 1e-4
+    dw, db = ops.conv3x3_relu_pool_bwd_weight(x.to(dev), gy.to(dev), mask)
+    assert_close(dw.cpu().numpy(), wr.grad.numpy(), rtol=1e-4, atol_frac=2e-5, what="conv dw")
+    assert_close(db.cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol_frac=2e-5, what="conv db")
+    if cin == 32:
+        dx = ops.conv3x3_relu_pool_bwd_data(gy.to(dev), mask, w.to(dev))
+        assert_close(dx.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol_frac=2e-5, what="conv dx")
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_conv1_3to32(dev, B):
+    _conv_case(dev, B, 3, 32, 128, seed=10 + B)
+
+
+@pytest.mark.parametrize("B", [1, 2, 5])
+def test_conv2_32to64(dev, B):
+    _conv_case(dev, B, 32, 64, 64, seed=20 + B)
+
+
+def test_conv_pool_ties_follow_first_max(dev):
+    _conv_case(dev, 2, 3, 32, 128, seed=31, uniform_patches=True)
+    _conv_case(dev, 2, 32, 64, 64, seed=32, uniform_patches=True)
+
+
+def test_conv_many_strips_persistent_loop(dev):
+    """More strips than work-groups: exercises the grid-stride loop and the double buffer across strips."""
+    _conv_case(dev, 40, 32, 64, 64, seed=41)
+    _conv_case(dev, 24, 3, 32, 128, seed=42)
+
+
+def test_conv_rejects_unsupported(dev):
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_relu_pool_fwd(torch.zeros(1, 5, 64, 64, device=dev), torch.zeros(8, 5, 3, 3, device=dev), torch.zeros(8, device=dev))
+
+
+@pytest.mark.parametrize("rows,cols", [(5, 7), (512, 167), (33, 2048), (4, 64)])
+def test_layernorm(dev, rows, cols):
+    x, r = rnd(rows, cols, seed=1), rnd(rows, cols, seed=2)
+    gam, bet, dy = rnd(cols, seed=3), rnd(cols, seed=4), rnd(rows, cols, seed=5)
+    xr, rr, gr, br = (t.clone().double().requires_grad_(True) for t in (x, r, gam, bet))
+    yr = F.layer_norm(xr + rr, (cols,), gr, br, 1e-5)
+    yr.backward(dy.double())
+    y, z, mean, rstd = ops.layernorm_fwd(x.to(dev), r.to(dev), gam.to(dev), bet.to(dev))
+    assert_close(y.cpu().numpy(), yr.detach().numpy(), rtol=1e-5, what="ln fwd")
+    dz, dx, dg, db = ops.layernorm_bwd(dy.to(dev), z, gam.to(dev), mean, rstd)
+    assert_close(dz.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol_frac=2e-5, what="ln dx")
+    assert_close(dg.cpu().numpy(), gr.grad.numpy(), rtol=1e-4, atol_frac=2e-5, what="ln dgamma")
+    assert_close(db.cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol_frac=2e-5, what="ln dbeta")
+
+
+@pytest.mark.parametrize("rows,cols", [(9, 9), (512, 512), (3, 4096), (70, 33)])
+def test_softmax(dev, rows, cols):
+    x, dp = rnd(rows, cols, seed=1, scale=3.0), rnd(rows, cols, seed=2)
+    xr = x.clone().double().requires_grad_(True)
+    pr = torch.softmax(xr, dim=-1)
+    pr.backward(dp.double())
+    p, pd = ops.softmax_fwd(x.to(dev))
+    assert pd is p
+    assert_close(p.cpu().numpy(), pr.detach().numpy(), rtol=1e-5, what="softmax")
+    ds = ops.softmax_bwd(dp.to(dev), p)
+    assert_close(ds.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol_frac=2e-5, what="softmax bwd")
+
+
+def test_batchnorm_golden_and_random(dev):
+    g = golden("ops")
+    x, w, b = (torch.from_numpy(g[k]).to(dev) for k in ("bn/x", "bn/w", "bn/b"))
+    rm, rv = torch.zeros(6, device=dev), torch.ones(6, device=dev)
+    y, sm, sr = ops.batchnorm1d_fwd(x, w, b, rm, rv, training=True)
+    assert_close(y.cpu().numpy(), g["bn/y_train"], rtol=1e-5, what="bn train")
+    assert_close(rm.cpu().numpy(), g["bn/running_mean"], rtol=1e-5, what="bn running_mean")
+    assert_close(rv.cpu().numpy(), g["bn/running_var"], rtol=1e-5, what="bn running_var")
+    dx, dg, db = ops.batchnorm1d_bwd(torch.from_numpy(g["bn/gy"]).to(dev), x, w, sm, sr, training=True)
+    assert_close(dx.cpu().numpy(), g["bn/gx"], rtol=1e-4, atol_frac=2e-5, what="bn dx")
+    assert_close(dg.cpu().numpy(), g["bn/gw"], rtol=1e-4, atol_frac=2e-5, what="bn dgamma")
+    assert_close(db.cpu().numpy(), g["bn/gb"], rtol=1e-4, atol_frac=2e-5, what="bn dbeta")
+    y2, _, _ = ops.batchnorm1d_fwd(x, w, b, rm, rv, training=False)
+    assert_close(y2.cpu().numpy(), g["bn/y_eval"], rtol=1e-5, what="bn eval")
+    with pytest.raises(RuntimeError, match="more than 1 value per channel"):
+        ops.batchnorm1d_fwd(x[:1].contiguous(), w, b, rm, rv, training=True)     # same failure as nn.BatchNorm1d
+    # larger random case, eval-mode backward
+    X = rnd(300, 256, seed=9).to(dev); W = rnd(256, seed=10).to(dev); Bb = rnd(256, seed=11).to(dev)
+    rm, rv = rnd(256, seed=12).to(dev), (rnd(256, seed=13).abs() + 0.5).to(dev)
+    dy = rnd(300, 256, seed=14)
+    Xr = X.cpu().double().requires_grad_(True)
+    yr = F.batch_norm(Xr, rm.cpu().double(), rv.cpu().double(), W.cpu().double(), Bb.cpu().double(), False, 0.1, 1e-5)
+    yr.backward(dy.double())
+    y, sm, sr = ops.batchnorm1d_fwd(X, W, Bb, rm, rv, training=False)
+    dx, _, _ = ops.batchnorm1d_bwd(dy.to(dev), X, W, sm, sr, training=False)
+    assert_close(y.cpu().numpy(), yr.detach().numpy(), rtol=1e-5, what="bn eval big")
+    assert_close(dx.cpu().numpy(), Xr.grad.numpy(), rtol=1e-4, what="bn eval dx")
+
+
+def test_bias_act_bwd_and_mse(dev):
+    y = torch.relu(rnd(50, 70, seed=1)); dy = rnd(50, 70, seed=2)
+    want = dy * (y > 0)
+    d = dy.clone().to(dev)
+    db = ops.bias_act_bwd(d, y.to(dev), act="relu")
+    assert_close(d.cpu().numpy(), want.numpy(), rtol=1e-6, what="relu bwd")
+    assert_close(db.cpu().numpy(), want.double().sum(0).numpy(), rtol=1e-5, what="db")
+    pred, tgt = rnd(37, seed=3), rnd(37, seed=4)
+    loss, dpred = ops.mse(pred.to(dev), tgt.to(dev))
+    assert_close(loss.cpu().numpy(), [float(((pred - tgt) ** 2).mean())], rtol=1e-5, what="mse")
+    assert_close(dpred.cpu().numpy(), (2 * (pred - tgt) / 37).numpy(), rtol=1e-5, what="dmse")
+
+
+def test_dropout_statistics_and_determinism(dev):
+    x = torch.ones(1 << 20, device=dev)
+    y1, y2, y3 = ops.dropout(x, 0.1, seed=5), ops.dropout(x, 0.1, seed=5), ops.dropout(x, 0.1, seed=6)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    keep = float((y1 > 0).float().mean())
+    assert abs(keep - 0.9) < 2e-3
+    assert abs(float(y1.mean()) - 1.0) < 3e-3 and abs(float(y1.max()) - 1 / 0.9) < 1e-6
+
+
+def test_adamw_matches_oracle(dev):
+    p, g_ = rnd(1000, seed=1), rnd(1000, seed=2)
+    m, v = torch.zeros(1000), torch.zeros(1000)
+    pd, md, vd = p.clone().to(dev), m.clone().to(dev), v.clone().to(dev)
+    for step in range(1, 4):
+        gs = g_ * step
+        oracle.adamw_step(p, gs, m, v, step)
+        ops.adamw_step_(pd, gs.to(dev), md, vd, step)
+    assert_close(pd.cpu().numpy(), p.numpy(), rtol=1e-5, what="adamw p")
+    assert_close(vd.cpu().numpy(), v.numpy(), rtol=1e-5, what="adamw v")
