@@ -54,6 +54,10 @@ _SIGNATURES = {
     "bbbp_adamw_step": (c_int, [c_void_p, _FP, _FP, _FP, _FP, c_long, c_float, c_float, c_float, c_float, c_float, c_int,
                                 c_float]),
     "bbbp_scale": (c_int, [c_void_p, _FP, c_long, c_float]),
+    "bbbp_profile_enable": (c_int, [c_int]),
+    "bbbp_profile_num_sections": (c_int, []),
+    "bbbp_profile_section_name": (c_char_p, [c_int]),
+    "bbbp_profile_collect": (c_int, [POINTER(c_float), POINTER(c_int)]),
     "bbbp_mixed_num_params": (c_int, [POINTER(MixedDesc)]),
     "bbbp_mixed_workspace_bytes": (c_size_t, [POINTER(MixedDesc)]),
     "bbbp_mixed_forward": (c_int, [c_void_p, POINTER(MixedDesc), _PP, _PP, _FP, _FP, _FP, c_void_p, c_size_t]),

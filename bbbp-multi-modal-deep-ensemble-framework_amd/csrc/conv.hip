@@ -609,18 +609,25 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradParams p) {
     }
 }
 
-// dW[co][ci][kh][kw] (= [co][27]) = sum_g slab[g][co][j], j = ci*9 + tap; db[co] = sum_g bslab[g][co]
+// dW[co][ci][kh][kw] (= [co][27]) = sum_g slab[g][co][j], j = ci*9 + tap; db[co] = sum_g bslab[g][co].
+// A block owns 32 outputs; its 8 thread groups each sum a fixed eighth of the slabs, then a fixed-order LDS add.
 __global__ __launch_bounds__(256) void conv_wgrad3_reduce_kernel(const float* slab, const float* bslab, float* dw,
                                                                 float* db, int nslab) {
-    int n = blockIdx.x * 256 + threadIdx.x;     // 0..1023 weights, 1024..1055 biases
+    __shared__ float part[8][32];
+    const int nl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + nl;          // 0..1023 weights (32 blocks), 1024..1055 biases (block 32)
+    const int per = (nslab + 7) / 8, g0 = grp * per, g1 = min(nslab, g0 + per);
     float s = 0.f;
-    if (n < 1024) {
-        for (int g = 0; g < nslab; ++g) s += slab[(long)g * 1024 + n];
-        int co = n / 32, jx = n % 32;
-        if (jx < 27) dw[co * 27 + jx] = s;
-    } else if (n < 1024 + 32) {
-        for (int g = 0; g < nslab; ++g) s += bslab[(long)g * 32 + (n - 1024)];
-        db[n - 1024] = s;
+    if (n < 1024) for (int g = g0; g < g1; ++g) s += slab[(long)g * 1024 + n];
+    else for (int g = g0; g < g1; ++g) s += bslab[(long)g * 32 + (n - 1024)];
+    part[grp][nl] = s;
+    __syncthreads();
+    if (grp == 0) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v += part[i][nl];
+        if (n < 1024) { if ((n & 31) < 27) dw[(n >> 5) * 27 + (n & 31)] = v; }
+        else db[n - 1024] = v;
     }
 }
 
@@ -734,7 +741,7 @@ extern "C" int bbbp_conv3x3_relu_pool_bwd_weight(void* stream, const float* x, c
         if (rc) return rc;
         hipLaunchKernelGGL((conv_wgrad3_kernel<128>), dim3(grid), dim3(512), C::LDS_BYTES, st, p);
         BBBP_CHECK_LAUNCH();
-        hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3(5), dim3(256), 0, st, slab, p.bslab, dw, db, grid);
+        hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3(33), dim3(256), 0, st, slab, p.bslab, dw, db, grid);
         BBBP_CHECK_LAUNCH();
     } else {
         using C = WgCfg<64, 64>;

@@ -119,6 +119,35 @@ struct Ctx {
 
 #define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
+// ---- optional per-section timing with HIP events on the launch stream (bench.py roofline leg) ----
+enum { SEC_CONV1_FWD = 0, SEC_CONV2_FWD, SEC_IMGFC_FWD, SEC_ENCODER_FWD, SEC_HEAD_FWD, SEC_HEAD_BWD, SEC_IMGFC_BWD,
+       SEC_CONV2_WGRAD, SEC_CONV2_DGRAD, SEC_CONV1_WGRAD, SEC_ENCODER_BWD, SEC_COUNT };
+const char* const kSectionNames[SEC_COUNT] = {"conv1_fwd", "conv2_fwd", "imgfc_fwd", "encoder_fwd", "head_fwd", "head_bwd",
+                                              "imgfc_bwd", "conv2_wgrad", "conv2_dgrad", "conv1_wgrad", "encoder_bwd"};
+constexpr int PROF_MAX = 4096;
+struct ProfState {
+    bool on = false;
+    int n = 0;
+    int sec[PROF_MAX];
+    hipEvent_t a[PROF_MAX], b[PROF_MAX];
+    int created = 0;
+} g_prof;
+
+struct Section {
+    hipStream_t st; int idx;
+    Section(hipStream_t s, int sec) : st(s), idx(-1) {
+        if (!g_prof.on || g_prof.n >= PROF_MAX) return;
+        idx = g_prof.n++;
+        if (idx >= g_prof.created) {
+            if (hipEventCreate(&g_prof.a[idx]) != hipSuccess || hipEventCreate(&g_prof.b[idx]) != hipSuccess) { idx = -1; --g_prof.n; return; }
+            g_prof.created = idx + 1;
+        }
+        g_prof.sec[idx] = sec;
+        (void)hipEventRecord(g_prof.a[idx], st);
+    }
+    ~Section() { if (idx >= 0) (void)hipEventRecord(g_prof.b[idx], st); }
+};
+
 // y[M,N] = act(x[M,K] W[N,K]^T + b) + res
 int linear_fwd(const Ctx& c, const float* x, int ldx, const float* W, const float* b, float* y, int ldy, int M, int N, int K,
                int act, const float* res = nullptr, int ldr = 0) {
@@ -140,6 +169,22 @@ int linear_bwd_weight(const Ctx& c, const float* dy, int lddy, const float* x, i
 uint64_t site_seed(uint64_t seed, int layer, int site) { return seed * 0x9E3779B97F4A7C15ull + (uint64_t)(layer * 8 + site + 1); }
 
 }  // namespace
+
+// Profiling: enable, run steps, synchronise the stream, then collect {sum of ms, launches} per section.
+extern "C" int bbbp_profile_enable(int on) { g_prof.on = on != 0; g_prof.n = 0; return BBBP_OK; }
+extern "C" int bbbp_profile_num_sections(void) { return SEC_COUNT; }
+extern "C" const char* bbbp_profile_section_name(int i) { return (i >= 0 && i < SEC_COUNT) ? kSectionNames[i] : ""; }
+extern "C" int bbbp_profile_collect(float* ms_sum, int* count) {
+    for (int i = 0; i < SEC_COUNT; ++i) { ms_sum[i] = 0.f; count[i] = 0; }
+    for (int i = 0; i < g_prof.n; ++i) {
+        float ms = 0.f;
+        BBBP_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.a[i], g_prof.b[i]));
+        ms_sum[g_prof.sec[i]] += ms;
+        count[g_prof.sec[i]] += 1;
+    }
+    g_prof.n = 0;
+    return BBBP_OK;
+}
 
 extern "C" int bbbp_mixed_num_params(const bbbp_mixed_desc* d) {
     if (!d) return -1;
@@ -170,6 +215,8 @@ extern "C" int bbbp_mixed_forward(void* stream, const bbbp_mixed_desc* d, const 
 
     // ---- fingerprint branch: encoder (R:75-78, 110-111) --------------------------------------
     const float* x = fingerprint;
+    Section* sec_enc = new Section(c.st, SEC_ENCODER_FWD);
+    struct Guard { Section*& p; ~Guard() { delete p; p = nullptr; } } enc_guard{sec_enc};
     for (int l = 0; l < plan.L; ++l) {
         const LayerOff& o = plan.layer[l];
         float* qkv = c.f(o.qkv); float* prob = c.f(o.prob); float* ctx = c.f(o.ctx);
@@ -197,14 +244,25 @@ extern "C" int bbbp_mixed_forward(void* stream, const bbbp_mixed_desc* d, const 
     float* comb = c.f(plan.combined);
     // fingerprint_fc (R:79-82, 112) -> combined[:, 0:128]
     TRY(linear_fwd(c, x, F, P[ix.fpfc_w()], P[ix.fpfc_b()], comb, COMB, B, FC, F, BBBP_ACT_RELU));
+    delete sec_enc; sec_enc = nullptr;
 
     // ---- image branch (R:84-94, 114-115) -------------------------------------------------------
     float* pool1 = c.f(plan.pool1); float* pool2 = c.f(plan.pool2);
-    TRY(bbbp_conv3x3_relu_pool_fwd(c.st, image, P[ix.c1_w()], P[ix.c1_b()], pool1, c.u8(plan.mask1), B, 3, C1, IMG, IMG,
-                                   c.scratch(), c.scratch_bytes()));
-    TRY(bbbp_conv3x3_relu_pool_fwd(c.st, pool1, P[ix.c2_w()], P[ix.c2_b()], pool2, c.u8(plan.mask2), B, C1, C2, IMG / 2, IMG / 2,
-                                   c.scratch(), c.scratch_bytes()));
-    TRY(linear_fwd(c, pool2, IMG_FLAT, P[ix.ifc_w()], P[ix.ifc_b()], comb + FC, COMB, B, FC, IMG_FLAT, BBBP_ACT_RELU));
+    {
+        Section s1(c.st, SEC_CONV1_FWD);
+        TRY(bbbp_conv3x3_relu_pool_fwd(c.st, image, P[ix.c1_w()], P[ix.c1_b()], pool1, c.u8(plan.mask1), B, 3, C1, IMG, IMG,
+                                       c.scratch(), c.scratch_bytes()));
+    }
+    {
+        Section s2(c.st, SEC_CONV2_FWD);
+        TRY(bbbp_conv3x3_relu_pool_fwd(c.st, pool1, P[ix.c2_w()], P[ix.c2_b()], pool2, c.u8(plan.mask2), B, C1, C2, IMG / 2,
+                                       IMG / 2, c.scratch(), c.scratch_bytes()));
+    }
+    {
+        Section s3(c.st, SEC_IMGFC_FWD);
+        TRY(linear_fwd(c, pool2, IMG_FLAT, P[ix.ifc_w()], P[ix.ifc_b()], comb + FC, COMB, B, FC, IMG_FLAT, BBBP_ACT_RELU));
+    }
+    Section sec_head(c.st, SEC_HEAD_FWD);
 
     // ---- attention fusion (R:60-65, 117) -------------------------------------------------------
     float* hid = c.f(plan.hid);
@@ -251,6 +309,9 @@ extern "C" int bbbp_mixed_backward(void* stream, const bbbp_mixed_desc* d, const
     float* dfused = c.f(plan.dfused); float* dcomb = c.f(plan.dcomb);
 
     // ---- head ------------------------------------------------------------------------------------
+    Section* sec = new Section(c.st, SEC_HEAD_BWD);
+    struct Guard { Section*& p; ~Guard() { delete p; p = nullptr; } } sec_guard{sec};
+    auto next_section = [&](int id) { delete sec; sec = nullptr; sec = new Section(c.st, id); };
     // fc.7: out = h3 W7^T + b7
     TRY(linear_bwd_weight(c, dout, 1, h3, H3, G[ix.fc7_w()], B, 1, H3));
     // db7 = sum(dout) (act = 0 leaves dy untouched, so the const_cast is safe)
@@ -290,16 +351,21 @@ extern "C" int bbbp_mixed_backward(void* stream, const bbbp_mixed_desc* d, const
     // ---- image branch ----------------------------------------------------------------------------
     float* pool1 = c.f(plan.pool1); float* pool2 = c.f(plan.pool2);
     float* dpool2 = c.f(plan.dpool2); float* dpool1 = c.f(plan.dpool1);
+    next_section(SEC_IMGFC_BWD);
     TRY(linear_bwd_weight(c, dcomb + FC, COMB, pool2, IMG_FLAT, G[ix.ifc_w()], B, FC, IMG_FLAT));
     TRY(linear_bwd_input(c, dcomb + FC, COMB, P[ix.ifc_w()], dpool2, IMG_FLAT, B, FC, IMG_FLAT));
+    next_section(SEC_CONV2_WGRAD);
     TRY(bbbp_conv3x3_relu_pool_bwd_weight(c.st, pool1, dpool2, c.u8(plan.mask2), G[ix.c2_w()], G[ix.c2_b()], B, C1, C2, IMG / 2,
                                           IMG / 2, c.scratch(), c.scratch_bytes()));
+    next_section(SEC_CONV2_DGRAD);
     TRY(bbbp_conv3x3_relu_pool_bwd_data(c.st, dpool2, c.u8(plan.mask2), P[ix.c2_w()], dpool1, B, C1, C2, IMG / 2, IMG / 2,
                                         c.scratch(), c.scratch_bytes()));
+    next_section(SEC_CONV1_WGRAD);
     TRY(bbbp_conv3x3_relu_pool_bwd_weight(c.st, image, dpool1, c.u8(plan.mask1), G[ix.c1_w()], G[ix.c1_b()], B, 3, C1, IMG, IMG,
                                           c.scratch(), c.scratch_bytes()));
 
     // ---- fingerprint branch ----------------------------------------------------------------------
+    next_section(SEC_ENCODER_BWD);
     const float* enc_out = plan.L > 0 ? c.f(plan.layer[plan.L - 1].y2) : fingerprint;
     TRY(linear_bwd_weight(c, dcomb, COMB, enc_out, F, G[ix.fpfc_w()], B, FC, F));
     float* dy = c.f(plan.dA);       // gradient wrt the current layer's output

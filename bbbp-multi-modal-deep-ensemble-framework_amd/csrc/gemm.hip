@@ -250,10 +250,12 @@ static void gemm_plan(int M, int N, int K, int batch, int* tile, int* splits, in
     int ncu = bbbp_num_cus();
     *tile = (t128 >= (long)ncu * 3 / 4) ? 128 : 64;
     long tiles = (*tile == 128) ? t128 : t64;
+    // Few output tiles and a deep K (weight gradients over the batch, the 65536-wide image FC, FFN2): these
+    // launches are latency-bound at one work-group per tile, so spread K over ~2 work-groups per CU.
     int s = 1;
-    if (tiles < ncu && K >= 1024) {
+    if (tiles < ncu && K >= 256) {
         s = (int)((2L * ncu + tiles - 1) / tiles);
-        int maxs = K / 256;
+        int maxs = K / 64;
         if (s > maxs) s = maxs;
         if (s < 1) s = 1;
     }

@@ -80,15 +80,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dy, con
 }
 
 // column sums over rows of (a) dy * xhat and (b) dy:  LayerNorm dgamma / dbeta.
+// Column reductions use 16-column x 64-row-lane blocks: enough blocks to spread a 167-wide tensor over the chip.
+constexpr int CW = 16, RL = 64;
 __global__ __launch_bounds__(1024) void layernorm_param_grad_kernel(const float* dy, const float* z, const float* mean,
                                                                    const float* rstd, float* dgamma, float* dbeta,
                                                                    int rows, int cols) {
-    __shared__ float s1[16][64], s2[16][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ float s1[RL][CW], s2[RL][CW];
+    const int cl = threadIdx.x % CW, rl = threadIdx.x / CW;
+    const int c = blockIdx.x * CW + cl;
     float a = 0.f, b = 0.f;
     if (c < cols)
-        for (int r = rl; r < rows; r += 16) {
+        for (int r = rl; r < rows; r += RL) {
             float g = dy[(long)r * cols + c];
             a += g * (z[(long)r * cols + c] - mean[r]) * rstd[r];
             b += g;
@@ -97,8 +99,8 @@ __global__ __launch_bounds__(1024) void layernorm_param_grad_kernel(const float*
     __syncthreads();
     if (rl == 0 && c < cols) {
         float ta = 0.f, tb = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { ta += s1[i][cl]; tb += s2[i][cl]; }
+#pragma unroll 8
+        for (int i = 0; i < RL; ++i) { ta += s1[i][cl]; tb += s2[i][cl]; }
         dgamma[c] = ta; dbeta[c] = tb;
     }
 }
@@ -247,12 +249,12 @@ __global__ __launch_bounds__(1024) void batchnorm_bwd_kernel(const float* dy, co
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void bias_act_bwd_kernel(float* dy, int lddy, const float* y, int ldy, float* db,
                                                            int rows, int cols, int act, float scale) {
-    __shared__ float red[16][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ float red[RL][CW];
+    const int cl = threadIdx.x % CW, rl = threadIdx.x / CW;
+    const int c = blockIdx.x * CW + cl;
     float a = 0.f;
     if (c < cols)
-        for (int r = rl; r < rows; r += 16) {
+        for (int r = rl; r < rows; r += RL) {
             float g = dy[(long)r * lddy + c];
             if (act == 1) g = y[(long)r * ldy + c] > 0.f ? g * scale : 0.f;
             else if (act == 2) { float t = y[(long)r * ldy + c]; g *= (1.f - t * t) * scale; }
@@ -263,8 +265,8 @@ __global__ __launch_bounds__(1024) void bias_act_bwd_kernel(float* dy, int lddy,
     __syncthreads();
     if (rl == 0 && c < cols && db) {
         float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t += red[i][cl];
+#pragma unroll 8
+        for (int i = 0; i < RL; ++i) t += red[i][cl];
         db[c] = t;
     }
 }
@@ -399,7 +401,7 @@ extern "C" int bbbp_layernorm_bwd(void* stream, const float* dy, const float* z,
                            rows, cols, dropout_p, seed);
         BBBP_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3(cdiv(cols, 64)), dim3(1024), 0, ST, dy, z, mean, rstd, dgamma,
+    hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3(cdiv(cols, CW)), dim3(1024), 0, ST, dy, z, mean, rstd, dgamma,
                        dbeta, rows, cols);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
@@ -464,7 +466,7 @@ extern "C" int bbbp_bias_act_bwd(void* stream, float* dy_inout, int lddy, const 
                                  int cols, int act, float scale) {
     BBBP_CHECK_ARG(cols > 0 && rows >= 0 && act >= 0 && act <= 2, "bias_act_bwd: bad args");
     BBBP_CHECK_ARG(act == 0 || y, "bias_act_bwd: activation output required");
-    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(cdiv(cols, 64)), dim3(1024), 0, ST, dy_inout, lddy, y, ldy, dbias, rows, cols,
+    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(cdiv(cols, CW)), dim3(1024), 0, ST, dy_inout, lddy, y, ldy, dbias, rows, cols,
                        act, scale);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;

@@ -1,0 +1,66 @@
+"""Fused AdamW for the hot path: same constructor arguments and arithmetic as ``torch.optim.AdamW``
+as the reference uses it (Models/multi_input_data_regression_opt_transformer_cnn_20250113.py:172,
+``optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5)``), run by ``bbbp_adamw_step``.
+
+When the parameters (and their gradients) are consecutive views of one flat buffer -- which
+``MixedInputModel`` arranges -- a whole step is ONE kernel launch over 13.5 M elements; otherwise one
+launch per tensor.  State tensors are exposed per parameter (``exp_avg``, ``exp_avg_sq``, ``step``) like
+torch's, so ``state_dict()`` has the familiar shape.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .models import flat_view_of
+
+
+class AdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("invalid AdamW hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._flat_state = {}
+
+    def _init_group_state(self, gi, params):
+        total = sum(p.numel() for p in params)
+        dev = params[0].device
+        m = torch.zeros(total, dtype=torch.float32, device=dev)
+        v = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in params:
+            n = p.numel()
+            self.state[p] = {"step": 0, "exp_avg": m[off:off + n].view(p.shape), "exp_avg_sq": v[off:off + n].view(p.shape)}
+            off += n
+        self._flat_state[gi] = (m, v)
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        """``grad_scale`` multiplies every gradient on the fly (1/world_size after a summing all-reduce)."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            if gi not in self._flat_state or any(p not in self.state for p in params):
+                self._init_group_state(gi, [p for p in group["params"]])
+            hp = dict(lr=group["lr"], betas=group["betas"], eps=group["eps"], weight_decay=group["weight_decay"])
+            for p in params:
+                self.state[p]["step"] += 1
+            step = self.state[params[0]]["step"]
+            all_params = list(group["params"])
+            pflat = flat_view_of(all_params) if len(params) == len(all_params) else None
+            gflat = flat_view_of([p.grad for p in all_params]) if pflat is not None else None
+            same_step = all(self.state[p]["step"] == step for p in params)
+            if pflat is not None and gflat is not None and same_step:
+                m, v = self._flat_state[gi]
+                ops.adamw_step_(pflat, gflat, m, v, step, grad_scale=grad_scale, **hp)
+            else:
+                for p in params:
+                    st = self.state[p]
+                    g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                    ops.adamw_step_(p.data, g, st["exp_avg"], st["exp_avg_sq"], st["step"], grad_scale=grad_scale, **hp)
+        return loss

@@ -138,6 +138,13 @@ int bbbp_mixed_backward(void* stream, const bbbp_mixed_desc* d, const float* con
                         const float* fingerprint, const float* image, const float* dout, void* workspace,
                         size_t workspace_bytes);
 
+/* ---- optional per-section timing (HIP events on the launch stream; used by bench.py's roofline leg) ----
+ * enable(1), run steps, synchronise the stream, collect(ms_sum[n], count[n]) with n = num_sections(). */
+int bbbp_profile_enable(int on);
+int bbbp_profile_num_sections(void);
+const char* bbbp_profile_section_name(int i);
+int bbbp_profile_collect(float* ms_sum, int* count);
+
 #ifdef __cplusplus
 }
 #endif
