@@ -1,0 +1,120 @@
+"""One process per GPU on one 8 x MI355X node; gradients are summed with ONE RCCL all-reduce over xGMI per step.
+
+The reference is single-process; this is the new data-parallel capability.  Mode implemented: replica data
+parallel -- every rank runs the reference model on its own local batch (attention across the LOCAL batch, BatchNorm on
+LOCAL statistics: exactly what torch DDP would do to the reference) and gradients are averaged.  Because the model keeps
+all gradients in one flat buffer (models.py), the collective is a single 53.9 MB (F=167) all-reduce instead of 106 small
+ones; xGMI is a point-to-point mesh, so one large message per peer is the shape RCCL handles best.
+Backend "nccl" is RCCL on ROCm; "gloo" runs the same code on CPU tensors for tests.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .models import flat_view_of
+
+
+def init(backend: Optional[str] = None) -> tuple:
+    """Initialise torch.distributed from the torchrun environment.  Returns (rank, world_size, device)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver
+    use_gpu = torch.cuda.is_available()
+    if backend is None:
+        backend = "nccl" if use_gpu else "gloo"
+    device = torch.device("cuda", local) if (use_gpu and backend == "nccl") else torch.device("cpu")
+    if device.type == "cuda":
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        kwargs = {"device_id": device} if device.type == "cuda" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+    return rank, world, device
+
+
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def shard_batch(n: int, rank: int, world: int) -> slice:
+    """Contiguous shard of a global batch of n samples for this rank (last ranks get the shorter shards)."""
+    per = (n + world - 1) // world
+    return slice(min(n, rank * per), min(n, (rank + 1) * per))
+
+
+def _params_with_grad(params: Iterable[torch.Tensor]) -> List[torch.Tensor]:
+    return [p for p in params if p.grad is not None]
+
+
+def allreduce_gradients(module_or_params, average: bool = True, group=None, bucket_bytes: int = 64 << 20) -> int:
+    """Sum (or average) ``.grad`` over all ranks.  Returns the number of collectives issued.
+    Fast path: gradients that are consecutive views of one buffer -> ONE all-reduce in place.
+    General path: size-capped buckets, flattened, reduced and scattered back."""
+    params = list(module_or_params.parameters()) if isinstance(module_or_params, torch.nn.Module) else list(module_or_params)
+    params = _params_with_grad(params)
+    world = world_size(group)
+    if world == 1 or not params:
+        return 0
+    flat = flat_view_of([p.grad for p in params])
+    if flat is not None:
+        dist.all_reduce(flat, group=group)
+        if average:
+            flat.div_(world)
+        return 1
+    n_coll, bucket, size = 0, [], 0
+
+    def flush():
+        nonlocal n_coll, bucket, size
+        if not bucket:
+            return
+        buf = torch.cat([p.grad.reshape(-1) for p in bucket])
+        dist.all_reduce(buf, group=group)
+        if average:
+            buf.div_(world)
+        off = 0
+        for p in bucket:
+            n = p.grad.numel()
+            p.grad.copy_(buf[off:off + n].view_as(p.grad))
+            off += n
+        n_coll += 1
+        bucket, size = [], 0
+
+    for p in params:
+        b = p.grad.numel() * p.grad.element_size()
+        if bucket and size + b > bucket_bytes:
+            flush()
+        bucket.append(p)
+        size += b
+    flush()
+    return n_coll
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
+    """Make every rank start from rank ``src``'s parameters and buffers (one collective when the parameters are flat)."""
+    if world_size(group) == 1:
+        return
+    params = [p.data for p in module.parameters()]
+    flat = flat_view_of(params)
+    if flat is not None:
+        dist.broadcast(flat, src, group=group)
+    else:
+        for p in params:
+            dist.broadcast(p, src, group=group)
+    for b in module.buffers():
+        dist.broadcast(b, src, group=group)
+
+
+def gather_predictions(pred: torch.Tensor, group=None) -> torch.Tensor:
+    """Screening (BASELINE config 5): concatenate every rank's [n_local] predictions on all ranks (equal n_local)."""
+    world = world_size(group)
+    if world == 1:
+        return pred
+    out = [torch.empty_like(pred) for _ in range(world)]
+    dist.all_gather(out, pred.contiguous(), group=group)
+    return torch.cat(out)

@@ -1,0 +1,73 @@
+"""Stacked-ensemble predict surface of the reference (float64, host side: k <= 4 columns, N ~ 1e3 rows).
+
+The reference stacks out-of-fold predictions ``[nn, rf, xgb(, cat)]`` with a linear meta-learner --
+``Ridge(alpha=1.0)`` (Models/multi_input_data_regression_opt_transformer_cnn_opt.py:173-176), ``LinearRegression``
+(..._morgan.py, same lines; final estimator of the StackingRegressor at ...20250113.py:394-403) -- or a fixed weighted
+sum 0.4/0.3/0.3 (Models/multi_input_data_regression_opt_transformer_cnn.py:216-218), and later calls
+``loaded_stacked_model.predict([[nn_out, rf_pred, xgb_pred]])`` (..._opt.py:202-203).  Tree base learners are third-party
+CPU code and enter as precomputed columns.  The meta-learner is a 3-4 parameter least-squares problem, so it stays on the
+host in float64 like sklearn's; ``predict_device`` applies it to device-resident NN predictions during screening.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def weighted_ensemble(nn_pred, rf_pred, xgb_pred, weights=(0.4, 0.3, 0.3)):
+    """0.4*nn + 0.3*rf + 0.3*xgb (..._transformer_cnn.py:216-218)."""
+    a, b, c = (np.asarray(v, dtype=np.float64) for v in (nn_pred, rf_pred, xgb_pred))
+    return weights[0] * a + weights[1] * b + weights[2] * c
+
+
+class StackedEnsemble:
+    """Linear meta-learner with sklearn's attribute names: ``alpha=0`` is LinearRegression, ``alpha=1`` the
+    reference's Ridge.  The intercept is not penalised (sklearn semantics)."""
+
+    def __init__(self, alpha: float = 0.0):
+        if alpha < 0:
+            raise ValueError("alpha must be >= 0")
+        self.alpha = float(alpha)
+        self.coef_ = None
+        self.intercept_ = None
+
+    @classmethod
+    def from_coefficients(cls, coef, intercept, alpha: float = 0.0):
+        """Rebuild a fitted meta-learner, e.g. from the values stored in the reference's stacked_model*.pkl."""
+        self = cls(alpha)
+        self.coef_ = np.asarray(coef, dtype=np.float64).copy()
+        self.intercept_ = float(intercept)
+        return self
+
+    def fit(self, X, y):
+        X = np.asarray(X, dtype=np.float64)
+        y = np.asarray(y, dtype=np.float64).reshape(-1)
+        if X.ndim != 2 or X.shape[0] != y.shape[0]:
+            raise ValueError(f"X {X.shape} and y {y.shape} do not match")
+        xm, ym = X.mean(axis=0), y.mean()
+        Xc, yc = X - xm, y - ym
+        if self.alpha == 0.0:
+            self.coef_ = np.linalg.lstsq(Xc, yc, rcond=None)[0]
+        else:
+            self.coef_ = np.linalg.solve(Xc.T @ Xc + self.alpha * np.eye(X.shape[1]), Xc.T @ yc)
+        self.intercept_ = float(ym - xm @ self.coef_)
+        return self
+
+    def predict(self, X):
+        if self.coef_ is None:
+            raise RuntimeError("StackedEnsemble is not fitted")
+        X = np.asarray(X, dtype=np.float64)
+        if X.ndim != 2 or X.shape[1] != self.coef_.shape[0]:
+            raise ValueError(f"X has shape {X.shape}, expected [N, {self.coef_.shape[0]}]")
+        return X @ self.coef_ + self.intercept_
+
+    def predict_device(self, nn_pred, *other_columns):
+        """Same arithmetic on torch tensors (float64 on the tensors' device): screening keeps NN outputs on the GPU."""
+        import torch
+        cols = [nn_pred.reshape(-1).to(torch.float64)] + [torch.as_tensor(c, device=nn_pred.device).reshape(-1).to(torch.float64)
+                                                          for c in other_columns]
+        if len(cols) != self.coef_.shape[0]:
+            raise ValueError(f"{len(cols)} columns given, meta-learner has {self.coef_.shape[0]} coefficients")
+        out = torch.full_like(cols[0], self.intercept_)
+        for c, w in zip(cols, self.coef_):
+            out = out + float(w) * c
+        return out

@@ -1,0 +1,61 @@
+"""CPU: the C-ABI library loads, exports every symbol include/bbbp_hip.h declares, and the product path refuses to
+run without a GPU instead of falling back to anything."""
+import ctypes
+
+import pytest
+import torch
+
+import bbbp_amd
+from bbbp_amd import _lib, ops
+
+
+def test_library_exports_every_declared_symbol():
+    declared = _lib.declared_symbols()
+    assert len(declared) >= 25
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), f"{name} is declared in include/bbbp_hip.h but not exported by libbbbp_hip.so"
+    # every declared symbol has a ctypes signature and vice versa
+    assert sorted(_lib._SIGNATURES) == declared
+    assert _lib.lib().bbbp_abi_version() == 1
+
+
+def test_descriptor_and_plan_functions_without_gpu():
+    L = _lib.lib()
+    d = _lib.MixedDesc(batch=512, fingerprint_size=167, nhead=1, num_layers=6, dim_feedforward=2048, training=1,
+                       dropout_p=0.1, seed=1, need_input_grad=0)
+    assert L.bbbp_mixed_num_params(ctypes.byref(d)) == 106 == len(list(bbbp_amd.MixedInputModel(167, 128).parameters()))
+    ws = L.bbbp_mixed_workspace_bytes(ctypes.byref(d))
+    assert 0.9e9 < ws < 4e9                 # ~1.0 GB of saved activations + scratch at B = 512
+    bad = _lib.MixedDesc(batch=4, fingerprint_size=167, nhead=8, num_layers=6, dim_feedforward=2048)
+    assert L.bbbp_mixed_workspace_bytes(ctypes.byref(bad)) == 0
+    assert b"divisible" in L.bbbp_last_error()
+    assert L.bbbp_gemm_workspace_bytes(512, 128, 65536, 1) > 0          # split-K slabs for the image FC
+
+
+def test_no_cpu_fallback():
+    m = bbbp_amd.MixedInputModel(64, 128)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(2, 64), torch.zeros(2, 49152))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gemm(torch.zeros(2, 2), torch.zeros(2, 2))
+    with pytest.raises(ValueError):
+        bbbp_amd.MixedInputModel(64, 64)        # the reference's forward hard-codes 3x128x128
+
+
+def test_module_surface_matches_reference_contract():
+    m = bbbp_amd.MixedInputModel(167, 128)
+    keys = list(m.state_dict().keys())
+    assert keys[0] == "fingerprint_transformer.layers.0.self_attn.in_proj_weight"
+    assert "image_cnn.7.weight" in keys and "attention_fusion.attention_heads.3.2.bias" in keys
+    assert "fc.2.running_mean" in keys and "fc.2.num_batches_tracked" in keys and "fc.7.bias" in keys
+    assert sum(p.numel() for p in m.parameters()) == 13_464_087
+    assert m.nhead == 1 and bbbp_amd.MixedInputModel(64, 128).nhead == 8
+    # parameters live in one flat buffer, in named_parameters order, and stay so after dtype/device moves
+    from bbbp_amd.models import flat_view_of
+    assert flat_view_of(list(m.parameters())) is not None
+    m.float()
+    assert flat_view_of(list(m.parameters())) is not None
+    ds = bbbp_amd.MixedDataset([[1.0, 2.0]], [[3.0]], [0.5])
+    fp, img, y = ds[0]
+    assert len(ds) == 1 and fp.dtype == img.dtype == y.dtype == torch.float32 and y.dim() == 0

@@ -1,0 +1,45 @@
+"""CPU: stacked-ensemble surface against the oracle, scikit-learn and the reference's shipped meta-learners."""
+import numpy as np
+import pytest
+import torch
+
+from bbbp_amd.ensemble import StackedEnsemble, weighted_ensemble
+from oracle import reference_cpu as oracle
+
+
+def test_known_answer_meta_learners():
+    rng = np.random.default_rng(1)
+    X = rng.normal(size=(50, 3))
+    for name, (coef, icpt) in oracle.STACKED_KNOWN.items():
+        m = StackedEnsemble.from_coefficients(coef, icpt, alpha=1.0 if "maccs_opt" in name else 0.0)
+        np.testing.assert_allclose(m.predict(X), oracle.linear_predict(X, coef, icpt), rtol=0, atol=1e-15)
+        np.testing.assert_allclose(m.predict_device(torch.from_numpy(X[:, 0]), X[:, 1], X[:, 2]).numpy(), m.predict(X), atol=1e-14)
+    # single-molecule call shape used by the reference: predict([[nn, rf, xgb]])  (..._opt.py:202-203)
+    m = StackedEnsemble.from_coefficients(*oracle.STACKED_KNOWN["stacked_model.pkl"])
+    assert m.predict([[0.1, 0.2, 0.3]]).shape == (1,)
+
+
+@pytest.mark.parametrize("alpha", [0.0, 1.0])
+def test_fit_matches_sklearn_and_oracle(alpha):
+    from sklearn.linear_model import LinearRegression, Ridge
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=(1058, 4))                       # [nn, rf, xgb, cat] out-of-fold columns, B3DB size
+    y = X @ np.array([0.2, 0.5, 0.2, 0.1]) + 0.02 + 0.1 * rng.normal(size=1058)
+    sk = (Ridge(alpha=1.0) if alpha else LinearRegression()).fit(X, y)
+    m = StackedEnsemble(alpha).fit(X, y)
+    np.testing.assert_allclose(m.coef_, sk.coef_, rtol=1e-9)
+    np.testing.assert_allclose(m.intercept_, sk.intercept_, rtol=1e-9)
+    np.testing.assert_allclose(m.predict(X), sk.predict(X), rtol=1e-10)
+    c, b = oracle.linear_fit(X, y, alpha)
+    np.testing.assert_allclose(m.coef_, c, rtol=1e-12)
+    assert abs(m.intercept_ - b) < 1e-12
+
+
+def test_weighted_and_errors():
+    np.testing.assert_allclose(weighted_ensemble([1, 2], [3, 4], [5, 6]), oracle.weighted_ensemble([1, 2], [3, 4], [5, 6]))
+    with pytest.raises(RuntimeError):
+        StackedEnsemble().predict([[1, 2, 3]])
+    with pytest.raises(ValueError):
+        StackedEnsemble.from_coefficients([1, 2, 3], 0.0).predict([[1, 2]])
+    with pytest.raises(ValueError):
+        StackedEnsemble().fit(np.zeros((3, 2)), np.zeros(4))
