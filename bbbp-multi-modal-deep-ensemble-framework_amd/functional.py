@@ -113,3 +113,73 @@ def attention_fusion(module, x1, x2):
     w2 = [h[2].weight for h in heads]; b2 = [h[2].bias for h in heads]
     hid = _HeadHidden.apply(combined, *w1, *b1)
     return _FusionCombine.apply(combined, hid, *w2, *b2)
+
+
+class _BatchNorm1d(torch.autograd.Function):
+    """nn.BatchNorm1d forward/backward on the HIP kernels; running statistics are updated in place when training."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, momentum):
+        y, save_mean, save_rstd = ops.batchnorm1d_fwd(x, weight, bias, running_mean, running_var, training, eps, momentum)
+        ctx.training = training
+        ctx.save_for_backward(x, weight, save_mean, save_rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, save_mean, save_rstd = ctx.saved_tensors
+        dx, dg, db = ops.batchnorm1d_bwd(dy, x, weight, save_mean, save_rstd, ctx.training)
+        return dx, dg, db, None, None, None, None, None
+
+
+def batchnorm1d(x, bn: "torch.nn.BatchNorm1d"):
+    y = _BatchNorm1d.apply(x.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.eps,
+                           0.1 if bn.momentum is None else bn.momentum)
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return y
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return ops.dropout(x, p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout(dy.contiguous(), ctx.p, ctx.seed), None, None
+
+
+def dropout(x, p: float, training: bool):
+    """nn.Dropout: identity in eval mode; the mask stream is seeded from torch's CPU generator."""
+    if not training or p == 0.0:
+        return x
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return _Dropout.apply(x.contiguous(), float(p), seed)
+
+
+def run_sequential(seq, x):
+    """Execute an nn.Sequential of Linear / ReLU / Tanh / BatchNorm1d / Dropout on the HIP ops, fusing each
+    Linear with the activation that follows it (the reference's MLP branches are built this way)."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, torch.nn.Linear):
+            act = None
+            if i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.ReLU):
+                act, i = "relu", i + 1
+            elif i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.Tanh):
+                act, i = "tanh", i + 1
+            x = linear(x, m.weight, m.bias, act)
+        elif isinstance(m, torch.nn.BatchNorm1d):
+            x = batchnorm1d(x, m)
+        elif isinstance(m, torch.nn.Dropout):
+            x = dropout(x, m.p, m.training)
+        elif isinstance(m, (torch.nn.ReLU, torch.nn.Tanh)):
+            raise RuntimeError("activation without a preceding Linear is not on the reference's path")
+        else:
+            raise RuntimeError(f"unsupported module on the HIP path: {type(m).__name__}")
+        i += 1
+    return x

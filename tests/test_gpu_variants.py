@@ -1,0 +1,82 @@
+"""GPU: the reference's MLP-only model variants on the HIP ops, against the goldens of the reference classes, the
+shipped best_nn_model*.pth weights (tests/golden/*.pth are the reference's own data files) and the CPU oracle."""
+import os
+
+import pytest
+import torch
+
+from bbbp_amd.variants import DenseMLPModel, PCAFusionModel
+from bbbp_amd import MultiHeadAttentionFusion
+from oracle import reference_cpu as oracle
+from helpers import GOLDEN, assert_close, check_param_checksums, golden, synth_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,pth,F,I", [("pca_mlp_maccs_pth", "best_nn_model_maccs.pth", 64, 128),
+                                          ("pca_mlp_pth", "best_nn_model.pth", 128, 256)])
+def test_pca_fusion_model_with_shipped_weights(dev, name, pth, F, I):
+    g = golden(name)
+    sd = torch.load(os.path.join(GOLDEN, pth), map_location="cpu", weights_only=True)
+    check_param_checksums(g, sd)
+    m = PCAFusionModel(F, I)
+    m.load_state_dict(sd, strict=True)                   # drop-in: the reference's keys load unchanged
+    m = m.to(dev).eval()
+    for B in (1, 9):
+        fp, img, _ = synth_inputs(1000 + B, B, F, I)
+        with torch.no_grad():
+            out = m(fp.to(dev), img.to(dev))
+        assert_close(out.cpu().numpy(), g[f"eval/B{B}/out"], rtol=1e-4, atol_frac=2e-5, what=f"{name} B{B}")
+    # gradients vs the float64 oracle
+    fp, img, y = synth_inputs(5, 9, F, I)
+    p = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
+    oracle.mse_loss(oracle.pca_mlp_forward(p, fp.double(), img.double()), y.double()).backward()
+    m.train()
+    torch.nn.MSELoss()(m(fp.to(dev), img.to(dev)).squeeze(), y.to(dev)).backward()
+    for k, q in m.named_parameters():
+        if not k.startswith("attention_fusion."):
+            assert_close(q.grad.cpu().numpy(), p[k].grad.numpy(), rtol=1e-4, atol_frac=5e-5, what=k)
+
+
+def test_dense_mlp_model(dev):
+    g = golden("dense_mlp")
+    torch.manual_seed(5)
+    m = DenseMLPModel(167, 768)
+    check_param_checksums(g, m.state_dict())             # same seed => the reference's initial weights
+    m = m.to(dev).eval()
+    fp, img, _ = synth_inputs(1004, 4, 167, 768)
+    with torch.no_grad():
+        assert_close(m(fp.to(dev), img.to(dev)).cpu().numpy(), g["eval/B4/out"], rtol=1e-4, atol_frac=2e-5, what="dense eval")
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m.train()
+    fp, img, y = synth_inputs(1006, 6, 167, 768)
+    sd0 = {k: v.detach().cpu().double().clone() if v.dtype.is_floating_point else v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    out = m(fp.to(dev), img.to(dev))
+    assert_close(out.detach().cpu().numpy(), g["train/B6/out"], rtol=1e-4, atol_frac=2e-5, what="dense train")
+    torch.nn.MSELoss()(out.squeeze(), y.to(dev)).backward()
+    p = {k: v.requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd0.items()}
+    st = {}
+    oracle.mse_loss(oracle.dense_mlp_forward(p, fp.double(), img.double(), training=True, bn_state=st), y.double()).backward()
+    for k, q in m.named_parameters():
+        assert_close(q.grad.cpu().numpy(), p[k].grad.numpy(), rtol=2e-4, atol_frac=1e-4, what=k)
+    for k, v in st.items():
+        if "running" in k:
+            assert_close(m.state_dict()[k].cpu().numpy(), v.numpy(), rtol=1e-5, what=k)
+    assert int(m.state_dict()["fc.2.num_batches_tracked"]) == 1
+
+
+def test_standalone_fusion_block(dev):
+    torch.manual_seed(3)
+    f = MultiHeadAttentionFusion(256, num_heads=4, hidden_dim=128).to(dev)
+    x1, x2 = torch.randn(10, 128), torch.randn(10, 128)
+    p = {"f." + k: v.detach().cpu().double() for k, v in f.state_dict().items()}
+    want = oracle.attention_fusion(x1.double(), x2.double(), p, "f.")
+    a, b = x1.to(dev).requires_grad_(True), x2.to(dev).requires_grad_(True)
+    got = f(a, b)
+    assert_close(got.detach().cpu().numpy(), want.numpy(), rtol=1e-5, what="fusion fwd")
+    got.sum().backward()
+    # fusion == identity on cat(x1, x2): d(sum)/dx = 1 up to rounding
+    assert_close(a.grad.cpu().numpy(), torch.ones(10, 128).numpy(), rtol=1e-4, what="fusion dx1")
+    assert all(torch.isfinite(q.grad).all() for q in f.parameters())

@@ -118,10 +118,9 @@ def test_pca_mlp_shipped_weights(name, pth_F, pth_I):
     assert shapes[keys.index("fingerprint_fc.0.weight")] == f"128,{pth_F}"
     assert shapes[keys.index("image_fc.0.weight")] == f"128,{pth_I}"
     import os
-    pth = {"pca_mlp_maccs_pth": "/root/reference/Models/best_nn_model_maccs.pth",
-           "pca_mlp_pth": "/root/reference/Models/best_nn_model.pth"}[name]
-    if not os.path.exists(pth):
-        pytest.skip("reference .pth not present on this machine (data file of the reference, never copied)")
+    from helpers import GOLDEN
+    # tests/golden/*.pth are the reference's own weight files (data, shipped in Models/)
+    pth = os.path.join(GOLDEN, {"pca_mlp_maccs_pth": "best_nn_model_maccs.pth", "pca_mlp_pth": "best_nn_model.pth"}[name])
     sd = torch.load(pth, map_location="cpu", weights_only=True)
     check_param_checksums(g, sd)
     for B in (1, 9):
