@@ -54,6 +54,7 @@ _SIGNATURES = {
     "bbbp_adamw_step": (c_int, [c_void_p, _FP, _FP, _FP, _FP, c_long, c_float, c_float, c_float, c_float, c_float, c_int,
                                 c_float]),
     "bbbp_scale": (c_int, [c_void_p, _FP, c_long, c_float]),
+    "bbbp_set_partition": (c_int, [c_int, c_size_t]),
     "bbbp_profile_enable": (c_int, [c_int]),
     "bbbp_profile_num_sections": (c_int, []),
     "bbbp_profile_section_name": (c_char_p, [c_int]),

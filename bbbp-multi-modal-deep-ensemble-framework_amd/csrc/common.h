@@ -40,6 +40,14 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 
 int bbbp_num_cus();   // cached multiProcessorCount of the current device
 
+// CU partitioning for the two-branch overlap (engine.hip).  A persistent conv work-group takes >= 120 KB of a CU's
+// 160 KB LDS, so exactly one fits per CU; with `reserved_cus` > 0 the conv grids shrink to (CUs - reserved) and the
+// small side-stream kernels request `small_lds_pad` bytes (> 40 KB) so that they can ONLY land on the CUs the conv
+// grids left free.  Measured without it: a 5 us kernel sharing CUs with a conv kernel takes 35-85 us.
+extern int g_bbbp_reserved_cus;
+extern size_t g_bbbp_small_lds_pad;
+constexpr size_t BBBP_CONV_MIN_LDS = 120 * 1024;
+
 // exact f32 MFMA: D[32x32] += A[32x2] * B[2x32]; lane l holds A[l&31][l>>5], B[l>>5][l&31];
 // D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5) for register r of 16.
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -72,3 +80,7 @@ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, floa
     float u = (float)(v >> 8) * (1.0f / 16777216.0f);
     return u >= p ? inv_keep : 0.0f;
 }
+
+// Small latency-bound kernels run beside persistent MFMA-bound conv work-groups (engine.hip, two streams); raising
+// their wave priority lets them win issue arbitration against the older conv waves on the same SIMD.
+#define BBBP_HIGH_PRIO() __builtin_amdgcn_s_setprio(3)

@@ -645,15 +645,21 @@ int set_lds(K kernel, size_t bytes) {
 template <int CIN, int COUT, int W, int MODE>
 int launch_conv(const ConvParams& p, hipStream_t st) {
     using C = ConvCfg<CIN, COUT, W, MODE>;
-    int rc = set_lds(conv3x3_kernel<CIN, COUT, W, MODE>, C::LDS_BYTES);
+    // with reserved CUs: one work-group per CU (LDS request raised to >= 120 KB) on (CUs - reserved) CUs
+    const bool part = g_bbbp_reserved_cus > 0;
+    size_t lds = C::LDS_BYTES;
+    if (part && lds < BBBP_CONV_MIN_LDS) lds = BBBP_CONV_MIN_LDS;
+    int rc = set_lds(conv3x3_kernel<CIN, COUT, W, MODE>, lds > C::LDS_BYTES ? lds : C::LDS_BYTES);
     if (rc) return rc;
     int nstrips = p.B * (p.H / C::TH);
-    int per_cu = (int)((160 * 1024) / C::LDS_BYTES);
+    int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 2) per_cu = 2;
     if (per_cu < 1) per_cu = 1;
-    int grid = bbbp_num_cus() * per_cu;
+    int cus = bbbp_num_cus() - (part ? g_bbbp_reserved_cus : 0);
+    if (cus < 1) cus = 1;
+    int grid = cus * per_cu;
     if (grid > nstrips) grid = nstrips;
-    hipLaunchKernelGGL((conv3x3_kernel<CIN, COUT, W, MODE>), dim3(grid), dim3(512), C::LDS_BYTES, st, p);
+    hipLaunchKernelGGL((conv3x3_kernel<CIN, COUT, W, MODE>), dim3(grid), dim3(512), lds, st, p);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }
@@ -727,19 +733,23 @@ extern "C" int bbbp_conv3x3_relu_pool_bwd_weight(void* stream, const float* x, c
         return BBBP_OK;
     }
     int nstrips = B * (H / 2);
-    int grid = bbbp_num_cus();
+    const bool part = g_bbbp_reserved_cus > 0;
+    const int cus = bbbp_num_cus() - (part ? g_bbbp_reserved_cus : 0) > 0 ? bbbp_num_cus() - (part ? g_bbbp_reserved_cus : 0) : 1;
+    int grid = cus;
     if (grid > nstrips) grid = nstrips;
     float* slab = static_cast<float*>(workspace);
     WgradParams p{x, gy, mask, slab, nullptr, B, H};
     if (cin == 3) {
         using C = Wg3Cfg<128>;
-        grid = bbbp_num_cus() * 2;
+        size_t lds3 = C::LDS_BYTES;
+        if (part) lds3 = BBBP_CONV_MIN_LDS;          // one per CU on the unreserved CUs
+        grid = part ? cus : bbbp_num_cus() * 2;
         if (grid > nstrips) grid = nstrips;
         BBBP_CHECK_ARG(workspace_bytes >= (size_t)grid * (1024 + 32) * sizeof(float), "conv bwd_weight: workspace too small");
         p.bslab = slab + (size_t)grid * 1024;
-        int rc = set_lds(conv_wgrad3_kernel<128>, C::LDS_BYTES);
+        int rc = set_lds(conv_wgrad3_kernel<128>, lds3);
         if (rc) return rc;
-        hipLaunchKernelGGL((conv_wgrad3_kernel<128>), dim3(grid), dim3(512), C::LDS_BYTES, st, p);
+        hipLaunchKernelGGL((conv_wgrad3_kernel<128>), dim3(grid), dim3(512), lds3, st, p);
         BBBP_CHECK_LAUNCH();
         hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3(33), dim3(256), 0, st, slab, p.bslab, dw, db, grid);
         BBBP_CHECK_LAUNCH();

@@ -7,6 +7,7 @@
 // tensor and batch_first=False (R:110-111), so self-attention runs ACROSS the mini-batch: S = B, N = 1.
 #include "common.h"
 #include "bbbp_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -51,15 +52,20 @@ struct Bump {
 };
 
 struct LayerOff { size_t qkv, prob, ctx, z1, y1, hff, z2, y2, mean1, rstd1, mean2, rstd2; };
+// per-layer gradient buffers: weight-gradient kernels read them on a third stream while the dependency
+// chain moves on to the next layer, so they must not be recycled within one backward pass
+struct LayerGrad { size_t dyout, dz2, dz2d, dhff, dy1, dz1, dz1d, dqkv; };
 
 struct Plan {
     int B, F, NH, D, L, DFF;
     bool drop;
     LayerOff layer[32];
+    LayerGrad lgrad[32];
+    size_t scratch3, scratch3_bytes;
     size_t pool1, mask1, pool2, mask2;
     size_t combined, hid, attn, fused, h, hb, bn_mean, bn_rstd, h2, h3;
     // temporaries
-    size_t pd, scratch, scratch_bytes;
+    size_t pd, scratch, scratch_bytes, scratch2, scratch2_bytes;
     size_t dA, dB, dqkv, dprob, dctx, dhff, dpool2, dpool1, dcomb, dfused, dlogit, dpre, dh, dhb, dh2, dh3;
     size_t total;
 };
@@ -97,7 +103,17 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     if (sb < ((size_t)32 << 20)) sb = (size_t)32 << 20;
     p->scratch_bytes = sb;
     p->scratch = b.take(sb);
+    // the fingerprint branch runs on its own stream beside the image branch: it needs its own split-K scratch
+    p->scratch2_bytes = (size_t)32 << 20;
+    p->scratch2 = b.take(p->scratch2_bytes);
     // backward temporaries
+    for (int l = 0; l < p->L; ++l) {
+        LayerGrad& g = p->lgrad[l];
+        g.dyout = b.f(B * F); g.dz2 = b.f(B * F); g.dz2d = p->drop ? b.f(B * F) : g.dz2; g.dhff = b.f(B * DFF);
+        g.dy1 = b.f(B * F); g.dz1 = b.f(B * F); g.dz1d = p->drop ? b.f(B * F) : g.dz1; g.dqkv = b.f(B * 3 * F);
+    }
+    p->scratch3_bytes = (size_t)32 << 20;
+    p->scratch3 = b.take(p->scratch3_bytes);
     p->dA = b.f(B * F); p->dB = b.f(B * F); p->dqkv = b.f(B * 3 * F); p->dprob = b.f(NH * B * B); p->dctx = b.f(B * F);
     p->dhff = b.f(B * DFF); p->dpool2 = b.f(B * IMG_FLAT); p->dpool1 = b.f(B * C1 * (IMG / 2) * (IMG / 2));
     p->dcomb = b.f(B * COMB); p->dfused = b.f(B * COMB); p->dlogit = b.f(NHEADS_FUSION * B);
@@ -111,11 +127,76 @@ struct Ctx {
     hipStream_t st;
     char* ws;
     const Plan* p;
+    int side = 0;          // 0 main stream, 1 fingerprint-branch chain, 2 weight-gradient leaves: own scratch each
     float* f(size_t off) const { return reinterpret_cast<float*>(ws + off); }
     uint8_t* u8(size_t off) const { return reinterpret_cast<uint8_t*>(ws + off); }
-    void* scratch() const { return ws + p->scratch; }
-    size_t scratch_bytes() const { return p->scratch_bytes; }
+    void* scratch() const { return ws + (side == 0 ? p->scratch : side == 1 ? p->scratch2 : p->scratch3); }
+    size_t scratch_bytes() const { return side == 0 ? p->scratch_bytes : side == 1 ? p->scratch2_bytes : p->scratch3_bytes; }
 };
+
+// ---- two-branch overlap -------------------------------------------------------------------------
+// The fingerprint branch (encoder, F = 167: ~270 launches of a few microseconds each, latency-bound) and the image
+// branch (five persistent MFMA-bound conv kernels) are independent between the input and the fusion block.  They
+// are enqueued on two HIP streams (fork/join with events, graph-capturable) so the small kernels run in the shadow
+// of the conv kernels: their work-groups are sized to co-reside on a CU with a conv work-group.
+constexpr int NEV = 32;
+struct SideStream { hipStream_t s = nullptr; hipStream_t leaf = nullptr; hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr;
+                    hipEvent_t ev[NEV]; int next = 0; };
+SideStream g_side[64];
+bool overlap_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("BBBP_SINGLE_STREAM"); v = (e && e[0] == '1') ? 0 : 1; }
+    return v == 1;
+}
+int reserved_cus() {
+    static int v = -1;
+    // default 0: measured (tools/exp_overlap.py, bench sweeps) the reservation costs the conv kernels what it gives
+    if (v < 0) { const char* e = getenv("BBBP_RESERVED_CUS"); v = e ? atoi(e) : 0; if (v < 0 || v > 128) v = 0; }
+    return v;
+}
+// scoped CU partition (common.h): conv grids leave `reserved_cus()` CUs to the side stream's small kernels
+struct Partition {
+    bool on;
+    explicit Partition(bool enable) : on(enable && reserved_cus() > 0) {
+        if (on) { g_bbbp_reserved_cus = reserved_cus(); g_bbbp_small_lds_pad = 48 * 1024; }
+    }
+    ~Partition() { if (on) { g_bbbp_reserved_cus = 0; g_bbbp_small_lds_pad = 0; } }
+};
+int get_side(SideStream** out) {
+    int dev = 0;
+    BBBP_CHECK_HIP(hipGetDevice(&dev));
+    BBBP_CHECK_ARG(dev >= 0 && dev < 64, "device index %d", dev);
+    SideStream& ss = g_side[dev];
+    if (!ss.s) {
+        BBBP_CHECK_HIP(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
+        BBBP_CHECK_HIP(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
+        BBBP_CHECK_HIP(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
+        BBBP_CHECK_HIP(hipStreamCreateWithFlags(&ss.leaf, hipStreamNonBlocking));
+        BBBP_CHECK_HIP(hipEventCreateWithFlags(&ss.join2, hipEventDisableTiming));
+        for (int i = 0; i < NEV; ++i) BBBP_CHECK_HIP(hipEventCreateWithFlags(&ss.ev[i], hipEventDisableTiming));
+    }
+    *out = &ss;
+    return BBBP_OK;
+}
+int fork_side(hipStream_t main, SideStream* ss) {
+    BBBP_CHECK_HIP(hipEventRecord(ss->fork, main));
+    BBBP_CHECK_HIP(hipStreamWaitEvent(ss->s, ss->fork, 0));
+    return BBBP_OK;
+}
+// make stream `waiter` wait for everything enqueued so far on stream `producer`
+int after(SideStream* ss, hipStream_t producer, hipStream_t waiter) {
+    if (producer == waiter) return BBBP_OK;
+    hipEvent_t e = ss->ev[ss->next];
+    ss->next = (ss->next + 1) % NEV;
+    BBBP_CHECK_HIP(hipEventRecord(e, producer));
+    BBBP_CHECK_HIP(hipStreamWaitEvent(waiter, e, 0));
+    return BBBP_OK;
+}
+int join_side(hipStream_t main, SideStream* ss) {
+    BBBP_CHECK_HIP(hipEventRecord(ss->join, ss->s));
+    BBBP_CHECK_HIP(hipStreamWaitEvent(main, ss->join, 0));
+    return BBBP_OK;
+}
 
 #define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
@@ -213,40 +294,20 @@ extern "C" int bbbp_mixed_forward(void* stream, const bbbp_mixed_desc* d, const 
     const float p_drop = plan.drop ? d->dropout_p : 0.f;
     const float scale = 1.0f / sqrtf((float)D);
 
-    // ---- fingerprint branch: encoder (R:75-78, 110-111) --------------------------------------
-    const float* x = fingerprint;
-    Section* sec_enc = new Section(c.st, SEC_ENCODER_FWD);
-    struct Guard { Section*& p; ~Guard() { delete p; p = nullptr; } } enc_guard{sec_enc};
-    for (int l = 0; l < plan.L; ++l) {
-        const LayerOff& o = plan.layer[l];
-        float* qkv = c.f(o.qkv); float* prob = c.f(o.prob); float* ctx = c.f(o.ctx);
-        TRY(linear_fwd(c, x, F, P[ix.layer(l, L_INW)], P[ix.layer(l, L_INB)], qkv, 3 * F, B, 3 * F, F, 0));
-        // scores_h = scale * Q_h K_h^T
-        TRY(bbbp_gemm_f32(c.st, 0, 1, B, B, D, scale, qkv, 3 * F, qkv + F, 3 * F, prob, B, nullptr, nullptr, 0, 0, NH, D, D,
-                          (long)B * B, 0, c.scratch(), c.scratch_bytes()));
-        float* pd = plan.drop ? c.f(plan.pd) : prob;
-        TRY(bbbp_softmax_fwd(c.st, prob, pd, (long)NH * B, B, p_drop, site_seed(d->seed, l, 0)));
-        // ctx_h = Pd_h V_h
-        TRY(bbbp_gemm_f32(c.st, 0, 0, B, D, B, 1.f, pd, B, qkv + 2 * F, 3 * F, ctx, F, nullptr, nullptr, 0, 0, NH, (long)B * B,
-                          D, D, 0, c.scratch(), c.scratch_bytes()));
-        float* z1 = c.f(o.z1); float* y1 = c.f(o.y1);
-        TRY(linear_fwd(c, ctx, F, P[ix.layer(l, L_OUTW)], P[ix.layer(l, L_OUTB)], z1, F, B, F, F, 0));
-        TRY(bbbp_layernorm_fwd(c.st, z1, x, y1, P[ix.layer(l, L_N1W)], P[ix.layer(l, L_N1B)], c.f(o.mean1), c.f(o.rstd1), B, F,
-                               1e-5f, p_drop, site_seed(d->seed, l, 1)));
-        float* hff = c.f(o.hff); float* z2 = c.f(o.z2); float* y2 = c.f(o.y2);
-        TRY(linear_fwd(c, y1, F, P[ix.layer(l, L_W1)], P[ix.layer(l, L_B1)], hff, DFF, B, DFF, F, BBBP_ACT_RELU));
-        if (plan.drop) TRY(bbbp_dropout(c.st, hff, hff, (long)B * DFF, p_drop, site_seed(d->seed, l, 2)));
-        TRY(linear_fwd(c, hff, DFF, P[ix.layer(l, L_W2)], P[ix.layer(l, L_B2)], z2, F, B, F, DFF, 0));
-        TRY(bbbp_layernorm_fwd(c.st, z2, y1, y2, P[ix.layer(l, L_N2W)], P[ix.layer(l, L_N2B)], c.f(o.mean2), c.f(o.rstd2), B, F,
-                               1e-5f, p_drop, site_seed(d->seed, l, 3)));
-        x = y2;
+    // ---- fingerprint branch: encoder (R:75-78, 110-111), on the side stream -------------------
+    Ctx ce = c;
+    SideStream* ss = nullptr;
+    if (overlap_enabled()) {
+        TRY(get_side(&ss));
+        TRY(fork_side(c.st, ss));
+        ce.st = ss->s;
+        ce.side = 1;
     }
+    Partition* part = new Partition(ss != nullptr);
+    struct PGuard { Partition*& p; ~PGuard() { delete p; p = nullptr; } } part_guard{part};
     float* comb = c.f(plan.combined);
-    // fingerprint_fc (R:79-82, 112) -> combined[:, 0:128]
-    TRY(linear_fwd(c, x, F, P[ix.fpfc_w()], P[ix.fpfc_b()], comb, COMB, B, FC, F, BBBP_ACT_RELU));
-    delete sec_enc; sec_enc = nullptr;
 
-    // ---- image branch (R:84-94, 114-115) -------------------------------------------------------
+    // ---- image branch (R:84-94, 114-115): enqueued first so the GPU is busy while the host feeds the encoder's launches -------------------------------------------------------
     float* pool1 = c.f(plan.pool1); float* pool2 = c.f(plan.pool2);
     {
         Section s1(c.st, SEC_CONV1_FWD);
@@ -262,6 +323,42 @@ extern "C" int bbbp_mixed_forward(void* stream, const bbbp_mixed_desc* d, const 
         Section s3(c.st, SEC_IMGFC_FWD);
         TRY(linear_fwd(c, pool2, IMG_FLAT, P[ix.ifc_w()], P[ix.ifc_b()], comb + FC, COMB, B, FC, IMG_FLAT, BBBP_ACT_RELU));
     }
+
+
+    // ---- fingerprint branch body (side stream)
+    const float* x = fingerprint;
+    Section* sec_enc = new Section(ce.st, SEC_ENCODER_FWD);
+    struct Guard { Section*& p; ~Guard() { delete p; p = nullptr; } } enc_guard{sec_enc};
+    for (int l = 0; l < plan.L; ++l) {
+        const LayerOff& o = plan.layer[l];
+        float* qkv = c.f(o.qkv); float* prob = c.f(o.prob); float* ctx = c.f(o.ctx);
+        TRY(linear_fwd(ce, x, F, P[ix.layer(l, L_INW)], P[ix.layer(l, L_INB)], qkv, 3 * F, B, 3 * F, F, 0));
+        // scores_h = scale * Q_h K_h^T
+        TRY(bbbp_gemm_f32(ce.st, 0, 1, B, B, D, scale, qkv, 3 * F, qkv + F, 3 * F, prob, B, nullptr, nullptr, 0, 0, NH, D, D,
+                          (long)B * B, 0, ce.scratch(), ce.scratch_bytes()));
+        float* pd = plan.drop ? c.f(plan.pd) : prob;
+        TRY(bbbp_softmax_fwd(ce.st, prob, pd, (long)NH * B, B, p_drop, site_seed(d->seed, l, 0)));
+        // ctx_h = Pd_h V_h
+        TRY(bbbp_gemm_f32(ce.st, 0, 0, B, D, B, 1.f, pd, B, qkv + 2 * F, 3 * F, ctx, F, nullptr, nullptr, 0, 0, NH, (long)B * B,
+                          D, D, 0, ce.scratch(), ce.scratch_bytes()));
+        float* z1 = c.f(o.z1); float* y1 = c.f(o.y1);
+        TRY(linear_fwd(ce, ctx, F, P[ix.layer(l, L_OUTW)], P[ix.layer(l, L_OUTB)], z1, F, B, F, F, 0));
+        TRY(bbbp_layernorm_fwd(ce.st, z1, x, y1, P[ix.layer(l, L_N1W)], P[ix.layer(l, L_N1B)], c.f(o.mean1), c.f(o.rstd1), B, F,
+                               1e-5f, p_drop, site_seed(d->seed, l, 1)));
+        float* hff = c.f(o.hff); float* z2 = c.f(o.z2); float* y2 = c.f(o.y2);
+        TRY(linear_fwd(ce, y1, F, P[ix.layer(l, L_W1)], P[ix.layer(l, L_B1)], hff, DFF, B, DFF, F, BBBP_ACT_RELU));
+        if (plan.drop) TRY(bbbp_dropout(ce.st, hff, hff, (long)B * DFF, p_drop, site_seed(d->seed, l, 2)));
+        TRY(linear_fwd(ce, hff, DFF, P[ix.layer(l, L_W2)], P[ix.layer(l, L_B2)], z2, F, B, F, DFF, 0));
+        TRY(bbbp_layernorm_fwd(ce.st, z2, y1, y2, P[ix.layer(l, L_N2W)], P[ix.layer(l, L_N2B)], c.f(o.mean2), c.f(o.rstd2), B, F,
+                               1e-5f, p_drop, site_seed(d->seed, l, 3)));
+        x = y2;
+    }
+    // fingerprint_fc (R:79-82, 112) -> combined[:, 0:128]
+    TRY(linear_fwd(ce, x, F, P[ix.fpfc_w()], P[ix.fpfc_b()], comb, COMB, B, FC, F, BBBP_ACT_RELU));
+    delete sec_enc; sec_enc = nullptr;
+
+    if (ss) TRY(join_side(c.st, ss));        // fusion needs both halves of `combined`
+    delete part; part = nullptr;
     Section sec_head(c.st, SEC_HEAD_FWD);
 
     // ---- attention fusion (R:60-65, 117) -------------------------------------------------------
@@ -296,7 +393,21 @@ extern "C" int bbbp_mixed_backward(void* stream, const bbbp_mixed_desc* d, const
         bbbp_set_error("mixed_backward: workspace %zu < %zu bytes", workspace_bytes, plan.total);
         return BBBP_ERR_WORKSPACE;
     }
+    // Three streams: `c` (caller's stream) carries the head, the fusion block and the image branch; `ce` carries the
+    // fingerprint branch's dependency chain (dy -> dx through the encoder layers); `cl` carries the LEAVES -- weight
+    // and bias gradients, LayerNorm parameter gradients -- which nothing downstream waits for, so the chain's
+    // critical path is half as long.  With overlap disabled all three are the caller's stream.
     Ctx c{static_cast<hipStream_t>(stream), static_cast<char*>(workspace), &plan};
+    Ctx ce = c, cl = c;
+    SideStream* ss = nullptr;
+    if (overlap_enabled()) {
+        TRY(get_side(&ss));
+        TRY(fork_side(c.st, ss));                         // chain stream starts after the caller's prior work
+        ce.st = ss->s; ce.side = 1;
+        TRY(after(ss, c.st, ss->leaf));
+        cl.st = ss->leaf; cl.side = 2;
+    }
+    auto leaf_after = [&](const Ctx& producer) -> int { return ss ? after(ss, producer.st, cl.st) : BBBP_OK; };
     const PIdx ix(plan.L);
     const int B = plan.B, F = plan.F, NH = plan.NH, D = plan.D, DFF = plan.DFF;
     const float p_drop = plan.drop ? d->dropout_p : 0.f;
@@ -308,25 +419,27 @@ extern "C" int bbbp_mixed_backward(void* stream, const bbbp_mixed_desc* d, const
     float* dh3 = c.f(plan.dh3); float* dh2 = c.f(plan.dh2); float* dhb = c.f(plan.dhb); float* dh = c.f(plan.dh);
     float* dfused = c.f(plan.dfused); float* dcomb = c.f(plan.dcomb);
 
-    // ---- head ------------------------------------------------------------------------------------
+    // ---- head (chain on the caller's stream, leaves on the leaf stream) ---------------------------
     Section* sec = new Section(c.st, SEC_HEAD_BWD);
     struct Guard { Section*& p; ~Guard() { delete p; p = nullptr; } } sec_guard{sec};
     auto next_section = [&](int id) { delete sec; sec = nullptr; sec = new Section(c.st, id); };
     // fc.7: out = h3 W7^T + b7
-    TRY(linear_bwd_weight(c, dout, 1, h3, H3, G[ix.fc7_w()], B, 1, H3));
-    // db7 = sum(dout) (act = 0 leaves dy untouched, so the const_cast is safe)
-    TRY(bbbp_bias_act_bwd(c.st, const_cast<float*>(dout), 1, nullptr, 0, G[ix.fc7_b()], B, 1, 0, 1.f));
+    TRY(linear_bwd_weight(cl, dout, 1, h3, H3, G[ix.fc7_w()], B, 1, H3));
+    TRY(bbbp_bias_act_bwd(cl.st, const_cast<float*>(dout), 1, nullptr, 0, G[ix.fc7_b()], B, 1, 0, 1.f));   // act 0: dy untouched
     TRY(linear_bwd_input(c, dout, 1, P[ix.fc7_w()], dh3, H3, B, 1, H3));
     TRY(bbbp_bias_act_bwd(c.st, dh3, H3, h3, H3, G[ix.fc5_b()], B, H3, BBBP_ACT_RELU, 1.f));
-    TRY(linear_bwd_weight(c, dh3, H3, h2, H2, G[ix.fc5_w()], B, H3, H2));
+    TRY(leaf_after(c));
+    TRY(linear_bwd_weight(cl, dh3, H3, h2, H2, G[ix.fc5_w()], B, H3, H2));
     TRY(linear_bwd_input(c, dh3, H3, P[ix.fc5_w()], dh2, H2, B, H3, H2));
     TRY(bbbp_bias_act_bwd(c.st, dh2, H2, h2, H2, G[ix.fc3_b()], B, H2, BBBP_ACT_RELU, 1.f));
-    TRY(linear_bwd_weight(c, dh2, H2, hb, H1, G[ix.fc3_w()], B, H2, H1));
+    TRY(leaf_after(c));
+    TRY(linear_bwd_weight(cl, dh2, H2, hb, H1, G[ix.fc3_w()], B, H2, H1));
     TRY(linear_bwd_input(c, dh2, H2, P[ix.fc3_w()], dhb, H1, B, H2, H1));
     TRY(bbbp_batchnorm1d_bwd(c.st, dhb, h, P[ix.bn_w()], c.f(plan.bn_mean), c.f(plan.bn_rstd), dh, G[ix.bn_w()], G[ix.bn_b()], B,
                              H1, d->training));
     TRY(bbbp_bias_act_bwd(c.st, dh, H1, h, H1, G[ix.fc0_b()], B, H1, BBBP_ACT_RELU, 1.f));
-    TRY(linear_bwd_weight(c, dh, H1, fused, COMB, G[ix.fc0_w()], B, H1, COMB));
+    TRY(leaf_after(c));
+    TRY(linear_bwd_weight(cl, dh, H1, fused, COMB, G[ix.fc0_w()], B, H1, COMB));
     TRY(linear_bwd_input(c, dh, H1, P[ix.fc0_w()], dfused, COMB, B, H1, COMB));
 
     // ---- attention fusion ------------------------------------------------------------------------
@@ -334,21 +447,26 @@ extern "C" int bbbp_mixed_backward(void* stream, const bbbp_mixed_desc* d, const
     const float* w2[NHEADS_FUSION];
     for (int hh = 0; hh < NHEADS_FUSION; ++hh) w2[hh] = P[ix.fus(hh, 2)];
     TRY(bbbp_fusion_combine_bwd(c.st, dfused, comb, hid, c.f(plan.attn), w2, dcomb, dlogit, dpre, B, COMB, FUS_HID, NHEADS_FUSION));
+    TRY(leaf_after(c));
     for (int hh = 0; hh < NHEADS_FUSION; ++hh) {
         float* dl = dlogit + (size_t)hh * B;
         float* dp = dpre + (size_t)hh * B * FUS_HID;
         const float* hd = hid + (size_t)hh * B * FUS_HID;
-        TRY(linear_bwd_weight(c, dl, 1, hd, FUS_HID, G[ix.fus(hh, 2)], B, 1, FUS_HID));
-        TRY(bbbp_bias_act_bwd(c.st, dl, 1, nullptr, 0, G[ix.fus(hh, 3)], B, 1, 0, 1.f));
-        TRY(linear_bwd_weight(c, dp, FUS_HID, comb, COMB, G[ix.fus(hh, 0)], B, FUS_HID, COMB));
-        TRY(bbbp_bias_act_bwd(c.st, dp, FUS_HID, nullptr, 0, G[ix.fus(hh, 1)], B, FUS_HID, 0, 1.f));
+        TRY(linear_bwd_weight(cl, dl, 1, hd, FUS_HID, G[ix.fus(hh, 2)], B, 1, FUS_HID));
+        TRY(bbbp_bias_act_bwd(cl.st, dl, 1, nullptr, 0, G[ix.fus(hh, 3)], B, 1, 0, 1.f));
+        TRY(linear_bwd_weight(cl, dp, FUS_HID, comb, COMB, G[ix.fus(hh, 0)], B, FUS_HID, COMB));
+        TRY(bbbp_bias_act_bwd(cl.st, dp, FUS_HID, nullptr, 0, G[ix.fus(hh, 1)], B, FUS_HID, 0, 1.f));
         TRY(linear_bwd_input(c, dp, FUS_HID, P[ix.fus(hh, 0)], dcomb, COMB, B, FUS_HID, COMB, dcomb, COMB));
     }
     // ReLU of both branch outputs + their bias gradients (combined = [fp_out | img_out])
     TRY(bbbp_bias_act_bwd(c.st, dcomb, COMB, comb, COMB, G[ix.fpfc_b()], B, FC, BBBP_ACT_RELU, 1.f));
     TRY(bbbp_bias_act_bwd(c.st, dcomb + FC, COMB, comb + FC, COMB, G[ix.ifc_b()], B, FC, BBBP_ACT_RELU, 1.f));
 
-    // ---- image branch ----------------------------------------------------------------------------
+    // both branches only READ dcomb from here on
+    if (ss) { TRY(after(ss, c.st, ce.st)); TRY(after(ss, c.st, cl.st)); }
+    Partition part(ss != nullptr);
+
+    // ---- image branch (caller's stream): enqueued first, five long MFMA-bound kernels -------------------
     float* pool1 = c.f(plan.pool1); float* pool2 = c.f(plan.pool2);
     float* dpool2 = c.f(plan.dpool2); float* dpool1 = c.f(plan.dpool1);
     next_section(SEC_IMGFC_BWD);
@@ -363,65 +481,77 @@ extern "C" int bbbp_mixed_backward(void* stream, const bbbp_mixed_desc* d, const
     next_section(SEC_CONV1_WGRAD);
     TRY(bbbp_conv3x3_relu_pool_bwd_weight(c.st, image, dpool1, c.u8(plan.mask1), G[ix.c1_w()], G[ix.c1_b()], B, 3, C1, IMG, IMG,
                                           c.scratch(), c.scratch_bytes()));
+    delete sec; sec = nullptr;
 
-    // ---- fingerprint branch ----------------------------------------------------------------------
-    next_section(SEC_ENCODER_BWD);
+    // ---- fingerprint branch: chain on `ce`, leaves on `cl` --------------------------------------------
+    Section sec_encb(ce.st, SEC_ENCODER_BWD);
     const float* enc_out = plan.L > 0 ? c.f(plan.layer[plan.L - 1].y2) : fingerprint;
-    TRY(linear_bwd_weight(c, dcomb, COMB, enc_out, F, G[ix.fpfc_w()], B, FC, F));
-    float* dy = c.f(plan.dA);       // gradient wrt the current layer's output
-    float* dtmp = c.f(plan.dB);
-    if (plan.L > 0 || d->need_input_grad) TRY(linear_bwd_input(c, dcomb, COMB, P[ix.fpfc_w()], dy, F, B, FC, F));
-    float* dqkv = c.f(plan.dqkv); float* dprob = c.f(plan.dprob); float* dctx = c.f(plan.dctx); float* dhff = c.f(plan.dhff);
+    TRY(linear_bwd_weight(cl, dcomb, COMB, enc_out, F, G[ix.fpfc_w()], B, FC, F));
+    float* dy = plan.L > 0 ? c.f(plan.lgrad[plan.L - 1].dyout) : c.f(plan.dA);
+    if (plan.L > 0 || d->need_input_grad) TRY(linear_bwd_input(ce, dcomb, COMB, P[ix.fpfc_w()], dy, F, B, FC, F));
+    float* dprob = c.f(plan.dprob); float* dctx = c.f(plan.dctx);
     for (int l = plan.L - 1; l >= 0; --l) {
         const LayerOff& o = plan.layer[l];
+        const LayerGrad& g = plan.lgrad[l];
         const float* xin = l > 0 ? c.f(plan.layer[l - 1].y2) : fingerprint;
         float* qkv = c.f(o.qkv); float* prob = c.f(o.prob); float* ctx = c.f(o.ctx);
         float* z1 = c.f(o.z1); float* y1 = c.f(o.y1); float* hff = c.f(o.hff); float* z2 = c.f(o.z2);
-        // norm2: dz2 -> dtmp (residual grad, flows to y1), dropped copy -> dctx (reused as d(ff out))
-        float* dff = plan.drop ? dctx : dtmp;
-        TRY(bbbp_layernorm_bwd(c.st, dy, z2, P[ix.layer(l, L_N2W)], c.f(o.mean2), c.f(o.rstd2), dtmp, plan.drop ? dff : nullptr,
-                               G[ix.layer(l, L_N2W)], G[ix.layer(l, L_N2B)], B, F, p_drop, site_seed(d->seed, l, 3)));
-        // linear2
-        TRY(linear_bwd_weight(c, dff, F, hff, DFF, G[ix.layer(l, L_W2)], B, F, DFF));
-        TRY(bbbp_bias_act_bwd(c.st, dff, F, nullptr, 0, G[ix.layer(l, L_B2)], B, F, 0, 1.f));
-        TRY(linear_bwd_input(c, dff, F, P[ix.layer(l, L_W2)], dhff, DFF, B, F, DFF));
-        // relu (+ dropout: hff is the post-dropout value, so hff > 0 <=> relu active and kept)
-        TRY(bbbp_bias_act_bwd(c.st, dhff, DFF, hff, DFF, G[ix.layer(l, L_B1)], B, DFF, BBBP_ACT_RELU, inv_keep));
-        TRY(linear_bwd_weight(c, dhff, DFF, y1, F, G[ix.layer(l, L_W1)], B, DFF, F));
-        // dy1 = dhff W1 + dz2  -> dy
-        TRY(linear_bwd_input(c, dhff, DFF, P[ix.layer(l, L_W1)], dy, F, B, DFF, F, dtmp, F));
-        // norm1: dz1 -> dtmp (flows to the layer input), dropped copy -> dsa
-        float* dsa = plan.drop ? dctx : dtmp;
-        TRY(bbbp_layernorm_bwd(c.st, dy, z1, P[ix.layer(l, L_N1W)], c.f(o.mean1), c.f(o.rstd1), dtmp, plan.drop ? dsa : nullptr,
-                               G[ix.layer(l, L_N1W)], G[ix.layer(l, L_N1B)], B, F, p_drop, site_seed(d->seed, l, 1)));
-        // out_proj
-        TRY(linear_bwd_weight(c, dsa, F, ctx, F, G[ix.layer(l, L_OUTW)], B, F, F));
-        TRY(bbbp_bias_act_bwd(c.st, dsa, F, nullptr, 0, G[ix.layer(l, L_OUTB)], B, F, 0, 1.f));
-        float* dctx2 = dy;     // dy is free now (its value was consumed by norm1 backward)
-        TRY(linear_bwd_input(c, dsa, F, P[ix.layer(l, L_OUTW)], dctx2, F, B, F, F));
+        float* dyout = c.f(g.dyout); float* dz2 = c.f(g.dz2); float* dff = c.f(g.dz2d); float* dhff = c.f(g.dhff);
+        float* dy1 = c.f(g.dy1); float* dz1 = c.f(g.dz1); float* dsa = c.f(g.dz1d); float* dqkv = c.f(g.dqkv);
+        // norm2: dz2 (residual gradient, flows to y1) and its dropped copy dff (gradient of the FFN output)
+        TRY(bbbp_layernorm_bwd(ce.st, dyout, z2, P[ix.layer(l, L_N2W)], c.f(o.mean2), c.f(o.rstd2), dz2, plan.drop ? dff : nullptr,
+                               nullptr, nullptr, B, F, p_drop, site_seed(d->seed, l, 3)));
+        TRY(leaf_after(ce));
+        TRY(bbbp_layernorm_bwd(cl.st, dyout, z2, P[ix.layer(l, L_N2W)], c.f(o.mean2), c.f(o.rstd2), nullptr, nullptr,
+                               G[ix.layer(l, L_N2W)], G[ix.layer(l, L_N2B)], B, F, p_drop, 0));
+        TRY(linear_bwd_weight(cl, dff, F, hff, DFF, G[ix.layer(l, L_W2)], B, F, DFF));
+        TRY(bbbp_bias_act_bwd(cl.st, dff, F, nullptr, 0, G[ix.layer(l, L_B2)], B, F, 0, 1.f));
+        // linear2 input gradient, then ReLU (+ dropout: hff is the post-dropout value, hff > 0 <=> active and kept)
+        TRY(linear_bwd_input(ce, dff, F, P[ix.layer(l, L_W2)], dhff, DFF, B, F, DFF));
+        TRY(bbbp_bias_act_bwd(ce.st, dhff, DFF, hff, DFF, G[ix.layer(l, L_B1)], B, DFF, BBBP_ACT_RELU, inv_keep));
+        TRY(leaf_after(ce));
+        TRY(linear_bwd_weight(cl, dhff, DFF, y1, F, G[ix.layer(l, L_W1)], B, DFF, F));
+        // dy1 = dhff W1 + dz2
+        TRY(linear_bwd_input(ce, dhff, DFF, P[ix.layer(l, L_W1)], dy1, F, B, DFF, F, dz2, F));
+        // norm1
+        TRY(bbbp_layernorm_bwd(ce.st, dy1, z1, P[ix.layer(l, L_N1W)], c.f(o.mean1), c.f(o.rstd1), dz1, plan.drop ? dsa : nullptr,
+                               nullptr, nullptr, B, F, p_drop, site_seed(d->seed, l, 1)));
+        TRY(leaf_after(ce));
+        TRY(bbbp_layernorm_bwd(cl.st, dy1, z1, P[ix.layer(l, L_N1W)], c.f(o.mean1), c.f(o.rstd1), nullptr, nullptr,
+                               G[ix.layer(l, L_N1W)], G[ix.layer(l, L_N1B)], B, F, p_drop, 0));
+        TRY(linear_bwd_weight(cl, dsa, F, ctx, F, G[ix.layer(l, L_OUTW)], B, F, F));
+        TRY(bbbp_bias_act_bwd(cl.st, dsa, F, nullptr, 0, G[ix.layer(l, L_OUTB)], B, F, 0, 1.f));
+        // out_proj input gradient
+        TRY(linear_bwd_input(ce, dsa, F, P[ix.layer(l, L_OUTW)], dctx, F, B, F, F));
         // attention: Pd (dropped probabilities) is recomputed when dropout is on
         const float* pdp = prob;
         if (plan.drop) {
             float* pd = c.f(plan.pd);
-            TRY(bbbp_dropout(c.st, prob, pd, (long)NH * B * B, p_drop, site_seed(d->seed, l, 0)));
+            TRY(bbbp_dropout(ce.st, prob, pd, (long)NH * B * B, p_drop, site_seed(d->seed, l, 0)));
             pdp = pd;
         }
         // dV_h = Pd_h^T dctx_h  -> dqkv[:, 2F + hD]
-        TRY(bbbp_gemm_f32(c.st, 1, 0, B, D, B, 1.f, pdp, B, dctx2, F, dqkv + 2 * F, 3 * F, nullptr, nullptr, 0, 0, NH, (long)B * B,
-                          D, D, 0, c.scratch(), c.scratch_bytes()));
+        TRY(bbbp_gemm_f32(ce.st, 1, 0, B, D, B, 1.f, pdp, B, dctx, F, dqkv + 2 * F, 3 * F, nullptr, nullptr, 0, 0, NH, (long)B * B,
+                          D, D, 0, ce.scratch(), ce.scratch_bytes()));
         // dPd_h = dctx_h V_h^T
-        TRY(bbbp_gemm_f32(c.st, 0, 1, B, B, D, 1.f, dctx2, F, qkv + 2 * F, 3 * F, dprob, B, nullptr, nullptr, 0, 0, NH, D, D,
-                          (long)B * B, 0, c.scratch(), c.scratch_bytes()));
-        TRY(bbbp_softmax_bwd(c.st, dprob, prob, (long)NH * B, B, p_drop, site_seed(d->seed, l, 0)));
+        TRY(bbbp_gemm_f32(ce.st, 0, 1, B, B, D, 1.f, dctx, F, qkv + 2 * F, 3 * F, dprob, B, nullptr, nullptr, 0, 0, NH, D, D,
+                          (long)B * B, 0, ce.scratch(), ce.scratch_bytes()));
+        TRY(bbbp_softmax_bwd(ce.st, dprob, prob, (long)NH * B, B, p_drop, site_seed(d->seed, l, 0)));
         // dQ_h = scale dS_h K_h ; dK_h = scale dS_h^T Q_h
-        TRY(bbbp_gemm_f32(c.st, 0, 0, B, D, B, scale, dprob, B, qkv + F, 3 * F, dqkv, 3 * F, nullptr, nullptr, 0, 0, NH,
-                          (long)B * B, D, D, 0, c.scratch(), c.scratch_bytes()));
-        TRY(bbbp_gemm_f32(c.st, 1, 0, B, D, B, scale, dprob, B, qkv, 3 * F, dqkv + F, 3 * F, nullptr, nullptr, 0, 0, NH,
-                          (long)B * B, D, D, 0, c.scratch(), c.scratch_bytes()));
-        // in_proj
-        TRY(linear_bwd_weight(c, dqkv, 3 * F, xin, F, G[ix.layer(l, L_INW)], B, 3 * F, F));
-        TRY(bbbp_bias_act_bwd(c.st, dqkv, 3 * F, nullptr, 0, G[ix.layer(l, L_INB)], B, 3 * F, 0, 1.f));
-        if (l > 0 || d->need_input_grad) TRY(linear_bwd_input(c, dqkv, 3 * F, P[ix.layer(l, L_INW)], dy, F, B, 3 * F, F, dtmp, F));
+        TRY(bbbp_gemm_f32(ce.st, 0, 0, B, D, B, scale, dprob, B, qkv + F, 3 * F, dqkv, 3 * F, nullptr, nullptr, 0, 0, NH,
+                          (long)B * B, D, D, 0, ce.scratch(), ce.scratch_bytes()));
+        TRY(bbbp_gemm_f32(ce.st, 1, 0, B, D, B, scale, dprob, B, qkv, 3 * F, dqkv + F, 3 * F, nullptr, nullptr, 0, 0, NH,
+                          (long)B * B, D, D, 0, ce.scratch(), ce.scratch_bytes()));
+        TRY(leaf_after(ce));
+        TRY(linear_bwd_weight(cl, dqkv, 3 * F, xin, F, G[ix.layer(l, L_INW)], B, 3 * F, F));
+        TRY(bbbp_bias_act_bwd(cl.st, dqkv, 3 * F, nullptr, 0, G[ix.layer(l, L_INB)], B, 3 * F, 0, 1.f));
+        if (l > 0) TRY(linear_bwd_input(ce, dqkv, 3 * F, P[ix.layer(l, L_INW)], c.f(plan.lgrad[l - 1].dyout), F, B, 3 * F, F, dz1, F));
+        else if (d->need_input_grad) TRY(linear_bwd_input(ce, dqkv, 3 * F, P[ix.layer(l, L_INW)], c.f(plan.dA), F, B, 3 * F, F, dz1, F));
+    }
+    if (ss) {
+        TRY(join_side(c.st, ss));
+        BBBP_CHECK_HIP(hipEventRecord(ss->join2, ss->leaf));
+        BBBP_CHECK_HIP(hipStreamWaitEvent(c.st, ss->join2, 0));
     }
     return BBBP_OK;
 }

@@ -10,8 +10,8 @@
 //   TN: A[K][M], B[K][N]   dW = dy^T x, dV = P^T dO, dK = dS^T Q
 // Both LDS tiles are k-major ([BK][BM], [BK][BN]) so that the MFMA operand fetch
 // (lane l: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]) is a conflict-free ds_read_b32 of 32 consecutive
-// floats per half-wave.  m-major global tiles are transposed on the way into LDS (row stride
-// = 2 mod 8 keeps those ds_write_b32 conflict-free).  Arbitrary M, N, K and leading dimensions
+// floats per half-wave.  m-major global tiles are transposed on the way into LDS (odd row stride:
+// at most 2 lanes per bank, which ds_write_b32 absorbs).  Arbitrary M, N, K and leading dimensions
 // (the MACCS width is the prime 167): 16-byte loads when alignment allows, predicated scalar loads
 // otherwise, zero fill out of range.  Split-K writes raw partial slabs that a second kernel sums
 // in a fixed order (bit-reproducible; no float atomics).
@@ -20,7 +20,11 @@
 
 namespace {
 
-constexpr int BK = 16;
+// K depth of one LDS stage.  The 64x64 tile keeps 17 KB of LDS and ~32 VGPRs on purpose: the encoder's small
+// GEMMs run on a second stream BESIDE the persistent conv kernels (engine.hip), and a work-group only co-resides
+// with a 140 KB / 224-VGPR conv work-group if it is this small.  Measured: deeper stages (64) bought < 5 %
+// because these launches sit on the ~5 us per-kernel latency floor, not on MFMA issue.
+constexpr int bk_of(int tile) { return tile == 64 ? 16 : 32; }
 
 struct GemmParams {
     const float* A; const float* B; float* C;
@@ -54,15 +58,21 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // LAYOUT 0: NT, 1: NN, 2: TN
 template <int BM, int BN, int LAYOUT>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+    BBBP_HIGH_PRIO();
+    constexpr int BK = bk_of(BM);
     constexpr bool A_KMAJ = (LAYOUT == 2);
     constexpr bool B_KMAJ = (LAYOUT != 0);
-    constexpr int LDAS = BM + (A_KMAJ ? 4 : 2);
-    constexpr int LDBS = BN + (B_KMAJ ? 4 : 2);
+    // k-major global tiles land with 16-B stores (row stride % 4 == 0); m-major tiles are transposed with
+    // ds_write_b32 at an odd row stride: lanes (k-quad, row) then hit every bank at most twice (free on gfx950)
+    constexpr int LDAS = BM + (A_KMAJ ? 4 : 1);
+    constexpr int LDBS = BN + (B_KMAJ ? 4 : 1);
+    constexpr int QK = BK / 4;                    // 16-B quads along k per m-major row
+    constexpr int RPP = 256 / QK;                 // m-major rows covered per pass
     constexpr int WM = BM / 2, WN = BN / 2;      // 2 x 2 waves
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NA = BM * BK / 256 / 4;         // float4 per thread per operand tile
     constexpr int NB = BN * BK / 256 / 4;
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDAS + 2 * BK * LDBS];
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // 2 * BK * (LDAS + LDBS) floats
     float* As = smem;
     float* Bs = smem + 2 * BK * LDAS;
 
@@ -87,7 +97,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 int valid = (k < kend) ? min(4, p.M - m) : 0;
                 ra[i] = ld4(A + (long)k * p.lda + m, p.vecA, valid);
             } else {            // global [M][K]: quads along k
-                int row = (t >> 2) + i * 64, kq = t & 3;
+                int row = t / QK + i * RPP, kq = t % QK;
                 int m = m0 + row, k = k0 + kq * 4;
                 int valid = (m < p.M) ? min(4, kend - k) : 0;
                 ra[i] = ld4(A + (long)m * p.lda + k, p.vecA, valid);
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 int valid = (k < kend) ? min(4, p.N - n) : 0;
                 rb[i] = ld4(B + (long)k * p.ldb + n, p.vecB, valid);
             } else {            // global [N][K]
-                int row = (t >> 2) + i * 64, kq = t & 3;
+                int row = t / QK + i * RPP, kq = t % QK;
                 int n = n0 + row, k = k0 + kq * 4;
                 int valid = (n < p.N) ? min(4, kend - k) : 0;
                 rb[i] = ld4(B + (long)n * p.ldb + k, p.vecB, valid);
@@ -119,7 +129,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 int q = t % QPR, kr = t / QPR + i * (256 / QPR);
                 *reinterpret_cast<float4*>(as + kr * LDAS + q * 4) = ra[i];
             } else {
-                int row = (t >> 2) + i * 64, kq = t & 3;
+                int row = t / QK + i * RPP, kq = t % QK;
                 as[(kq * 4 + 0) * LDAS + row] = ra[i].x;
                 as[(kq * 4 + 1) * LDAS + row] = ra[i].y;
                 as[(kq * 4 + 2) * LDAS + row] = ra[i].z;
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 int q = t % QPR, kr = t / QPR + i * (256 / QPR);
                 *reinterpret_cast<float4*>(bs + kr * LDBS + q * 4) = rb[i];
             } else {
-                int row = (t >> 2) + i * 64, kq = t & 3;
+                int row = t / QK + i * RPP, kq = t % QK;
                 bs[(kq * 4 + 0) * LDBS + row] = rb[i].x;
                 bs[(kq * 4 + 1) * LDBS + row] = rb[i].y;
                 bs[(kq * 4 + 2) * LDBS + row] = rb[i].z;
@@ -217,6 +227,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 
 // sums the split-K slabs in split order and applies the epilogue
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
+    BBBP_HIGH_PRIO();
     const long mn = (long)p.M * p.N;
     const int batch = blockIdx.y;
     const float* S = p.slab + (long)batch * p.splits * mn;
@@ -232,11 +243,24 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
     }
 }
 
+template <int BM, int BN, int LAYOUT>
+void launch_one(const GemmParams& p, dim3 grid, hipStream_t st) {
+    constexpr int BK = bk_of(BM);
+    constexpr size_t lds = (size_t)2 * BK * ((BM + (LAYOUT == 2 ? 4 : 1)) + (BN + (LAYOUT != 0 ? 4 : 1))) * sizeof(float);
+    static bool attr_set = false;        // > 64 KB of dynamic LDS needs the opt-in once per kernel
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, LAYOUT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, LAYOUT>), grid, dim3(256), lds > g_bbbp_small_lds_pad ? lds : g_bbbp_small_lds_pad, st, p);
+}
+
 template <int BM, int BN>
 void launch_tile(const GemmParams& p, int layout, dim3 grid, hipStream_t st) {
-    if (layout == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0>), grid, dim3(256), 0, st, p);
-    else if (layout == 1) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 2>), grid, dim3(256), 0, st, p);
+    if (layout == 0) launch_one<BM, BN, 0>(p, grid, st);
+    else if (layout == 1) launch_one<BM, BN, 1>(p, grid, st);
+    else launch_one<BM, BN, 2>(p, grid, st);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -259,8 +283,11 @@ static void gemm_plan(int M, int N, int K, int batch, int* tile, int* splits, in
         if (s > maxs) s = maxs;
         if (s < 1) s = 1;
     }
+    const int BK = bk_of(*tile);
     int kc = cdiv(cdiv(K, s), BK) * BK;
+    if (kc < BK) kc = BK;
     s = cdiv(K, kc);
+    if (s < 1) s = 1;
     *splits = s;
     *kchunk = kc;
 }
@@ -300,12 +327,12 @@ extern "C" int bbbp_gemm_f32(void* stream, int transA, int transB, int M, int N,
         size_t need = (size_t)batch * p.splits * M * N * sizeof(float);
         if (!workspace || workspace_bytes < need) {   // no room: fall back to a single pass
             p.splits = 1;
-            p.kchunk = cdiv(K, BK) * BK;
+            p.kchunk = cdiv(K, bk_of(tile)) * bk_of(tile);
         } else {
             p.slab = static_cast<float*>(workspace);
         }
     }
-    if (K == 0) { p.splits = 1; p.kchunk = BK; }
+    if (K == 0) { p.splits = 1; p.kchunk = bk_of(tile); }
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid(cdiv(N, tile), cdiv(M, tile), batch * p.splits);
     BBBP_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
@@ -316,7 +343,7 @@ extern "C" int bbbp_gemm_f32(void* stream, int transA, int transB, int M, int N,
         long mn = (long)M * N;
         int gx = (int)((mn + 255) / 256);
         if (gx > 4096) gx = 4096;
-        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(gx, batch), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(gx, batch), dim3(256), g_bbbp_small_lds_pad, st, p);
         BBBP_CHECK_LAUNCH();
     }
     return BBBP_OK;

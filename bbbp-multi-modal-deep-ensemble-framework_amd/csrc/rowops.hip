@@ -28,6 +28,7 @@ __device__ __forceinline__ float wave_max(float v) {
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(float* x, const float* r, float* y, const float* gamma,
                                                            const float* beta, float* mean_out, float* rstd_out,
                                                            int rows, int cols, float eps, float p, uint64_t seed) {
+    BBBP_HIGH_PRIO();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(float* x, const floa
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dy, const float* z, const float* gamma,
                                                            const float* mean, const float* rstd, float* dz, float* dx,
                                                            int rows, int cols, float p, uint64_t seed) {
+    BBBP_HIGH_PRIO();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -85,6 +87,7 @@ constexpr int CW = 16, RL = 64;
 __global__ __launch_bounds__(1024) void layernorm_param_grad_kernel(const float* dy, const float* z, const float* mean,
                                                                    const float* rstd, float* dgamma, float* dbeta,
                                                                    int rows, int cols) {
+    BBBP_HIGH_PRIO();
     __shared__ float s1[RL][CW], s2[RL][CW];
     const int cl = threadIdx.x % CW, rl = threadIdx.x / CW;
     const int c = blockIdx.x * CW + cl;
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(1024) void layernorm_param_grad_kernel(const float*
 // softmax over the last dim, one wave per row, in place; optional dropout copy pd = dropout(p).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(float* x, float* pd, long rows, int cols, float p, uint64_t seed) {
+    BBBP_HIGH_PRIO();
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -129,6 +133,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(float* x, float* pd, l
 
 // ds = P * (dP - sum(dP * P)), dP = dpd * keep-scale.  In place over dpd.
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(float* dpd, const float* prob, long rows, int cols, float p, uint64_t seed) {
+    BBBP_HIGH_PRIO();
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -147,6 +152,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(float* dpd, const floa
 
 // y = x * keep-scale (forward and backward of nn.Dropout share this kernel and the seed)
 __global__ __launch_bounds__(256) void dropout_kernel(const float* x, float* y, long n, float p, uint64_t seed) {
+    BBBP_HIGH_PRIO();
     const float inv_keep = 1.f / (1.f - p);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
         y[i] = x[i] * dropout_scale(seed, (uint64_t)i, p, inv_keep);
@@ -159,6 +165,7 @@ __global__ __launch_bounds__(1024) void batchnorm_fwd_kernel(const float* x, flo
                                                             float* running_mean, float* running_var, float* save_mean,
                                                             float* save_rstd, int rows, int cols, float eps, float momentum,
                                                             int training) {
+    BBBP_HIGH_PRIO();
     __shared__ float red[16][64];
     __shared__ float smean[64], srstd[64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -211,6 +218,7 @@ __global__ __launch_bounds__(1024) void batchnorm_fwd_kernel(const float* x, flo
 __global__ __launch_bounds__(1024) void batchnorm_bwd_kernel(const float* dy, const float* x, const float* gamma,
                                                             const float* save_mean, const float* save_rstd, float* dx,
                                                             float* dgamma, float* dbeta, int rows, int cols, int training) {
+    BBBP_HIGH_PRIO();
     __shared__ float r1[16][64], r2[16][64];
     __shared__ float t1[64], t2[64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -249,6 +257,7 @@ __global__ __launch_bounds__(1024) void batchnorm_bwd_kernel(const float* dy, co
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void bias_act_bwd_kernel(float* dy, int lddy, const float* y, int ldy, float* db,
                                                            int rows, int cols, int act, float scale) {
+    BBBP_HIGH_PRIO();
     __shared__ float red[RL][CW];
     const int cl = threadIdx.x % CW, rl = threadIdx.x / CW;
     const int c = blockIdx.x * CW + cl;
@@ -280,6 +289,7 @@ struct FusionPtrs { const float* w2[8]; const float* b2[8]; };
 
 __global__ __launch_bounds__(256) void fusion_combine_fwd_kernel(const float* combined, const float* hid, FusionPtrs fp,
                                                                 float* out, float* attn, int rows, int dim, int hd, int nh) {
+    BBBP_HIGH_PRIO();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -307,6 +317,7 @@ __global__ __launch_bounds__(256) void fusion_combine_fwd_kernel(const float* co
 __global__ __launch_bounds__(256) void fusion_combine_bwd_kernel(const float* dout, const float* combined, const float* hid,
                                                                 const float* attn, FusionPtrs fp, float* dcombined,
                                                                 float* dlogit, float* dpre, int rows, int dim, int hd, int nh) {
+    BBBP_HIGH_PRIO();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -333,6 +344,7 @@ __global__ __launch_bounds__(256) void fusion_combine_bwd_kernel(const float* do
 // MSE: loss = mean((pred - y)^2); dpred = 2 (pred - y) / n * gscale.  Single block, fixed order.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mse_kernel(const float* pred, const float* y, float* loss, float* dpred, int n, float gscale) {
+    BBBP_HIGH_PRIO();
     __shared__ float red[256];
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -355,6 +367,7 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* pred, const float
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, long n, float decay,
                                                    float omb1, float beta2, float omb2, float step_size, float bc2_sqrt,
                                                    float eps, float gscale) {
+    BBBP_HIGH_PRIO();
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         float gi = g[i] * gscale;
         float pi = p[i] * decay;
@@ -367,6 +380,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
 }
 
 __global__ __launch_bounds__(256) void scale_kernel(float* x, long n, float s) {
+    BBBP_HIGH_PRIO();
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] *= s;
 }
 
@@ -386,7 +400,7 @@ extern "C" int bbbp_layernorm_fwd(void* stream, float* x_inout_z, const float* r
     BBBP_CHECK_ARG(rows >= 0 && cols > 0, "layernorm: bad shape %d x %d", rows, cols);
     BBBP_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "layernorm: bad dropout %f", dropout_p);
     if (rows == 0) return BBBP_OK;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, ST, x_inout_z, residual, y, gamma, beta,
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), g_bbbp_small_lds_pad, ST, x_inout_z, residual, y, gamma, beta,
                        mean, rstd, rows, cols, eps, dropout_p, seed);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
@@ -396,14 +410,18 @@ extern "C" int bbbp_layernorm_bwd(void* stream, const float* dy, const float* z,
                                   const float* rstd, float* dz, float* dx, float* dgamma, float* dbeta, int rows, int cols,
                                   float dropout_p, uint64_t seed) {
     BBBP_CHECK_ARG(rows >= 0 && cols > 0, "layernorm bwd: bad shape %d x %d", rows, cols);
-    if (rows > 0) {
-        hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, ST, dy, z, gamma, mean, rstd, dz, dx,
+    // dz == NULL skips the input gradient, dgamma == NULL skips the parameter gradients (the engine runs the two
+    // halves on different streams: the parameter gradients are off the critical dependency chain)
+    if (rows > 0 && dz) {
+        hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), g_bbbp_small_lds_pad, ST, dy, z, gamma, mean, rstd, dz, dx,
                            rows, cols, dropout_p, seed);
         BBBP_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3(cdiv(cols, CW)), dim3(1024), 0, ST, dy, z, mean, rstd, dgamma,
-                       dbeta, rows, cols);
-    BBBP_CHECK_LAUNCH();
+    if (dgamma) {
+        hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3(cdiv(cols, CW)), dim3(1024), g_bbbp_small_lds_pad, ST, dy, z, mean, rstd, dgamma,
+                           dbeta, rows, cols);
+        BBBP_CHECK_LAUNCH();
+    }
     return BBBP_OK;
 }
 
@@ -411,7 +429,7 @@ extern "C" int bbbp_softmax_fwd(void* stream, float* x_inout, float* dropped_out
                                 uint64_t seed) {
     BBBP_CHECK_ARG(rows >= 0 && cols > 0, "softmax: bad shape");
     if (rows == 0) return BBBP_OK;
-    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST, x_inout,
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), g_bbbp_small_lds_pad, ST, x_inout,
                        dropout_p > 0.f ? dropped_out : nullptr, rows, cols, dropout_p, seed);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
@@ -421,7 +439,7 @@ extern "C" int bbbp_softmax_bwd(void* stream, float* dprob_inout, const float* p
                                 uint64_t seed) {
     BBBP_CHECK_ARG(rows >= 0 && cols > 0, "softmax bwd: bad shape");
     if (rows == 0) return BBBP_OK;
-    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST, dprob_inout, prob, rows, cols,
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), g_bbbp_small_lds_pad, ST, dprob_inout, prob, rows, cols,
                        dropout_p, seed);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
@@ -434,7 +452,7 @@ extern "C" int bbbp_dropout(void* stream, const float* x, float* y, long n, floa
         if (x != y) BBBP_CHECK_HIP(hipMemcpyAsync(y, x, n * sizeof(float), hipMemcpyDeviceToDevice, ST));
         return BBBP_OK;
     }
-    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, ST, x, y, n, p, seed);
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), g_bbbp_small_lds_pad, ST, x, y, n, p, seed);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }
@@ -446,7 +464,7 @@ extern "C" int bbbp_batchnorm1d_fwd(void* stream, const float* x, float* y, cons
     // same failure mode as nn.BatchNorm1d on a single-row training batch (tiny-batch tails)
     BBBP_CHECK_ARG(!(training && rows <= 1), "Expected more than 1 value per channel when training, got input size [%d, %d]", rows, cols);
     if (rows == 0) return BBBP_OK;
-    hipLaunchKernelGGL(batchnorm_fwd_kernel, dim3(cdiv(cols, 64)), dim3(1024), 0, ST, x, y, gamma, beta, running_mean,
+    hipLaunchKernelGGL(batchnorm_fwd_kernel, dim3(cdiv(cols, 64)), dim3(1024), g_bbbp_small_lds_pad, ST, x, y, gamma, beta, running_mean,
                        running_var, save_mean, save_rstd, rows, cols, eps, momentum, training);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
@@ -456,7 +474,7 @@ extern "C" int bbbp_batchnorm1d_bwd(void* stream, const float* dy, const float* 
                                     const float* save_rstd, float* dx, float* dgamma, float* dbeta, int rows, int cols,
                                     int training) {
     BBBP_CHECK_ARG(cols > 0 && rows >= 0, "batchnorm bwd: bad shape");
-    hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3(cdiv(cols, 64)), dim3(1024), 0, ST, dy, x, gamma, save_mean, save_rstd, dx,
+    hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3(cdiv(cols, 64)), dim3(1024), g_bbbp_small_lds_pad, ST, dy, x, gamma, save_mean, save_rstd, dx,
                        dgamma, dbeta, rows, cols, training);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
@@ -466,7 +484,7 @@ extern "C" int bbbp_bias_act_bwd(void* stream, float* dy_inout, int lddy, const 
                                  int cols, int act, float scale) {
     BBBP_CHECK_ARG(cols > 0 && rows >= 0 && act >= 0 && act <= 2, "bias_act_bwd: bad args");
     BBBP_CHECK_ARG(act == 0 || y, "bias_act_bwd: activation output required");
-    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(cdiv(cols, CW)), dim3(1024), 0, ST, dy_inout, lddy, y, ldy, dbias, rows, cols,
+    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(cdiv(cols, CW)), dim3(1024), g_bbbp_small_lds_pad, ST, dy_inout, lddy, y, ldy, dbias, rows, cols,
                        act, scale);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
@@ -479,7 +497,7 @@ extern "C" int bbbp_fusion_combine_fwd(void* stream, const float* combined, cons
     if (rows == 0) return BBBP_OK;
     FusionPtrs fp;
     for (int h = 0; h < 8; ++h) { fp.w2[h] = h < num_heads ? w2[h] : nullptr; fp.b2[h] = h < num_heads ? b2[h] : nullptr; }
-    hipLaunchKernelGGL(fusion_combine_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, ST, combined, hid, fp, out, attn, rows,
+    hipLaunchKernelGGL(fusion_combine_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), g_bbbp_small_lds_pad, ST, combined, hid, fp, out, attn, rows,
                        dim, hidden, num_heads);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
@@ -492,7 +510,7 @@ extern "C" int bbbp_fusion_combine_bwd(void* stream, const float* dout, const fl
     if (rows == 0) return BBBP_OK;
     FusionPtrs fp;
     for (int h = 0; h < 8; ++h) { fp.w2[h] = h < num_heads ? w2[h] : nullptr; fp.b2[h] = nullptr; }
-    hipLaunchKernelGGL(fusion_combine_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, ST, dout, combined, hid, attn, fp,
+    hipLaunchKernelGGL(fusion_combine_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), g_bbbp_small_lds_pad, ST, dout, combined, hid, attn, fp,
                        dcombined, dlogit, dpre, rows, dim, hidden, num_heads);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
@@ -500,7 +518,7 @@ extern "C" int bbbp_fusion_combine_bwd(void* stream, const float* dout, const fl
 
 extern "C" int bbbp_mse(void* stream, const float* pred, const float* target, float* loss, float* dpred, int n, float grad_scale) {
     BBBP_CHECK_ARG(n > 0, "mse: empty input");
-    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(256), 0, ST, pred, target, loss, dpred, n, grad_scale);
+    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(256), g_bbbp_small_lds_pad, ST, pred, target, loss, dpred, n, grad_scale);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }
@@ -511,7 +529,7 @@ extern "C" int bbbp_adamw_step(void* stream, float* param, const float* grad, fl
     if (n == 0) return BBBP_OK;
     double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     float decay = (float)(1.0 - (double)lr * (double)weight_decay);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, ST, param, grad, exp_avg, exp_avg_sq, n, decay,
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), g_bbbp_small_lds_pad, ST, param, grad, exp_avg, exp_avg_sq, n, decay,
                        (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), (float)((double)lr / bc1),
                        (float)sqrt(bc2), eps, grad_scale);
     BBBP_CHECK_LAUNCH();
@@ -520,7 +538,7 @@ extern "C" int bbbp_adamw_step(void* stream, float* param, const float* grad, fl
 
 extern "C" int bbbp_scale(void* stream, float* x, long n, float s) {
     if (n == 0) return BBBP_OK;
-    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, ST, x, n, s);
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), g_bbbp_small_lds_pad, ST, x, n, s);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }

@@ -4,6 +4,8 @@
 #include <stdarg.h>
 
 static thread_local char g_err[512] = "";
+int g_bbbp_reserved_cus = 0;
+size_t g_bbbp_small_lds_pad = 0;
 
 void bbbp_set_error(const char* fmt, ...) {
     va_list ap;
@@ -27,3 +29,11 @@ int bbbp_num_cus() {
 }
 
 extern "C" int bbbp_abi_version(void) { return 1; }
+
+// Experiment / tuning knob: reserve CUs for side-stream kernels (see common.h).  Returns the previous reservation.
+extern "C" int bbbp_set_partition(int reserved_cus, size_t small_lds_pad) {
+    int prev = g_bbbp_reserved_cus;
+    g_bbbp_reserved_cus = reserved_cus;
+    g_bbbp_small_lds_pad = small_lds_pad;
+    return prev;
+}
