@@ -25,6 +25,7 @@
 //   second kernel sums the slabs in a fixed order (bit-reproducible; no float atomics).
 #include "common.h"
 #include "bbbp_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -44,84 +45,112 @@ struct ConvParams {
 
 template <int CIN, int COUT, int W, int MODE>
 struct ConvCfg {
-    static constexpr int CC = CIN >= 8 ? 8 : 4;              // channels per LDS chunk
+    static constexpr int NW = 4;                             // waves per work-group (one per SIMD)
+    static constexpr int NT = NW * 64;
+    static constexpr int CC = CIN >= 8 ? 8 : 4;              // channels per LDS stage
     static constexpr int NCH = (CIN + CC - 1) / CC;
     static constexpr int CINP = NCH * CC;
-    static constexpr int TH = 512 / W;                       // strip rows: 8 wave tiles of 2 x 32
+    static constexpr int TH = NT / W;                        // strip rows: NW wave tiles of 2 rows x 32 columns
     static constexpr int ROWS = TH + 2;
     static constexpr int LDW = W + 8;
     static constexpr int PLANE = ROWS * LDW;
-    static constexpr int CHUNK = CC * PLANE;                 // floats per strip buffer
-    static constexpr int WFLOATS = 9 * CINP * COUT;
+    static constexpr int XCHUNK = CC * PLANE;                // input floats per stage
+    static constexpr int WCHUNK = 9 * CC * COUT;             // weight floats per stage: [tap][ci in chunk][co]
+    static constexpr bool WRES = (NCH == 1);                 // a single chunk: weights stay resident
+    static constexpr int STAGE = XCHUNK + (WRES ? 0 : WCHUNK);
     static constexpr int MT = COUT / 32;
-    static constexpr size_t LDS_BYTES = (size_t)(WFLOATS + 2 * CHUNK) * sizeof(float);
+    static constexpr size_t LDS_BYTES = (size_t)(2 * STAGE + (WRES ? WCHUNK : 0)) * sizeof(float);
     static_assert(COUT % 32 == 0 && MT <= 2, "output channels: 32 or 64 per pass");
-    static_assert(W == 64 || W == 128 || W == 32, "row width");
+    static_assert(TH >= 2 && TH % 2 == 0 && W % 32 == 0, "tile shape");
     static_assert(CC % 2 == 0, "k pairs are adjacent channel planes");
 };
 
+// swap with the neighbouring lane (lane ^ 1) in one VALU op (DPP quad_perm [1,0,3,2])
+__device__ __forceinline__ float swap_lane1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+}
+
 template <int CIN, int COUT, int W, int MODE>
-__global__ __launch_bounds__(512) void conv3x3_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     using C = ConvCfg<CIN, COUT, W, MODE>;
-    constexpr int CC = C::CC, NCH = C::NCH, CINP = C::CINP, TH = C::TH, ROWS = C::ROWS, LDW = C::LDW,
-                  PLANE = C::PLANE, CHUNK = C::CHUNK, MT = C::MT;
+    constexpr int NT = C::NT, CC = C::CC, NCH = C::NCH, CINP = C::CINP, TH = C::TH, ROWS = C::ROWS, LDW = C::LDW,
+                  PLANE = C::PLANE, XCHUNK = C::XCHUNK, WCHUNK = C::WCHUNK, STAGE = C::STAGE, MT = C::MT;
+    constexpr bool WRES = C::WRES;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ws = smem;
-    float* Xs = smem + C::WFLOATS;
+    // stage s: [X chunk][W chunk]; resident weights (single-chunk layers) sit behind the two stages
+    float* Wres = smem + 2 * STAGE;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int H = p.H;
     const int strips_per_img = H / TH;
     const int nstrips = p.B * strips_per_img;
 
-    // resident weights + zero both strip buffers (halo columns / padded channel planes stay zero)
-    for (int i = t * 4; i < C::WFLOATS; i += 512 * 4)
-        *reinterpret_cast<float4*>(Ws + i) = *reinterpret_cast<const float4*>(p.wt + i);
-    for (int i = t * 4; i < 2 * CHUNK; i += 512 * 4)
-        *reinterpret_cast<float4*>(Xs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    // zero both input stages once: halo columns and padded channel planes are never written again
+    for (int s = 0; s < 2; ++s)
+        for (int i = t * 4; i < XCHUNK; i += NT * 4)
+            *reinterpret_cast<float4*>(smem + s * STAGE + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (WRES)
+        for (int i = t * 4; i < WCHUNK; i += NT * 4)
+            *reinterpret_cast<float4*>(Wres + i) = *reinterpret_cast<const float4*>(p.wt + i);
     __syncthreads();
 
-    // ---- strip loader (register staged) ----
+    // ---- stage loader (register staged): input strip chunk + (streamed) weight chunk ----
     constexpr int QW = (MODE == MODE_FWD) ? W / 4 : W / 8;      // work items per row
     constexpr int ITEMS = CC * ROWS * QW;
-    constexpr int NIT = (ITEMS + 511) / 512;
+    constexpr int NIT = (ITEMS + NT - 1) / NT;
+    constexpr int WQ = WRES ? 0 : WCHUNK / 4;                   // float4 of weights per stage
+    constexpr int WNIT = (WQ + NT - 1) / NT;
     float4 rg[NIT];
     uint32_t rm[NIT];
-    auto load_stage = [&](int strip, int chunk) {
+    f32x4 rw[WNIT > 0 ? WNIT : 1];     // clang vector type: the float4 struct array was demoted to scratch here
+    uint32_t okbits = 0;       // validity of the staged items (bit i), applied when they are written to LDS
+    // NOTE: every load below is UNCONDITIONAL (addresses are clamped into the tensor).  A load under a per-item
+    // `if` makes hipcc wait vmcnt(0) at the join, which exposed the full HBM latency once per stage.
+    auto load_stage = [&](int strip, int chunk) __attribute__((always_inline)) {
         const int b = strip / strips_per_img, h0 = (strip % strips_per_img) * TH;
+        okbits = 0;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            int idx = t + i * 512;
+            int idx = t + i * NT;
             int q = idx % QW, row = (idx / QW) % ROWS, ci = idx / (QW * ROWS);
             int c = chunk * CC + ci, hh = h0 - 1 + row;
             bool ok = idx < ITEMS && c < CIN && hh >= 0 && hh < H;
-            rg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            rm[i] = 0x04040404u;
-            if (ok) {
-                if (MODE == MODE_FWD) {
-                    rg[i] = *reinterpret_cast<const float4*>(p.x + (((long)b * CIN + c) * H + hh) * W + q * 4);
-                } else {
-                    long off = (((long)b * CIN + c) * (H / 2) + (hh >> 1)) * (W / 2) + q * 4;
-                    rg[i] = *reinterpret_cast<const float4*>(p.x + off);
-                    rm[i] = *reinterpret_cast<const uint32_t*>(p.xmask + off);
-                }
+            okbits |= (ok ? 1u : 0u) << i;
+            int cc = min(c, CIN - 1), hc = min(max(hh, 0), H - 1);
+            if (MODE == MODE_FWD) {
+                rg[i] = *reinterpret_cast<const float4*>(p.x + (((long)b * CIN + cc) * H + hc) * W + q * 4);
+            } else {
+                long off = (((long)b * CIN + cc) * (H / 2) + (hc >> 1)) * (W / 2) + q * 4;
+                rg[i] = *reinterpret_cast<const float4*>(p.x + off);
+                rm[i] = *reinterpret_cast<const uint32_t*>(p.xmask + off);
+            }
+        }
+        if (!WRES) {
+#pragma unroll
+            for (int i = 0; i < WNIT; ++i) {
+                int idx = min(t + i * NT, WQ - 1);           // float4 index within [tap][CC][COUT]
+                int tap = idx / (CC * COUT / 4), rem = idx % (CC * COUT / 4);
+                rw[i] = *reinterpret_cast<const f32x4*>(p.wt + ((long)tap * CINP + chunk * CC) * COUT + rem * 4);
             }
         }
     };
-    auto store_stage = [&](int strip, int buf) {
+    auto store_stage = [&](int strip, int buf) __attribute__((always_inline)) {
         const int h0 = (strip % strips_per_img) * TH;
-        float* xs = Xs + buf * CHUNK;
+        float* xs = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            int idx = t + i * 512;
+            int idx = t + i * NT;
             if (idx >= ITEMS) continue;
             int q = idx % QW, row = (idx / QW) % ROWS, ci = idx / (QW * ROWS);
+            const bool ok = (okbits >> i) & 1u;
             if (MODE == MODE_FWD) {
-                *reinterpret_cast<float4*>(xs + ci * PLANE + row * LDW + PADL + q * 4) = rg[i];
+                float4 v = rg[i];
+                v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+                *reinterpret_cast<float4*>(xs + ci * PLANE + row * LDW + PADL + q * 4) = v;
             } else {
                 // expand 4 pooled gradients to the 8 full-resolution columns of image row hh
                 int pr = ((h0 - 1 + row) & 1) * 2;     // (hh & 1) also for hh = -1 (two's complement)
-                uint32_t m = rm[i];
+                uint32_t m = ok ? rm[i] : 0x04040404u;
                 float4 lo, hi;
                 lo.x = ((m & 0xff) == (uint32_t)pr) ? rg[i].x : 0.f;
                 lo.y = ((m & 0xff) == (uint32_t)pr + 1) ? rg[i].x : 0.f;
@@ -134,6 +163,14 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(ConvParams p) {
                 float* d = xs + ci * PLANE + row * LDW + PADL + q * 8;
                 *reinterpret_cast<float4*>(d) = lo;
                 *reinterpret_cast<float4*>(d + 4) = hi;
+            }
+        }
+        if (!WRES) {
+            float* wsd = xs + XCHUNK;
+#pragma unroll
+            for (int i = 0; i < WNIT; ++i) {
+                int idx = t + i * NT;
+                if (idx < WQ) *reinterpret_cast<f32x4*>(wsd + idx * 4) = rw[i];
             }
         }
     };
@@ -174,23 +211,29 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(ConvParams p) {
             const bool have_next = nstrip < nstrips;
             if (have_next) load_stage(nstrip, nchunk);
 
-            const float* xs = Xs + buf * CHUNK + xbase;
-            const float* ws = Ws + (chunk * CC) * COUT + wbase;
+            const float* xs = smem + buf * STAGE + xbase;
+            const float* ws = (WRES ? Wres : smem + buf * STAGE + XCHUNK) + wbase;
+            // 9 taps x CC/2 channel pairs = NS k-steps, software pipelined: the LDS reads of step s+1 are issued
+            // BEFORE the MFMAs of step s (hipcc otherwise issues them after, exposing the LDS latency every step)
+            constexpr int NS = 9 * (CC / 2);
+            float a[2][MT], bb[2][2];
+            auto ld = [&](int st, float* av, float* bv) __attribute__((always_inline)) {
+                const int tap = st / (CC / 2), cp = st % (CC / 2), kh = tap / 3, kw = tap % 3;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int kh = tap / 3, kw = tap % 3;
+                for (int mt = 0; mt < MT; ++mt) av[mt] = ws[(tap * CC + 2 * cp) * COUT + mt * 32];
 #pragma unroll
-                for (int cp = 0; cp < CC / 2; ++cp) {
-                    float a[MT], bb[2];
+                for (int n = 0; n < 2; ++n) bv[n] = xs[(2 * cp) * PLANE + (n + kh) * LDW + kw];
+            };
+            ld(0, a[0], bb[0]);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) a[mt] = ws[(tap * CINP + 2 * cp) * COUT + mt * 32];
+            for (int st = 0; st < NS; ++st) {
+                if (st + 1 < NS) ld(st + 1, a[(st + 1) & 1], bb[(st + 1) & 1]);
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) bb[n] = xs[(2 * cp) * PLANE + (n + kh) * LDW + kw];
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int n = 0; n < 2; ++n) acc[mt][n] = mfma32(a[mt], bb[n], acc[mt][n]);
-                }
+                    for (int n = 0; n < 2; ++n) acc[mt][n] = mfma32(a[st & 1][mt], bb[st & 1][n], acc[mt][n]);
+                __builtin_amdgcn_sched_group_barrier(0x100, MT + 2, 0);     // DS reads of the next step first
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * 2, 0);     // then this step's MFMAs
             }
             if (have_next) store_stage(nstrip, buf ^ 1);
             __syncthreads();
@@ -198,24 +241,29 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(ConvParams p) {
         }
         // ---- epilogue ----
         if (MODE == MODE_FWD) {
+            // 2x2 max-pool: rows are the wave's two accumulator tiles, columns are lane pairs (2w, 2w+1).  Even lanes
+            // finish register r, odd lanes register r+1, so every lane stores: one DPP swap per value, half the stores.
             const int ph = (h0 + r0) >> 1, Hp = H / 2, Wp = W / 2;
+            const bool odd = j & 1;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v00 = acc[mt][0][r], v10 = acc[mt][1][r];
-                    float v01 = __shfl_xor(v00, 1), v11 = __shfl_xor(v10, 1);
+                for (int r = 0; r < 16; r += 2) {
+                    float a0 = acc[mt][0][r], a1 = acc[mt][0][r + 1];     // image row h:   registers r, r+1
+                    float b0 = acc[mt][1][r], b1 = acc[mt][1][r + 1];     // image row h+1
+                    float ra = swap_lane1(odd ? a0 : a1);                 // even gets odd's a0, odd gets even's a1
+                    float rb = swap_lane1(odd ? b0 : b1);
+                    float v00 = odd ? ra : a0, v01 = odd ? a1 : ra;
+                    float v10 = odd ? rb : b0, v11 = odd ? b1 : rb;
                     // PyTorch max-pool keeps the FIRST maximum in (h, w) scan order
                     float m = v00; int am = 0;
                     if (v01 > m) { m = v01; am = 1; }
                     if (v10 > m) { m = v10; am = 2; }
                     if (v11 > m) { m = v11; am = 3; }
-                    if ((j & 1) == 0) {
-                        int co = mt * 32 + mfma_row(r, lane);
-                        long o = (((long)b * COUT + co) * Hp + ph) * Wp + ((c0 + j) >> 1);
-                        p.y[o] = m > 0.f ? m : 0.f;
-                        p.ymask[o] = m > 0.f ? (uint8_t)am : (uint8_t)4;
-                    }
+                    int co = mt * 32 + mfma_row(r + (odd ? 1 : 0), lane);
+                    long o = (((long)b * COUT + co) * Hp + ph) * Wp + ((c0 + j) >> 1);
+                    p.y[o] = m > 0.f ? m : 0.f;
+                    p.ymask[o] = m > 0.f ? (uint8_t)am : (uint8_t)4;
                 }
             }
         } else {
@@ -302,32 +350,29 @@ __global__ __launch_bounds__(512) void conv_wgrad32_kernel(WgradParams p) {
     float bsum[DY_NIT];      // bias-gradient partial of this thread's fixed channel
 #pragma unroll
     for (int i = 0; i < DY_NIT; ++i) bsum[i] = 0.f;
-    auto load_stage = [&](int strip) {
+    auto load_stage = [&](int strip) __attribute__((always_inline)) {
         const int b = strip / strips_per_img, ph = strip % strips_per_img, h0 = ph * 2;
+        // unconditional loads from clamped addresses (a load under a per-item `if` makes hipcc wait vmcnt(0) at the
+        // join and exposes the HBM latency every strip); out-of-range items are zeroed with selects afterwards
 #pragma unroll
         for (int i = 0; i < DY_NIT; ++i) {
-            int idx = t + i * 512;
-            gq[i] = make_float4(0.f, 0.f, 0.f, 0.f); mq[i] = 0x04040404u;
-            if (idx < DY_ITEMS) {
-                int q = idx % (Wp / 4), co = idx / (Wp / 4);
-                long off = (((long)b * COUT + co) * Hp + ph) * Wp + q * 4;
-                gq[i] = *reinterpret_cast<const float4*>(p.gy + off);
-                mq[i] = *reinterpret_cast<const uint32_t*>(p.mask + off);
-            }
+            int idx = min(t + i * 512, DY_ITEMS - 1);
+            int q = idx % (Wp / 4), co = idx / (Wp / 4);
+            long off = (((long)b * COUT + co) * Hp + ph) * Wp + q * 4;
+            gq[i] = *reinterpret_cast<const float4*>(p.gy + off);
+            mq[i] = *reinterpret_cast<const uint32_t*>(p.mask + off);
         }
 #pragma unroll
         for (int i = 0; i < X_NIT; ++i) {
-            int idx = t + i * 512;
-            xq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < X_ITEMS) {
-                int q = idx % (W / 4), row = (idx / (W / 4)) % 4, ci = idx / (W / 4 * 4);
-                int hh = h0 - 1 + row;
-                if (hh >= 0 && hh < H)
-                    xq[i] = *reinterpret_cast<const float4*>(p.x + (((long)b * CIN + ci) * H + hh) * W + q * 4);
-            }
+            int idx = min(t + i * 512, X_ITEMS - 1);
+            int q = idx % (W / 4), row = (idx / (W / 4)) % 4, ci = idx / (W / 4 * 4);
+            int hh = h0 - 1 + row;
+            const bool ok = hh >= 0 && hh < H;
+            float4 v = *reinterpret_cast<const float4*>(p.x + (((long)b * CIN + ci) * H + min(max(hh, 0), H - 1)) * W + q * 4);
+            xq[i].x = ok ? v.x : 0.f; xq[i].y = ok ? v.y : 0.f; xq[i].z = ok ? v.z : 0.f; xq[i].w = ok ? v.w : 0.f;
         }
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](int buf) __attribute__((always_inline)) {
         float* dys = smem + buf * C::BUF;
         float* xs = dys + C::DYF;
 #pragma unroll
@@ -495,32 +540,29 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradParams p) {
     float bsum[DY_NIT];      // bias-gradient partial of this thread's fixed channel
 #pragma unroll
     for (int i = 0; i < DY_NIT; ++i) bsum[i] = 0.f;
-    auto load_stage = [&](int strip) {
+    auto load_stage = [&](int strip) __attribute__((always_inline)) {
         const int b = strip / strips_per_img, ph = strip % strips_per_img, h0 = ph * 2;
+        // unconditional loads from clamped addresses (a load under a per-item `if` makes hipcc wait vmcnt(0) at the
+        // join and exposes the HBM latency every strip); out-of-range items are zeroed with selects afterwards
 #pragma unroll
         for (int i = 0; i < DY_NIT; ++i) {
-            int idx = t + i * 512;
-            gq[i] = make_float4(0.f, 0.f, 0.f, 0.f); mq[i] = 0x04040404u;
-            if (idx < DY_ITEMS) {
-                int q = idx % (Wp / 4), co = idx / (Wp / 4);
-                long off = (((long)b * COUT + co) * Hp + ph) * Wp + q * 4;
-                gq[i] = *reinterpret_cast<const float4*>(p.gy + off);
-                mq[i] = *reinterpret_cast<const uint32_t*>(p.mask + off);
-            }
+            int idx = min(t + i * 512, DY_ITEMS - 1);
+            int q = idx % (Wp / 4), co = idx / (Wp / 4);
+            long off = (((long)b * COUT + co) * Hp + ph) * Wp + q * 4;
+            gq[i] = *reinterpret_cast<const float4*>(p.gy + off);
+            mq[i] = *reinterpret_cast<const uint32_t*>(p.mask + off);
         }
 #pragma unroll
         for (int i = 0; i < X_NIT; ++i) {
-            int idx = t + i * 512;
-            xq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < X_ITEMS) {
-                int q = idx % (W / 4), row = (idx / (W / 4)) % 4, ci = idx / (W / 4 * 4);
-                int hh = h0 - 1 + row;
-                if (hh >= 0 && hh < H)
-                    xq[i] = *reinterpret_cast<const float4*>(p.x + (((long)b * CIN + ci) * H + hh) * W + q * 4);
-            }
+            int idx = min(t + i * 512, X_ITEMS - 1);
+            int q = idx % (W / 4), row = (idx / (W / 4)) % 4, ci = idx / (W / 4 * 4);
+            int hh = h0 - 1 + row;
+            const bool ok = hh >= 0 && hh < H;
+            float4 v = *reinterpret_cast<const float4*>(p.x + (((long)b * CIN + ci) * H + min(max(hh, 0), H - 1)) * W + q * 4);
+            xq[i].x = ok ? v.x : 0.f; xq[i].y = ok ? v.y : 0.f; xq[i].z = ok ? v.z : 0.f; xq[i].w = ok ? v.w : 0.f;
         }
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](int buf) __attribute__((always_inline)) {
         float* dys = smem + buf * C::BUF;
         float* xs = dys + C::DYF;
 #pragma unroll
@@ -645,21 +687,26 @@ int set_lds(K kernel, size_t bytes) {
 template <int CIN, int COUT, int W, int MODE>
 int launch_conv(const ConvParams& p, hipStream_t st) {
     using C = ConvCfg<CIN, COUT, W, MODE>;
-    // with reserved CUs: one work-group per CU (LDS request raised to >= 120 KB) on (CUs - reserved) CUs
+    // 4-wave work-groups, 2-4 per CU: the co-resident groups hit their per-chunk barriers at different times, so a
+    // SIMD's MFMA pipe keeps being fed by the other group's wave (one 8-wave group per CU measured 79 % MFMA busy).
+    // With reserved CUs (two-branch overlap experiments): one work-group per CU, LDS request raised to >= 120 KB.
     const bool part = g_bbbp_reserved_cus > 0;
     size_t lds = C::LDS_BYTES;
     if (part && lds < BBBP_CONV_MIN_LDS) lds = BBBP_CONV_MIN_LDS;
-    int rc = set_lds(conv3x3_kernel<CIN, COUT, W, MODE>, lds > C::LDS_BYTES ? lds : C::LDS_BYTES);
+    int rc = set_lds(conv3x3_kernel<CIN, COUT, W, MODE>, lds);
     if (rc) return rc;
     int nstrips = p.B * (p.H / C::TH);
     int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > 2) per_cu = 2;
+    if (per_cu > 4) per_cu = 4;
     if (per_cu < 1) per_cu = 1;
+    static int cap = -1;
+    if (cap < 0) { const char* e = getenv("BBBP_CONV_PER_CU"); cap = e ? atoi(e) : 0; }
+    if (cap > 0 && per_cu > cap) per_cu = cap;
     int cus = bbbp_num_cus() - (part ? g_bbbp_reserved_cus : 0);
     if (cus < 1) cus = 1;
     int grid = cus * per_cu;
     if (grid > nstrips) grid = nstrips;
-    hipLaunchKernelGGL((conv3x3_kernel<CIN, COUT, W, MODE>), dim3(grid), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((conv3x3_kernel<CIN, COUT, W, MODE>), dim3(grid), dim3(C::NT), lds, st, p);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }

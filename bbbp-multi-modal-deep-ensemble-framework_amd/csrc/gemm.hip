@@ -39,14 +39,21 @@ struct GemmParams {
     int vecA, vecB;          // 16-byte global loads allowed
 };
 
-__device__ __forceinline__ float4 ld4(const float* p, bool vec, int valid) {
-    if (vec && valid >= 4) return *reinterpret_cast<const float4*>(p);
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid > 0) r.x = p[0];
-    if (valid > 1) r.y = p[1];
-    if (valid > 2) r.z = p[2];
-    if (valid > 3) r.w = p[3];
-    return r;
+// Four consecutive elements starting at p, `valid` (0..4) of them inside the matrix; the rest read as 0.
+// The loads are UNCONDITIONAL: out-of-range lanes read a clamped in-range address (or `safe`, the matrix base) and
+// are zeroed by selects.  A load under a per-lane `if` makes hipcc wait vmcnt(0) at the join, which serialised
+// every K stage behind a full memory round trip.  VEC: one 16-byte load (the host guarantees valid is 0 or 4).
+template <bool VEC>
+__device__ __forceinline__ float4 ld4(const float* p, const float* safe, int valid) {
+    const float* q = valid > 0 ? p : safe;
+    if (VEC) return *reinterpret_cast<const float4*>(q);
+    const int m = max(valid, 1) - 1;
+    return make_float4(q[0], q[min(1, m)], q[min(2, m)], q[min(3, m)]);
+}
+// ... and the zeroing select, applied when the staged registers are written to LDS (NOT right after the load: a
+// consumer next to the load would put the wait back in front of the MFMA block)
+__device__ __forceinline__ float4 mask4(float4 v, int valid) {
+    return make_float4(valid > 0 ? v.x : 0.f, valid > 1 ? v.y : 0.f, valid > 2 ? v.z : 0.f, valid > 3 ? v.w : 0.f);
 }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -55,8 +62,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-// LAYOUT 0: NT, 1: NN, 2: TN
-template <int BM, int BN, int LAYOUT>
+// LAYOUT 0: NT, 1: NN, 2: TN;  VEC: 16-byte global loads on both operands
+template <int BM, int BN, int LAYOUT, bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     BBBP_HIGH_PRIO();
     constexpr int BK = bk_of(BM);
@@ -86,8 +93,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const float* B = p.B + (long)batch * p.sB;
 
     float4 ra[NA], rb[NB];
+    int va[NA], vb[NB];          // valid element counts of the staged quads
 
-    auto load_tiles = [&](int k0) {
+    auto load_tiles = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if (A_KMAJ) {       // global [K][M]: quads along m
@@ -95,12 +103,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 int q = t % QPR, kr = t / QPR + i * (256 / QPR);
                 int k = k0 + kr, m = m0 + q * 4;
                 int valid = (k < kend) ? min(4, p.M - m) : 0;
-                ra[i] = ld4(A + (long)k * p.lda + m, p.vecA, valid);
+                ra[i] = ld4<VEC>(A + (long)k * p.lda + m, A, valid); va[i] = valid;
             } else {            // global [M][K]: quads along k
                 int row = t / QK + i * RPP, kq = t % QK;
                 int m = m0 + row, k = k0 + kq * 4;
                 int valid = (m < p.M) ? min(4, kend - k) : 0;
-                ra[i] = ld4(A + (long)m * p.lda + k, p.vecA, valid);
+                ra[i] = ld4<VEC>(A + (long)m * p.lda + k, A, valid); va[i] = valid;
             }
         }
 #pragma unroll
@@ -110,44 +118,46 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 int q = t % QPR, kr = t / QPR + i * (256 / QPR);
                 int k = k0 + kr, n = n0 + q * 4;
                 int valid = (k < kend) ? min(4, p.N - n) : 0;
-                rb[i] = ld4(B + (long)k * p.ldb + n, p.vecB, valid);
+                rb[i] = ld4<VEC>(B + (long)k * p.ldb + n, B, valid); vb[i] = valid;
             } else {            // global [N][K]
                 int row = t / QK + i * RPP, kq = t % QK;
                 int n = n0 + row, k = k0 + kq * 4;
                 int valid = (n < p.N) ? min(4, kend - k) : 0;
-                rb[i] = ld4(B + (long)n * p.ldb + k, p.vecB, valid);
+                rb[i] = ld4<VEC>(B + (long)n * p.ldb + k, B, valid); vb[i] = valid;
             }
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf) __attribute__((always_inline)) {
         float* as = As + buf * BK * LDAS;
         float* bs = Bs + buf * BK * LDBS;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
+            const float4 v = mask4(ra[i], va[i]);
             if (A_KMAJ) {
                 constexpr int QPR = BM / 4;
                 int q = t % QPR, kr = t / QPR + i * (256 / QPR);
-                *reinterpret_cast<float4*>(as + kr * LDAS + q * 4) = ra[i];
+                *reinterpret_cast<float4*>(as + kr * LDAS + q * 4) = v;
             } else {
                 int row = t / QK + i * RPP, kq = t % QK;
-                as[(kq * 4 + 0) * LDAS + row] = ra[i].x;
-                as[(kq * 4 + 1) * LDAS + row] = ra[i].y;
-                as[(kq * 4 + 2) * LDAS + row] = ra[i].z;
-                as[(kq * 4 + 3) * LDAS + row] = ra[i].w;
+                as[(kq * 4 + 0) * LDAS + row] = v.x;
+                as[(kq * 4 + 1) * LDAS + row] = v.y;
+                as[(kq * 4 + 2) * LDAS + row] = v.z;
+                as[(kq * 4 + 3) * LDAS + row] = v.w;
             }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
+            const float4 v = mask4(rb[i], vb[i]);
             if (B_KMAJ) {
                 constexpr int QPR = BN / 4;
                 int q = t % QPR, kr = t / QPR + i * (256 / QPR);
-                *reinterpret_cast<float4*>(bs + kr * LDBS + q * 4) = rb[i];
+                *reinterpret_cast<float4*>(bs + kr * LDBS + q * 4) = v;
             } else {
                 int row = t / QK + i * RPP, kq = t % QK;
-                bs[(kq * 4 + 0) * LDBS + row] = rb[i].x;
-                bs[(kq * 4 + 1) * LDBS + row] = rb[i].y;
-                bs[(kq * 4 + 2) * LDBS + row] = rb[i].z;
-                bs[(kq * 4 + 3) * LDBS + row] = rb[i].w;
+                bs[(kq * 4 + 0) * LDBS + row] = v.x;
+                bs[(kq * 4 + 1) * LDBS + row] = v.y;
+                bs[(kq * 4 + 2) * LDBS + row] = v.z;
+                bs[(kq * 4 + 3) * LDBS + row] = v.w;
             }
         }
     };
@@ -243,24 +253,25 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
     }
 }
 
-template <int BM, int BN, int LAYOUT>
+template <int BM, int BN, int LAYOUT, bool VEC>
 void launch_one(const GemmParams& p, dim3 grid, hipStream_t st) {
     constexpr int BK = bk_of(BM);
     constexpr size_t lds = (size_t)2 * BK * ((BM + (LAYOUT == 2 ? 4 : 1)) + (BN + (LAYOUT != 0 ? 4 : 1))) * sizeof(float);
     static bool attr_set = false;        // > 64 KB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, LAYOUT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, LAYOUT, VEC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, LAYOUT>), grid, dim3(256), lds > g_bbbp_small_lds_pad ? lds : g_bbbp_small_lds_pad, st, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, LAYOUT, VEC>), grid, dim3(256), lds > g_bbbp_small_lds_pad ? lds : g_bbbp_small_lds_pad, st, p);
 }
 
 template <int BM, int BN>
 void launch_tile(const GemmParams& p, int layout, dim3 grid, hipStream_t st) {
-    if (layout == 0) launch_one<BM, BN, 0>(p, grid, st);
-    else if (layout == 1) launch_one<BM, BN, 1>(p, grid, st);
-    else launch_one<BM, BN, 2>(p, grid, st);
+    const bool vec = p.vecA && p.vecB;
+    if (layout == 0) { if (vec) launch_one<BM, BN, 0, true>(p, grid, st); else launch_one<BM, BN, 0, false>(p, grid, st); }
+    else if (layout == 1) { if (vec) launch_one<BM, BN, 1, true>(p, grid, st); else launch_one<BM, BN, 1, false>(p, grid, st); }
+    else { if (vec) launch_one<BM, BN, 2, true>(p, grid, st); else launch_one<BM, BN, 2, false>(p, grid, st); }
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -273,6 +284,10 @@ static void gemm_plan(int M, int N, int K, int batch, int* tile, int* splits, in
     long t64 = (long)cdiv(M, 64) * cdiv(N, 64) * batch;
     int ncu = bbbp_num_cus();
     *tile = (t128 >= (long)ncu * 3 / 4) ? 128 : 64;
+    // Very deep K over a small output (the 65536-wide image FC forward): the 128x128 tile does 64 MFMAs per wave per
+    // stage, enough to cover the global-load latency of the next stage, and split-K supplies the parallelism; the
+    // 64x64 tile (8 MFMAs per stage) is latency-bound there (measured 36 vs ~90 TFLOP/s).
+    if (K >= 8192 && M >= 128 && N >= 128) *tile = 128;
     long tiles = (*tile == 128) ? t128 : t64;
     // Few output tiles and a deep K (weight gradients over the batch, the 65536-wide image FC, FFN2): these
     // launches are latency-bound at one work-group per tile, so spread K over ~2 work-groups per CU.
@@ -318,8 +333,10 @@ extern "C" int bbbp_gemm_f32(void* stream, int transA, int transB, int M, int N,
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
     p.sA = strideA; p.sB = strideB; p.sC = strideC; p.sR = strideR;
     p.alpha = alpha; p.act = act;
-    p.vecA = aligned16(A) && (lda % 4 == 0) && (strideA % 4 == 0);
-    p.vecB = aligned16(B) && (ldb % 4 == 0) && (strideB % 4 == 0);
+    // 16-byte loads need aligned bases/strides AND a contiguous extent that is a multiple of 4 (so that a quad is
+    // either fully inside or fully outside the matrix): K for an [M][K] / [N][K] operand, M or N for a [K][.] one
+    p.vecA = aligned16(A) && (lda % 4 == 0) && (strideA % 4 == 0) && ((transA ? M : K) % 4 == 0);
+    p.vecB = aligned16(B) && (ldb % 4 == 0) && (strideB % 4 == 0) && ((transB ? K : N) % 4 == 0);
     int tile;
     gemm_plan(M, N, K, batch, &tile, &p.splits, &p.kchunk);
     p.slab = nullptr;

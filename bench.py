@@ -111,7 +111,7 @@ def main():
 
     import bbbp_amd
     from bbbp_amd import _lib
-    from bbbp_amd.models import flat_view_of
+    from bbbp_amd import distributed as D
     from bbbp_amd.optim import AdamW
 
     torch.manual_seed(20250113)           # same initial weights on every rank
@@ -127,10 +127,8 @@ def main():
         loss = crit(out, y[s:s + BATCH])
         loss.backward()
         if world > 1:
-            g = flat_view_of([p.grad for p in params])
-            if g is None:
-                raise RuntimeError("gradients are not one flat buffer")
-            dist.all_reduce(g)                      # RCCL sum over xGMI; 1/world folded into the optimizer
+            # ONE RCCL sum over xGMI when the gradients are one flat buffer (they are); 1/world folded into AdamW
+            D.allreduce_gradients(params, average=False)
         opt.step(grad_scale=1.0 / world)
         opt.zero_grad(set_to_none=True)
         return loss

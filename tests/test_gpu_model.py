@@ -104,6 +104,28 @@ def test_full_gradients_against_oracle(dev):
         assert_close(q.grad.cpu().numpy(), p[k].grad.numpy(), rtol=1e-4, atol_frac=5e-5, what=k)
 
 
+def test_gradients_arrive_as_one_flat_buffer(dev):
+    """autograd adopts the backward's gradient views without copying, so AdamW and the RCCL all-reduce see ONE
+    contiguous buffer in named_parameters order (one launch / one collective)."""
+    from bbbp_amd.models import flat_view_of
+    from bbbp_amd.optim import AdamW
+    m = build(64, 5, dev).train()
+    opt = AdamW(m.parameters(), lr=1e-4, weight_decay=1e-5)
+    fp, img, y = synth_inputs(3, 4, 64, 49152)
+    for _ in range(2):
+        torch.nn.MSELoss()(m(fp.to(dev), img.to(dev)).squeeze(), y.to(dev)).backward()
+        params = list(m.parameters())
+        g = flat_view_of([p.grad for p in params])
+        assert g is not None and g.numel() == sum(p.numel() for p in params)
+        assert flat_view_of(params) is not None
+        before = params[0].detach().clone()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        assert not torch.equal(before, params[0])
+    st = opt.state[params[0]]
+    assert st["step"] == 2 and st["exp_avg"].shape == params[0].shape
+
+
 def test_batch_size_one_and_errors(dev):
     m = build(64, 1, dev)
     fp, img, _ = synth_inputs(5, 1, 64, 49152)
