@@ -288,6 +288,11 @@ static void gemm_plan(int M, int N, int K, int batch, int* tile, int* splits, in
     // stage, enough to cover the global-load latency of the next stage, and split-K supplies the parallelism; the
     // 64x64 tile (8 MFMAs per stage) is latency-bound there (measured 36 vs ~90 TFLOP/s).
     if (K >= 8192 && M >= 128 && N >= 128) *tile = 128;
+    // Deep K with a large, 128-divisible output (the F = 2048 encoder's FFN / projection GEMMs): same argument.
+    {
+        const long covered = (long)cdiv(M, 128) * 128 * (long)cdiv(N, 128) * 128;
+        if (K >= 512 && M >= 256 && N >= 256 && covered * 100 <= (long)M * N * 115) *tile = 128;
+    }
     long tiles = (*tile == 128) ? t128 : t64;
     // Few output tiles and a deep K (weight gradients over the batch, the 65536-wide image FC, FFN2): these
     // launches are latency-bound at one work-group per tile, so spread K over ~2 work-groups per CU.

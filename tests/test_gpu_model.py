@@ -188,3 +188,36 @@ def test_headline_batch_properties(dev):
         want = oracle.mixed_input_forward(p, fp[:16], img[:16], training=False)
         got = m(fp[:16].to(dev), img[:16].to(dev))
     assert_close(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol_frac=2e-5, what="sub-batch vs oracle")
+
+
+def test_morgan_width_2048_against_oracle(dev):
+    """BASELINE config 4 width: F = 2048 => nhead 256, head_dim 8 (batched K = 8 attention GEMMs), 160 M parameters."""
+    m = build(2048, 7, dev)
+    assert m.nhead == 256 and sum(p.numel() for p in m.parameters()) == 160_027_845
+    zero_dropout(m)
+    m.train()
+    B = 6
+    fp, img, y = synth_inputs(2048, B, 2048, 49152)
+    out = m(fp.to(dev), img.to(dev))
+    torch.nn.MSELoss()(out.squeeze(), y.to(dev)).backward()
+    p = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in m.state_dict().items()}
+    ref = oracle.mixed_input_forward(p, fp, img, training=True, bn_state={})
+    oracle.mse_loss(ref, y).backward()
+    assert_close(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol_frac=5e-5, what="F=2048 forward")
+    for k in ("fingerprint_transformer.layers.0.self_attn.in_proj_weight", "fingerprint_transformer.layers.5.linear2.weight",
+              "fingerprint_transformer.layers.2.norm1.weight", "fingerprint_fc.0.weight", "fc.7.weight"):
+        q = dict(m.named_parameters())[k]
+        assert_close(q.grad.cpu().numpy(), p[k].grad.numpy(), rtol=1e-3, atol_frac=2e-4, what=k)
+
+
+def test_screening_batch_1024_eval(dev):
+    """Inference shape of BASELINE config 5 (large eval batches => long attention rows): B = 1024 against the oracle."""
+    m = build(167, 20250113, dev).eval()
+    B = 1024
+    fp, img, _ = synth_inputs(555, B, 167, 49152)
+    with torch.no_grad():
+        got = m(fp.to(dev), img.to(dev))
+    p = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        want = oracle.mixed_input_forward(p, fp, img, training=False)
+    assert_close(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol_frac=2e-5, what="B=1024 eval")
