@@ -55,6 +55,7 @@ _SIGNATURES = {
                                 c_float]),
     "bbbp_scale": (c_int, [c_void_p, _FP, c_long, c_float]),
     "bbbp_set_partition": (c_int, [c_int, c_size_t]),
+    "bbbp_set_overlap": (c_int, [c_int]),
     "bbbp_profile_enable": (c_int, [c_int]),
     "bbbp_profile_num_sections": (c_int, []),
     "bbbp_profile_section_name": (c_char_p, [c_int]),

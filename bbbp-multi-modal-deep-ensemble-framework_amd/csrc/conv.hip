@@ -47,7 +47,7 @@ template <int CIN, int COUT, int W, int MODE>
 struct ConvCfg {
     static constexpr int NW = 4;                             // waves per work-group (one per SIMD)
     static constexpr int NT = NW * 64;
-    static constexpr int CC = CIN >= 8 ? 8 : 4;              // channels per LDS stage
+    static constexpr int CC = 4;                              // channels per LDS stage (8 measured equal; 4 halves the LDS footprint)
     static constexpr int NCH = (CIN + CC - 1) / CC;
     static constexpr int CINP = NCH * CC;
     static constexpr int TH = NT / W;                        // strip rows: NW wave tiles of 2 rows x 32 columns
@@ -697,7 +697,7 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
     if (rc) return rc;
     int nstrips = p.B * (p.H / C::TH);
     int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > 4) per_cu = 4;
+    if (per_cu > 2) per_cu = 2;      // measured: more than 2 groups per CU buys nothing and crowds out the side-stream kernels
     if (per_cu < 1) per_cu = 1;
     static int cap = -1;
     if (cap < 0) { const char* e = getenv("BBBP_CONV_PER_CU"); cap = e ? atoi(e) : 0; }

@@ -143,10 +143,10 @@ constexpr int NEV = 32;
 struct SideStream { hipStream_t s = nullptr; hipStream_t leaf = nullptr; hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr;
                     hipEvent_t ev[NEV]; int next = 0; };
 SideStream g_side[64];
+int g_overlap = -1;
 bool overlap_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("BBBP_SINGLE_STREAM"); v = (e && e[0] == '1') ? 0 : 1; }
-    return v == 1;
+    if (g_overlap < 0) { const char* e = getenv("BBBP_SINGLE_STREAM"); g_overlap = (e && e[0] == '1') ? 0 : 1; }
+    return g_overlap == 1;
 }
 int reserved_cus() {
     static int v = -1;
@@ -250,6 +250,9 @@ int linear_bwd_weight(const Ctx& c, const float* dy, int lddy, const float* x, i
 uint64_t site_seed(uint64_t seed, int layer, int site) { return seed * 0x9E3779B97F4A7C15ull + (uint64_t)(layer * 8 + site + 1); }
 
 }  // namespace
+
+// Branch overlap on/off at run time (default on; env BBBP_SINGLE_STREAM=1 starts with it off).  Returns the old value.
+extern "C" int bbbp_set_overlap(int on) { int old = overlap_enabled() ? 1 : 0; g_overlap = on ? 1 : 0; return old; }
 
 // Profiling: enable, run steps, synchronise the stream, then collect {sum of ms, launches} per section.
 extern "C" int bbbp_profile_enable(int on) { g_prof.on = on != 0; g_prof.n = 0; return BBBP_OK; }

@@ -101,13 +101,21 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal knob (not used by the driver): BBBP_BENCH_BACKEND=gloo lets N ranks share the GPUs that exist
+    # (a 1-GPU box) to exercise the multi-rank control flow; the real runs use RCCL, one GPU per rank.
+    backend = os.environ.get("BBBP_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import bbbp_amd
     from bbbp_amd import _lib
@@ -158,6 +166,22 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # outside the timed region: the same kernels with the branch overlap off, i.e. each conv kernel alone on the GPU
+    isolated = {}
+    if rank == 0:
+        old = L.bbbp_set_overlap(0)
+        for i in range(2):
+            step(i)
+        L.bbbp_profile_enable(1)
+        for i in range(5):
+            step(i)
+        torch.cuda.synchronize()
+        _lib.check(L.bbbp_profile_collect(ms_sum, cnt), "bbbp_profile_collect")
+        L.bbbp_profile_enable(0)
+        L.bbbp_set_overlap(old)
+        isolated = {L.bbbp_profile_section_name(i).decode(): ms_sum[i] / cnt[i] for i in range(nsec) if cnt[i]}
+    if world > 1:
+        dist.barrier()
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -176,6 +200,10 @@ def main():
             roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                             frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
                             flops_per_launch=conv2, ms_per_launch=round(cand[dom], 4),
+                            note="timed inside the training step, where the kernel shares the GPU with the fingerprint "
+                                 "branch's side-stream kernels; *_isolated = same kernel, overlap off, after the timed region",
+                            ms_per_launch_isolated=round(isolated.get(dom, 0.0), 4),
+                            frac_isolated=round(conv2 / (isolated[dom] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if isolated.get(dom) else None,
                             sections_ms={k: round(v, 4) for k, v in sections.items()})
         total_flops = sum(fl.values()) * 3 - fl["conv1"]          # bwd = 2 * fwd - conv1 dgrad
         result = {

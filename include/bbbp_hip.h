@@ -141,6 +141,7 @@ int bbbp_mixed_backward(void* stream, const bbbp_mixed_desc* d, const float* con
 /* ---- optional per-section timing (HIP events on the launch stream; used by bench.py's roofline leg) ----
  * enable(1), run steps, synchronise the stream, collect(ms_sum[n], count[n]) with n = num_sections(). */
 int bbbp_set_partition(int reserved_cus, size_t small_lds_pad);   /* CU partition knob, see csrc/common.h */
+int bbbp_set_overlap(int on);   /* two/three-stream branch overlap inside bbbp_mixed_forward/backward (default on) */
 int bbbp_profile_enable(int on);
 int bbbp_profile_num_sections(void);
 const char* bbbp_profile_section_name(int i);
