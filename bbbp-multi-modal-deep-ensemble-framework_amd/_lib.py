@@ -54,6 +54,9 @@ _SIGNATURES = {
     "bbbp_adamw_step": (c_int, [c_void_p, _FP, _FP, _FP, _FP, c_long, c_float, c_float, c_float, c_float, c_float, c_int,
                                 c_float]),
     "bbbp_scale": (c_int, [c_void_p, _FP, c_long, c_float]),
+    "bbbp_resize_bilinear_totensor": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _FP, c_void_p, c_void_p, c_int, c_void_p,
+                                              c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "bbbp_standardize_chunk": (c_int, [c_void_p, c_void_p, _FP, _FP, _FP, c_void_p, c_void_p, c_int, c_int, c_int]),
     "bbbp_set_partition": (c_int, [c_int, c_size_t]),
     "bbbp_set_overlap": (c_int, [c_int]),
     "bbbp_profile_enable": (c_int, [c_int]),

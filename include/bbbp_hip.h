@@ -109,6 +109,19 @@ int bbbp_adamw_step(void* stream, float* param, const float* grad, float* exp_av
                     float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale);
 int bbbp_scale(void* stream, float* x, long n, float s);
 
+/* ---- input pipeline at the tensor boundary (Descriptors/multi_input_data_preprocess_maccs_opt_IsolationForest_fixed_1.py) ----
+ * :56-71  PIL convert('RGB') + torchvision Resize((128,128)) + ToTensor: Pillow's fixed-point two-pass bilinear
+ *         resampling, bit-exact; coefficient tables (bounds [out][2] = {first, count}, kk [out][ksize] int32) come from
+ *         the host (preprocess.py: pil_resample_coeffs).  src [N][Hs][Ws][3] u8; tmp [N][Hs][Wo][3] u8 scratch;
+ *         dst_u8 [N][Ho][Wo][3] (optional); dst_chw [N][3][Ho][Wo] f32 = byte / 255.
+ * :86-101 StandardScaler().fit_transform over one chunk of rows of hstack([fingerprint u8, image f32]), float64
+ *         statistics, float32 output; mean_out / scale_out [F+I] optional. */
+int bbbp_resize_bilinear_totensor(void* stream, const uint8_t* src, uint8_t* tmp, uint8_t* dst_u8, float* dst_chw,
+                                  const int* bounds_x, const int* kk_x, int ksize_x, const int* bounds_y,
+                                  const int* kk_y, int ksize_y, int N, int Hs, int Ws, int Ho, int Wo);
+int bbbp_standardize_chunk(void* stream, const uint8_t* fingerprint_u8, const float* image, float* fingerprint_out,
+                           float* image_out, double* mean_out, double* scale_out, int rows, int F, int I);
+
 /* ---- whole-model entry points: MixedInputModel.forward (R:109-119) and its autograd ------------
  * params[]: device pointers in the reference's named_parameters() order:
  *   per encoder layer l (12): self_attn.in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias,

@@ -1,0 +1,60 @@
+"""GPU: the input pipeline kernels against Pillow / scikit-learn (through the oracle) -- bit-exact bytes for the resize,
+exact float32 equality for ToTensor, and <= 1 ulp-level agreement for the chunked StandardScaler."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from bbbp_amd import preprocess
+from oracle import preprocess_cpu as oracle
+from helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+PNGS = sorted(glob.glob(os.path.join(GOLDEN, "img", "*.png")))
+
+
+def test_real_molecule_images_bit_exact(dev):
+    from PIL import Image
+    batch = torch.from_numpy(np.stack([np.asarray(Image.open(p).convert("RGB")) for p in PNGS])).to(dev)
+    feats, bytes8 = preprocess.resize_totensor(batch, return_bytes=True)
+    assert feats.shape == (8, 49152)
+    for i, p in enumerate(PNGS):
+        assert np.array_equal(bytes8[i].cpu().numpy(), oracle.resized_bytes(p)), p           # bit-exact bytes
+        assert np.array_equal(feats[i].cpu().numpy(), oracle.load_image_features(p)), p      # exact float32
+    again = preprocess.load_image_features(PNGS, device=dev)
+    assert torch.equal(again, feats)
+
+
+def test_random_images_and_sizes_bit_exact(dev):
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    for (h, w) in ((300, 300), (64, 200), (500, 333)):
+        a = rng.integers(0, 256, size=(3, h, w, 3), dtype=np.uint8)
+        _, b8 = preprocess.resize_totensor(torch.from_numpy(a).to(dev), return_bytes=True)
+        for i in range(3):
+            want = np.asarray(Image.fromarray(a[i]).resize((128, 128), Image.BILINEAR))
+            assert np.array_equal(b8[i].cpu().numpy(), want), (h, w, i)
+    assert preprocess.resize_totensor(torch.zeros((0, 300, 300, 3), dtype=torch.uint8, device=dev)).shape == (0, 49152)
+    with pytest.raises(RuntimeError):
+        preprocess.resize_totensor(torch.zeros((1, 300, 300, 3), dtype=torch.uint8))          # CPU tensor
+
+
+def test_chunked_standard_scaler_matches_sklearn(dev):
+    rng = np.random.default_rng(2)
+    N, F = 230, 167                                     # 3 chunks: 100, 100, 30 (ragged tail)
+    maccs = (rng.random((N, F)) < 0.25).astype(np.uint8)
+    maccs[:, 0] = 0                                     # constant column: scale -> 1 (sklearn keeps the values)
+    imgs = np.stack([oracle.load_image_features(PNGS[i % 8]) for i in range(N)])
+    imgs += rng.normal(scale=0.01, size=imgs.shape).astype(np.float32) * (rng.random(imgs.shape) < 0.3)
+    imgs = imgs.astype(np.float32)
+    want_fp, want_img = oracle.standardize_features(maccs, imgs, batch_size=100)
+    got_fp, got_img = preprocess.standardize_features(torch.from_numpy(maccs).to(dev), torch.from_numpy(imgs).to(dev), 100)
+    for got, want, nm in ((got_fp.cpu().numpy(), want_fp, "fp"), (got_img.cpu().numpy(), want_img, "img")):
+        assert got.dtype == np.float32 and got.shape == want.shape
+        diff = np.abs(got.astype(np.float64) - want.astype(np.float64))
+        tol = 2e-6 * np.maximum(1.0, np.abs(want))
+        assert (diff <= tol).all(), f"{nm}: max diff {diff.max():.3e}"
+        assert np.mean(got == want) > 0.99, f"{nm}: only {np.mean(got == want):.4f} of the values are bit-identical"
+    assert float(np.abs(got_fp[:, 0].cpu().numpy()).max()) == 0.0
