@@ -41,6 +41,7 @@ struct ConvParams {
     float* y;              // FWD: pooled [B][COUT][H/2][W/2];  DGRAD: [B][COUT][H][W]
     uint8_t* ymask;        // FWD: [B][COUT][H/2][W/2]
     int B, H;
+    int co_total;          // all output channels; the kernel computes COUT of them per work item (block cb)
 };
 
 template <int CIN, int COUT, int W, int MODE>
@@ -83,7 +84,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int H = p.H;
     const int strips_per_img = H / TH;
-    const int nstrips = p.B * strips_per_img;
+    const int ncb = p.co_total / COUT;                        // output-channel blocks; work item = (strip, block)
+    const int nstrips = p.B * strips_per_img * ncb;           // (named nstrips for history: number of work items)
+    const int CO_T = p.co_total;
 
     // zero both input stages once: halo columns and padded channel planes are never written again
     for (int s = 0; s < 2; ++s)
@@ -106,7 +109,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     uint32_t okbits = 0;       // validity of the staged items (bit i), applied when they are written to LDS
     // NOTE: every load below is UNCONDITIONAL (addresses are clamped into the tensor).  A load under a per-item
     // `if` makes hipcc wait vmcnt(0) at the join, which exposed the full HBM latency once per stage.
-    auto load_stage = [&](int strip, int chunk) __attribute__((always_inline)) {
+    auto load_stage = [&](int work, int chunk) __attribute__((always_inline)) {
+        const int strip = work / ncb, cb = work % ncb;
         const int b = strip / strips_per_img, h0 = (strip % strips_per_img) * TH;
         okbits = 0;
 #pragma unroll
@@ -130,12 +134,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
             for (int i = 0; i < WNIT; ++i) {
                 int idx = min(t + i * NT, WQ - 1);           // float4 index within [tap][CC][COUT]
                 int tap = idx / (CC * COUT / 4), rem = idx % (CC * COUT / 4);
-                rw[i] = *reinterpret_cast<const f32x4*>(p.wt + ((long)tap * CINP + chunk * CC) * COUT + rem * 4);
+                int cil = rem / (COUT / 4), q4 = rem % (COUT / 4);
+                rw[i] = *reinterpret_cast<const f32x4*>(p.wt + ((long)tap * CINP + chunk * CC + cil) * CO_T + cb * COUT + q4 * 4);
             }
         }
     };
-    auto store_stage = [&](int strip, int buf) __attribute__((always_inline)) {
-        const int h0 = (strip % strips_per_img) * TH;
+    auto store_stage = [&](int work, int buf) __attribute__((always_inline)) {
+        const int h0 = ((work / ncb) % strips_per_img) * TH;
         float* xs = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
@@ -193,13 +198,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     __syncthreads();
     int buf = 0;
     for (; strip < nstrips; strip += gridDim.x) {
-        const int b = strip / strips_per_img, h0 = (strip % strips_per_img) * TH;
+        const int cb = strip % ncb;
+        const int b = (strip / ncb) / strips_per_img, h0 = ((strip / ncb) % strips_per_img) * TH;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float bv = 0.f;
-                if (MODE == MODE_FWD) bv = p.bias[mt * 32 + mfma_row(r, lane)];
+                if (MODE == MODE_FWD) bv = p.bias[cb * COUT + mt * 32 + mfma_row(r, lane)];
                 acc[mt][0][r] = bv;
                 acc[mt][1][r] = bv;
             }
@@ -260,8 +266,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
                     if (v01 > m) { m = v01; am = 1; }
                     if (v10 > m) { m = v10; am = 2; }
                     if (v11 > m) { m = v11; am = 3; }
-                    int co = mt * 32 + mfma_row(r + (odd ? 1 : 0), lane);
-                    long o = (((long)b * COUT + co) * Hp + ph) * Wp + ((c0 + j) >> 1);
+                    int co = cb * COUT + mt * 32 + mfma_row(r + (odd ? 1 : 0), lane);
+                    long o = (((long)b * CO_T + co) * Hp + ph) * Wp + ((c0 + j) >> 1);
                     p.y[o] = m > 0.f ? m : 0.f;
                     p.ymask[o] = m > 0.f ? (uint8_t)am : (uint8_t)4;
                 }
@@ -273,8 +279,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        int co = mt * 32 + mfma_row(r, lane);
-                        p.y[(((long)b * COUT + co) * H + h0 + r0 + n) * W + c0 + j] = acc[mt][n][r];
+                        int co = cb * COUT + mt * 32 + mfma_row(r, lane);
+                        p.y[(((long)b * CO_T + co) * H + h0 + r0 + n) * W + c0 + j] = acc[mt][n][r];
                     }
         }
     }
@@ -309,6 +315,8 @@ struct WgradParams {
     float* slab;           // [grid][COUT][9*32]  (CIN = 32)  or [grid][32][32] (CIN = 3)
     float* bslab;          // [grid][COUT] bias-gradient partials
     int B, H;
+    int cin_total, cout_total;   // the kernel handles one (32-input-channel, COUT-output-channel) block pair per work-group
+    int groups;                  // work-groups per pair: blockIdx.x = pair * groups + g
 };
 
 template <int COUT, int W>
@@ -337,6 +345,10 @@ __global__ __launch_bounds__(512) void conv_wgrad32_kernel(WgradParams p) {
     const int H = p.H, Hp = H / 2, Wp = W / 2;
     const int strips_per_img = H / 2;
     const int nstrips = p.B * strips_per_img;
+    const int pair = blockIdx.x / p.groups, grp = blockIdx.x % p.groups;
+    const int ncib = p.cin_total / 32;
+    const int cob = pair / ncib, cib = pair % ncib;          // output / input channel block of this work-group
+    const int CIN_T = p.cin_total, COUT_T = p.cout_total;
 
     for (int i = t; i < 2 * C::BUF; i += 512) smem[i] = 0.f;
     __syncthreads();
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(512) void conv_wgrad32_kernel(WgradParams p) {
         for (int i = 0; i < DY_NIT; ++i) {
             int idx = min(t + i * 512, DY_ITEMS - 1);
             int q = idx % (Wp / 4), co = idx / (Wp / 4);
-            long off = (((long)b * COUT + co) * Hp + ph) * Wp + q * 4;
+            long off = (((long)b * COUT_T + cob * COUT + co) * Hp + ph) * Wp + q * 4;
             gq[i] = *reinterpret_cast<const float4*>(p.gy + off);
             mq[i] = *reinterpret_cast<const uint32_t*>(p.mask + off);
         }
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(512) void conv_wgrad32_kernel(WgradParams p) {
             int q = idx % (W / 4), row = (idx / (W / 4)) % 4, ci = idx / (W / 4 * 4);
             int hh = h0 - 1 + row;
             const bool ok = hh >= 0 && hh < H;
-            float4 v = *reinterpret_cast<const float4*>(p.x + (((long)b * CIN + ci) * H + min(max(hh, 0), H - 1)) * W + q * 4);
+            float4 v = *reinterpret_cast<const float4*>(p.x + (((long)b * CIN_T + cib * 32 + ci) * H + min(max(hh, 0), H - 1)) * W + q * 4);
             xq[i].x = ok ? v.x : 0.f; xq[i].y = ok ? v.y : 0.f; xq[i].z = ok ? v.z : 0.f; xq[i].w = ok ? v.w : 0.f;
         }
     };
@@ -415,12 +427,12 @@ __global__ __launch_bounds__(512) void conv_wgrad32_kernel(WgradParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    int strip = blockIdx.x;
+    int strip = grp;
     if (strip < nstrips) { load_stage(strip); store_stage(0); }
     __syncthreads();
     int buf = 0;
-    for (; strip < nstrips; strip += gridDim.x) {
-        const int nstrip = strip + gridDim.x;
+    for (; strip < nstrips; strip += p.groups) {
+        const int nstrip = strip + p.groups;
         if (nstrip < nstrips) load_stage(nstrip);
         const float* dys = smem + buf * C::BUF + abase;
         const float* xs = smem + buf * C::BUF + C::DYF + bbase;
@@ -476,30 +488,34 @@ __global__ __launch_bounds__(512) void conv_wgrad32_kernel(WgradParams p) {
     }
 }
 
-// dW[co][ci][tap] = sum_g slab[g][co][tap*32+ci], db[co] = sum_g bslab[g][co]   (fixed order)
+// dW[cob*64+co][cib*32+ci][tap] = sum_g slab[pair][g][co][tap*32+ci]; db[cob*64+co] = sum_g bslab[pair(cib=0)][g][co]
+// grid: (ceil((64*288 + 64) / 64), pairs).  Fixed summation order.
 __global__ __launch_bounds__(256) void conv_wgrad32_reduce_kernel(const float* slab, const float* bslab, float* dw,
-                                                                 float* db, int nslab, int cout) {
+                                                                 float* db, int groups, int cin_total, int cout_total) {
     __shared__ float part[256];
-    const int total = cout * 288;
+    constexpr int CO = 64, total = CO * 288;
+    const int pair = blockIdx.y, ncib = cin_total / 32, cob = pair / ncib, cib = pair % ncib;
     const int nl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + nl;          // [0, total) weights, [total, total + cout) biases
+    const int n = blockIdx.x * 64 + nl;          // [0, total) weights, [total, total + CO) biases
     float s = 0.f;
-    int per = (nslab + 3) / 4;
-    int g0 = grp * per, g1 = min(nslab, g0 + per);
+    int per = (groups + 3) / 4;
+    int g0 = grp * per, g1 = min(groups, g0 + per);
+    const float* sl = slab + (long)pair * groups * total;
+    const float* bs = bslab + (long)pair * groups * CO;
     if (n < total) {
-        for (int g = g0; g < g1; ++g) s += slab[(long)g * total + n];
-    } else if (n < total + cout) {
-        for (int g = g0; g < g1; ++g) s += bslab[(long)g * cout + (n - total)];
+        for (int g = g0; g < g1; ++g) s += sl[(long)g * total + n];
+    } else if (n < total + CO) {
+        for (int g = g0; g < g1; ++g) s += bs[(long)g * CO + (n - total)];
     }
     part[threadIdx.x] = s;
     __syncthreads();
-    if (grp == 0 && n < total + cout) {
+    if (grp == 0 && n < total + CO) {
         float v = part[nl] + part[64 + nl] + part[128 + nl] + part[192 + nl];
         if (n < total) {
             int co = n / 288, rem = n % 288, tap = rem / 32, ci = rem % 32;
-            dw[((long)co * 32 + ci) * 9 + tap] = v;
-        } else {
-            db[n - total] = v;
+            dw[((long)(cob * CO + co) * cin_total + cib * 32 + ci) * 9 + tap] = v;
+        } else if (cib == 0) {
+            db[cob * CO + (n - total)] = v;
         }
     }
 }
@@ -529,6 +545,8 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradParams p) {
     const int H = p.H, Hp = H / 2, Wp = W / 2;
     const int strips_per_img = H / 2;
     const int nstrips = p.B * strips_per_img;
+    const int cob = blockIdx.x / p.groups, grp = blockIdx.x % p.groups;   // 32-output-channel block, group within it
+    const int COUT_T = p.cout_total;
     for (int i = t; i < 2 * C::BUF; i += 512) smem[i] = 0.f;
     __syncthreads();
 
@@ -548,7 +566,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradParams p) {
         for (int i = 0; i < DY_NIT; ++i) {
             int idx = min(t + i * 512, DY_ITEMS - 1);
             int q = idx % (Wp / 4), co = idx / (Wp / 4);
-            long off = (((long)b * COUT + co) * Hp + ph) * Wp + q * 4;
+            long off = (((long)b * COUT_T + cob * COUT + co) * Hp + ph) * Wp + q * 4;
             gq[i] = *reinterpret_cast<const float4*>(p.gy + off);
             mq[i] = *reinterpret_cast<const uint32_t*>(p.mask + off);
         }
@@ -607,12 +625,12 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    int strip = blockIdx.x;
+    int strip = grp;
     if (strip < nstrips) { load_stage(strip); store_stage(0); }
     __syncthreads();
     int buf = 0;
-    for (; strip < nstrips; strip += gridDim.x) {
-        const int nstrip = strip + gridDim.x;
+    for (; strip < nstrips; strip += p.groups) {
+        const int nstrip = strip + p.groups;
         if (nstrip < nstrips) load_stage(nstrip);
         const float* dys = smem + buf * C::BUF + abase;
         const float* xs = smem + buf * C::BUF + C::DYF + bbase;
@@ -651,25 +669,28 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradParams p) {
     }
 }
 
-// dW[co][ci][kh][kw] (= [co][27]) = sum_g slab[g][co][j], j = ci*9 + tap; db[co] = sum_g bslab[g][co].
-// A block owns 32 outputs; its 8 thread groups each sum a fixed eighth of the slabs, then a fixed-order LDS add.
+// dW[cob*32+co][27] = sum_g slab[cob][g][co][j], j = ci*9 + tap; db[cob*32+co] = sum_g bslab[cob][g][co].
+// grid (33, cout/32): a block owns 32 outputs; its 8 thread groups each sum a fixed eighth of the slabs.
 __global__ __launch_bounds__(256) void conv_wgrad3_reduce_kernel(const float* slab, const float* bslab, float* dw,
-                                                                float* db, int nslab) {
+                                                                float* db, int groups) {
     __shared__ float part[8][32];
+    const int cob = blockIdx.y;
+    const float* sl = slab + (long)cob * groups * 1024;
+    const float* bs = bslab + (long)cob * groups * 32;
     const int nl = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int n = blockIdx.x * 32 + nl;          // 0..1023 weights (32 blocks), 1024..1055 biases (block 32)
-    const int per = (nslab + 7) / 8, g0 = grp * per, g1 = min(nslab, g0 + per);
+    const int per = (groups + 7) / 8, g0 = grp * per, g1 = min(groups, g0 + per);
     float s = 0.f;
-    if (n < 1024) for (int g = g0; g < g1; ++g) s += slab[(long)g * 1024 + n];
-    else for (int g = g0; g < g1; ++g) s += bslab[(long)g * 32 + (n - 1024)];
+    if (n < 1024) for (int g = g0; g < g1; ++g) s += sl[(long)g * 1024 + n];
+    else for (int g = g0; g < g1; ++g) s += bs[(long)g * 32 + (n - 1024)];
     part[grp][nl] = s;
     __syncthreads();
     if (grp == 0) {
         float v = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) v += part[i][nl];
-        if (n < 1024) { if ((n & 31) < 27) dw[(n >> 5) * 27 + (n & 31)] = v; }
-        else db[n - 1024] = v;
+        if (n < 1024) { if ((n & 31) < 27) dw[(cob * 32 + (n >> 5)) * 27 + (n & 31)] = v; }
+        else db[cob * 32 + (n - 1024)] = v;
     }
 }
 
@@ -711,9 +732,12 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
     return BBBP_OK;
 }
 
-struct Shape { int cin, cout, w; };
+// shapes on the reference's paths: the flagship CNN (3->32 @128, 32->64 @64; ...20250113.py:84-90) and the wide/deep
+// variant (3->64 @128, 64->128 @64, 128->256 @32; ..._opt_20250107_network.py:129-138)
 inline bool supported(int cin, int cout, int h, int w) {
-    return h == w && ((cin == 3 && cout == 32 && w == 128) || (cin == 32 && cout == 64 && w == 64));
+    if (h != w) return false;
+    return (cin == 3 && cout == 32 && w == 128) || (cin == 32 && cout == 64 && w == 64) || (cin == 3 && cout == 64 && w == 128) ||
+           (cin == 64 && cout == 128 && w == 64) || (cin == 128 && cout == 256 && w == 32);
 }
 
 }  // namespace
@@ -723,7 +747,8 @@ extern "C" size_t bbbp_conv3x3_workspace_bytes(int B, int cin, int cout, int H, 
     (void)B; (void)H; (void)W;
     size_t prep = (size_t)9 * (cin < 8 ? 4 : cin) * cout * sizeof(float);
     size_t prep_d = (size_t)9 * cout * cin * sizeof(float);
-    size_t slab = (size_t)2 * 256 * ((cin == 3 ? 1024 : (size_t)cout * 288) + cout) * sizeof(float);
+    // wgrad: (pairs * groups) slabs with pairs * groups <= 2 * 256 work-groups
+    size_t slab = (size_t)2 * 256 * ((cin == 3 ? 1024 + 32 : (size_t)64 * 288 + 64)) * sizeof(float);
     size_t m = prep > prep_d ? prep : prep_d;
     return align_up(m > slab ? m : slab, 256);
 }
@@ -742,16 +767,19 @@ extern "C" int bbbp_conv3x3_relu_pool_fwd(void* stream, const float* x, const fl
     int total = 9 * cinp * cout;
     hipLaunchKernelGGL(conv_prep_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, wt, cin, cout, cinp, MODE_FWD);
     BBBP_CHECK_LAUNCH();
-    ConvParams p{x, nullptr, wt, bias, y, mask, B, H};
-    if (cin == 3) return launch_conv<3, 32, 128, MODE_FWD>(p, st);
-    return launch_conv<32, 64, 64, MODE_FWD>(p, st);
+    ConvParams p{x, nullptr, wt, bias, y, mask, B, H, cout};
+    if (cin == 3 && cout == 32) return launch_conv<3, 32, 128, MODE_FWD>(p, st);
+    if (cin == 3 && cout == 64) return launch_conv<3, 64, 128, MODE_FWD>(p, st);
+    if (cin == 32) return launch_conv<32, 64, 64, MODE_FWD>(p, st);
+    if (cin == 64) return launch_conv<64, 64, 64, MODE_FWD>(p, st);
+    return launch_conv<128, 64, 32, MODE_FWD>(p, st);
 }
 
 // dx[B][cin][H][W] from the pooled output gradient gy[B][cout][H/2][W/2] and the forward mask
 extern "C" int bbbp_conv3x3_relu_pool_bwd_data(void* stream, const float* gy, const uint8_t* mask, const float* w,
                                                float* dx, int B, int cin, int cout, int H, int W,
                                                void* workspace, size_t workspace_bytes) {
-    BBBP_CHECK_ARG(cin == 32 && cout == 64 && H == 64 && W == 64,
+    BBBP_CHECK_ARG(supported(cin, cout, H, W) && cin != 3,
                    "conv bwd_data: unsupported shape cin=%d cout=%d H=%d W=%d", cin, cout, H, W);
     BBBP_CHECK_ARG(gy && mask && w && dx && workspace, "conv bwd_data: null pointer");
     if (B == 0) return BBBP_OK;
@@ -763,8 +791,20 @@ extern "C" int bbbp_conv3x3_relu_pool_bwd_data(void* stream, const float* gy, co
     hipLaunchKernelGGL(conv_prep_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, wt, cin, cout, 0, MODE_DGRAD);
     BBBP_CHECK_LAUNCH();
     // the data-gradient conv reads cout channels and writes cin channels
-    ConvParams p{gy, mask, wt, nullptr, dx, nullptr, B, H};
-    return launch_conv<64, 32, 64, MODE_DGRAD>(p, st);
+    ConvParams p{gy, mask, wt, nullptr, dx, nullptr, B, H, cin};
+    if (cin == 32) return launch_conv<64, 32, 64, MODE_DGRAD>(p, st);
+    if (cin == 64) return launch_conv<128, 64, 64, MODE_DGRAD>(p, st);
+    return launch_conv<256, 64, 32, MODE_DGRAD>(p, st);
+}
+
+template <int W>
+static int launch_wgrad32(WgradParams p, int grid, hipStream_t st) {
+    using C = WgCfg<64, W>;
+    int rc = set_lds(conv_wgrad32_kernel<64, W>, C::LDS_BYTES);
+    if (rc) return rc;
+    hipLaunchKernelGGL((conv_wgrad32_kernel<64, W>), dim3(grid), dim3(512), C::LDS_BYTES, st, p);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
 }
 
 // dw[cout][cin][3][3], db[cout] from the layer input x, the pooled output gradient and the mask
@@ -782,33 +822,39 @@ extern "C" int bbbp_conv3x3_relu_pool_bwd_weight(void* stream, const float* x, c
     int nstrips = B * (H / 2);
     const bool part = g_bbbp_reserved_cus > 0;
     const int cus = bbbp_num_cus() - (part ? g_bbbp_reserved_cus : 0) > 0 ? bbbp_num_cus() - (part ? g_bbbp_reserved_cus : 0) : 1;
-    int grid = cus;
-    if (grid > nstrips) grid = nstrips;
     float* slab = static_cast<float*>(workspace);
-    WgradParams p{x, gy, mask, slab, nullptr, B, H};
+    WgradParams p{x, gy, mask, slab, nullptr, B, H, cin, cout, 1};
     if (cin == 3) {
         using C = Wg3Cfg<128>;
+        const int ncob = cout / 32;
         size_t lds3 = C::LDS_BYTES;
         if (part) lds3 = BBBP_CONV_MIN_LDS;          // one per CU on the unreserved CUs
-        grid = part ? cus : bbbp_num_cus() * 2;
-        if (grid > nstrips) grid = nstrips;
+        int groups = (part ? cus : bbbp_num_cus() * 2) / ncob;
+        if (groups > nstrips) groups = nstrips;
+        if (groups < 1) groups = 1;
+        const int grid = groups * ncob;
         BBBP_CHECK_ARG(workspace_bytes >= (size_t)grid * (1024 + 32) * sizeof(float), "conv bwd_weight: workspace too small");
+        p.groups = groups;
         p.bslab = slab + (size_t)grid * 1024;
         int rc = set_lds(conv_wgrad3_kernel<128>, lds3);
         if (rc) return rc;
         hipLaunchKernelGGL((conv_wgrad3_kernel<128>), dim3(grid), dim3(512), lds3, st, p);
         BBBP_CHECK_LAUNCH();
-        hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3(33), dim3(256), 0, st, slab, p.bslab, dw, db, grid);
+        hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3(33, ncob), dim3(256), 0, st, slab, p.bslab, dw, db, groups);
         BBBP_CHECK_LAUNCH();
     } else {
-        using C = WgCfg<64, 64>;
-        BBBP_CHECK_ARG(workspace_bytes >= (size_t)grid * cout * 289 * sizeof(float), "conv bwd_weight: workspace too small");
-        p.bslab = slab + (size_t)grid * cout * 288;
-        int rc = set_lds(conv_wgrad32_kernel<64, 64>, C::LDS_BYTES);
+        const int pairs = (cin / 32) * (cout / 64);
+        int groups = cus / pairs;
+        if (groups > nstrips) groups = nstrips;
+        if (groups < 1) groups = 1;
+        const int grid = groups * pairs;
+        BBBP_CHECK_ARG(workspace_bytes >= (size_t)grid * (64 * 288 + 64) * sizeof(float), "conv bwd_weight: workspace too small");
+        p.groups = groups;
+        p.bslab = slab + (size_t)grid * 64 * 288;
+        int rc = (W == 64) ? launch_wgrad32<64>(p, grid, st) : launch_wgrad32<32>(p, grid, st);
         if (rc) return rc;
-        hipLaunchKernelGGL((conv_wgrad32_kernel<64, 64>), dim3(grid), dim3(512), C::LDS_BYTES, st, p);
-        BBBP_CHECK_LAUNCH();
-        hipLaunchKernelGGL(conv_wgrad32_reduce_kernel, dim3(cdiv(cout * 289, 64)), dim3(256), 0, st, slab, p.bslab, dw, db, grid, cout);
+        hipLaunchKernelGGL(conv_wgrad32_reduce_kernel, dim3(cdiv(64 * 289, 64), pairs), dim3(256), 0, st, slab, p.bslab, dw, db,
+                           groups, cin, cout);
         BBBP_CHECK_LAUNCH();
     }
     return BBBP_OK;

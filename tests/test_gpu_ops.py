@@ -86,7 +86,7 @@ def _conv_case(dev, B, cin, cout, hw, seed, uniform_patches=False):
     dw, db = ops.conv3x3_relu_pool_bwd_weight(x.to(dev), gy.to(dev), mask)
     assert_close(dw.cpu().numpy(), wr.grad.numpy(), rtol=1e-4, atol_frac=2e-5, what="conv dw")
     assert_close(db.cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol_frac=2e-5, what="conv db")
-    if cin == 32:
+    if cin != 3:
         dx = ops.conv3x3_relu_pool_bwd_data(gy.to(dev), mask, w.to(dev))
         assert_close(dx.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol_frac=2e-5, what="conv dx")
 
@@ -99,6 +99,13 @@ def test_conv1_3to32(dev, B):
 @pytest.mark.parametrize("B", [1, 2, 5])
 def test_conv2_32to64(dev, B):
     _conv_case(dev, B, 32, 64, 64, seed=20 + B)
+
+
+@pytest.mark.parametrize("cin,cout,hw,B", [(3, 64, 128, 2), (64, 128, 64, 2), (128, 256, 32, 3), (128, 256, 32, 20)])
+def test_conv_wide_deep_shapes(dev, cin, cout, hw, B):
+    """The three conv stages of the wide/deep variant (Models/..._opt_20250107_network.py:129-138): output-channel
+    blocks in forward / data-gradient, (input block, output block) pairs in the weight gradient."""
+    _conv_case(dev, B, cin, cout, hw, seed=100 + cin + B)
 
 
 def test_conv_pool_ties_follow_first_max(dev):
