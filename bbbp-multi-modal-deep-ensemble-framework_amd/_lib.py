@@ -11,7 +11,7 @@ import re
 from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_long, c_size_t, c_uint8, c_uint64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbbbp_hip.so")
+LIB_PATH = os.environ.get("BBBP_LIB", os.path.join(_HERE, "libbbbp_hip.so"))    # BBBP_LIB: A/B another build
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bbbp_hip.h")
 
 _lib = None

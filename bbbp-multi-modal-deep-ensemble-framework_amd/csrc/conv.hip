@@ -336,7 +336,10 @@ struct WgCfg {
     static_assert(NPIX % KG == 0 && PIX_PER_KG % 2 == 0 && W % PIX_PER_KG == 0, "k-group split");
 };
 
-template <int COUT, int W>
+// Channel totals are template constants: with run-time strides the kernel needs 228 VGPRs instead of 224, and 224 x 2 waves
+// per SIMD is what leaves 64 registers per lane free for the side-stream kernels' waves (measured: at 232 the
+// fingerprint chain beside this kernel ran 7 % longer).
+template <int COUT, int W, int CIN_TOTAL, int COUT_TOTAL>
 __global__ __launch_bounds__(512) void conv_wgrad32_kernel(WgradParams p) {
     using C = WgCfg<COUT, W>;
     constexpr int CIN = 32, MT = C::MT, KG = C::KG, LDP = C::LDP, LDW = C::LDW, PLANE = C::PLANE;
@@ -346,9 +349,13 @@ __global__ __launch_bounds__(512) void conv_wgrad32_kernel(WgradParams p) {
     const int strips_per_img = H / 2;
     const int nstrips = p.B * strips_per_img;
     const int pair = blockIdx.x / p.groups, grp = blockIdx.x % p.groups;
-    const int ncib = p.cin_total / 32;
+    constexpr int ncib = CIN_TOTAL / 32;
     const int cob = pair / ncib, cib = pair % ncib;          // output / input channel block of this work-group
-    const int CIN_T = p.cin_total, COUT_T = p.cout_total;
+    constexpr int CIN_T = CIN_TOTAL, COUT_T = COUT_TOTAL;
+    // block offsets folded into the (wave-uniform) base pointers: per-thread address math stays as in the single-pair case
+    const float* xbase = p.x + (long)cib * 32 * H * W;
+    const float* gybase = p.gy + (long)cob * COUT * Hp * Wp;
+    const uint8_t* mbase = p.mask + (long)cob * COUT * Hp * Wp;
 
     for (int i = t; i < 2 * C::BUF; i += 512) smem[i] = 0.f;
     __syncthreads();
@@ -370,9 +377,9 @@ __global__ __launch_bounds__(512) void conv_wgrad32_kernel(WgradParams p) {
         for (int i = 0; i < DY_NIT; ++i) {
             int idx = min(t + i * 512, DY_ITEMS - 1);
             int q = idx % (Wp / 4), co = idx / (Wp / 4);
-            long off = (((long)b * COUT_T + cob * COUT + co) * Hp + ph) * Wp + q * 4;
-            gq[i] = *reinterpret_cast<const float4*>(p.gy + off);
-            mq[i] = *reinterpret_cast<const uint32_t*>(p.mask + off);
+            long off = (((long)b * COUT_T + co) * Hp + ph) * Wp + q * 4;
+            gq[i] = *reinterpret_cast<const float4*>(gybase + off);
+            mq[i] = *reinterpret_cast<const uint32_t*>(mbase + off);
         }
 #pragma unroll
         for (int i = 0; i < X_NIT; ++i) {
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(512) void conv_wgrad32_kernel(WgradParams p) {
             int q = idx % (W / 4), row = (idx / (W / 4)) % 4, ci = idx / (W / 4 * 4);
             int hh = h0 - 1 + row;
             const bool ok = hh >= 0 && hh < H;
-            float4 v = *reinterpret_cast<const float4*>(p.x + (((long)b * CIN_T + cib * 32 + ci) * H + min(max(hh, 0), H - 1)) * W + q * 4);
+            float4 v = *reinterpret_cast<const float4*>(xbase + (((long)b * CIN_T + ci) * H + min(max(hh, 0), H - 1)) * W + q * 4);
             xq[i].x = ok ? v.x : 0.f; xq[i].y = ok ? v.y : 0.f; xq[i].z = ok ? v.z : 0.f; xq[i].w = ok ? v.w : 0.f;
         }
     };
@@ -797,12 +804,12 @@ extern "C" int bbbp_conv3x3_relu_pool_bwd_data(void* stream, const float* gy, co
     return launch_conv<256, 64, 32, MODE_DGRAD>(p, st);
 }
 
-template <int W>
+template <int W, int CIN_TOTAL, int COUT_TOTAL>
 static int launch_wgrad32(WgradParams p, int grid, hipStream_t st) {
     using C = WgCfg<64, W>;
-    int rc = set_lds(conv_wgrad32_kernel<64, W>, C::LDS_BYTES);
+    int rc = set_lds(conv_wgrad32_kernel<64, W, CIN_TOTAL, COUT_TOTAL>, C::LDS_BYTES);
     if (rc) return rc;
-    hipLaunchKernelGGL((conv_wgrad32_kernel<64, W>), dim3(grid), dim3(512), C::LDS_BYTES, st, p);
+    hipLaunchKernelGGL((conv_wgrad32_kernel<64, W, CIN_TOTAL, COUT_TOTAL>), dim3(grid), dim3(512), C::LDS_BYTES, st, p);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }
@@ -851,7 +858,8 @@ extern "C" int bbbp_conv3x3_relu_pool_bwd_weight(void* stream, const float* x, c
         BBBP_CHECK_ARG(workspace_bytes >= (size_t)grid * (64 * 288 + 64) * sizeof(float), "conv bwd_weight: workspace too small");
         p.groups = groups;
         p.bslab = slab + (size_t)grid * 64 * 288;
-        int rc = (W == 64) ? launch_wgrad32<64>(p, grid, st) : launch_wgrad32<32>(p, grid, st);
+        int rc = cin == 32 ? launch_wgrad32<64, 32, 64>(p, grid, st)
+               : cin == 64 ? launch_wgrad32<64, 64, 128>(p, grid, st) : launch_wgrad32<32, 128, 256>(p, grid, st);
         if (rc) return rc;
         hipLaunchKernelGGL(conv_wgrad32_reduce_kernel, dim3(cdiv(64 * 289, 64), pairs), dim3(256), 0, st, slab, p.bslab, dw, db,
                            groups, cin, cout);

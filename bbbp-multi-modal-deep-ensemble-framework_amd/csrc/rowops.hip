@@ -83,8 +83,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dy, con
 
 // column sums over rows of (a) dy * xhat and (b) dy:  LayerNorm dgamma / dbeta.
 // Column reductions use 16-column x 64-row-lane blocks: enough blocks to spread a 167-wide tensor over the chip.
-constexpr int CW = 16, RL = 64;
-__global__ __launch_bounds__(1024) void layernorm_param_grad_kernel(const float* dy, const float* z, const float* mean,
+// 512 threads = 2 waves per SIMD x <= 32 VGPRs: small enough to co-reside with a 224-VGPR x 2 conv weight-gradient
+// work-group (64 registers per lane are free per SIMD); 1024-thread blocks could not be placed while it runs.
+constexpr int CW = 16, RL = 32;
+__global__ __launch_bounds__(512) void layernorm_param_grad_kernel(const float* dy, const float* z, const float* mean,
                                                                    const float* rstd, float* dgamma, float* dbeta,
                                                                    int rows, int cols) {
     BBBP_HIGH_PRIO();
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(1024) void batchnorm_bwd_kernel(const float* dy, co
 // dy <- dy * act'(y) in place (y = the activation's OUTPUT), db[n] = column sums of the result.
 // act: 0 none, 1 relu (y > 0), 2 tanh (1 - y^2).  Leading dims allow column slices.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void bias_act_bwd_kernel(float* dy, int lddy, const float* y, int ldy, float* db,
+__global__ __launch_bounds__(512) void bias_act_bwd_kernel(float* dy, int lddy, const float* y, int ldy, float* db,
                                                            int rows, int cols, int act, float scale) {
     BBBP_HIGH_PRIO();
     __shared__ float red[RL][CW];
@@ -418,7 +420,7 @@ extern "C" int bbbp_layernorm_bwd(void* stream, const float* dy, const float* z,
         BBBP_CHECK_LAUNCH();
     }
     if (dgamma) {
-        hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3(cdiv(cols, CW)), dim3(1024), g_bbbp_small_lds_pad, ST, dy, z, mean, rstd, dgamma,
+        hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3(cdiv(cols, CW)), dim3(CW * RL), g_bbbp_small_lds_pad, ST, dy, z, mean, rstd, dgamma,
                            dbeta, rows, cols);
         BBBP_CHECK_LAUNCH();
     }
@@ -484,7 +486,7 @@ extern "C" int bbbp_bias_act_bwd(void* stream, float* dy_inout, int lddy, const 
                                  int cols, int act, float scale) {
     BBBP_CHECK_ARG(cols > 0 && rows >= 0 && act >= 0 && act <= 2, "bias_act_bwd: bad args");
     BBBP_CHECK_ARG(act == 0 || y, "bias_act_bwd: activation output required");
-    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(cdiv(cols, CW)), dim3(1024), g_bbbp_small_lds_pad, ST, dy_inout, lddy, y, ldy, dbias, rows, cols,
+    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(cdiv(cols, CW)), dim3(CW * RL), g_bbbp_small_lds_pad, ST, dy_inout, lddy, y, ldy, dbias, rows, cols,
                        act, scale);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
