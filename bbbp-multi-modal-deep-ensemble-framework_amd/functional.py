@@ -183,3 +183,158 @@ def run_sequential(seq, x):
             raise RuntimeError(f"unsupported module on the HIP path: {type(m).__name__}")
         i += 1
     return x
+
+
+class _MatMul(torch.autograd.Function):
+    """op(a) @ op(b) on the MFMA GEMM with its two gradient GEMMs (2-D operands, unit inner stride)."""
+
+    @staticmethod
+    def forward(ctx, a, b, trans_a, trans_b):
+        ctx.ta, ctx.tb = trans_a, trans_b
+        ctx.save_for_backward(a, b)
+        return ops.gemm(a, b, trans_a=trans_a, trans_b=trans_b)
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        dc = dc.contiguous()
+        ta, tb = ctx.ta, ctx.tb
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            if not ta:   # C = A op(B): dA = dC op(B)^T
+                da = ops.gemm(dc, b, trans_b=not tb)
+            else:        # C = A^T op(B): dA = op(B) dC^T
+                da = ops.gemm(b, dc, trans_a=tb, trans_b=True)
+        if ctx.needs_input_grad[1]:
+            if not tb:   # C = op(A) B: dB = op(A)^T dC
+                db = ops.gemm(a, dc, trans_a=not ta)
+            else:        # C = op(A) B^T: dB = dC^T op(A)
+                db = ops.gemm(dc, a, trans_a=True, trans_b=ta)
+        return da, db, None, None
+
+
+def matmul(a, b, trans_a=False, trans_b=False):
+    return _MatMul.apply(a.contiguous(), b.contiguous(), trans_a, trans_b)
+
+
+class _Softmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        p, _ = ops.softmax_fwd(x)
+        ctx.save_for_backward(p)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        (p,) = ctx.saved_tensors
+        return ops.softmax_bwd(dp, p)
+
+
+def softmax_lastdim(x):
+    return _Softmax.apply(x.contiguous())
+
+
+class _ConvReluPool(torch.autograd.Function):
+    """Conv2d(k3,s1,p1) + ReLU + MaxPool2d(2,2) as one fused HIP op with its data / weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y, mask = ops.conv3x3_relu_pool_fwd(x, weight, bias)
+        ctx.save_for_backward(x, weight, mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, mask = ctx.saved_tensors
+        gy = gy.contiguous()
+        dw, db = ops.conv3x3_relu_pool_bwd_weight(x, gy, mask)
+        dx = ops.conv3x3_relu_pool_bwd_data(gy, mask, weight) if ctx.needs_input_grad[0] else None
+        return dx, dw, db
+
+
+def conv3x3_relu_pool(x, conv: "torch.nn.Conv2d"):
+    return _ConvReluPool.apply(x.contiguous(), conv.weight, conv.bias)
+
+
+class _EncoderLayer(torch.autograd.Function):
+    """One post-norm nn.TransformerEncoderLayer applied to x[S, E] (sequence = the mini-batch, batch 1), op by op on the HIP
+    kernels -- the same schedule as csrc/engine.hip, orchestrated from Python for the model variants that do not have a
+    fused engine.  params: in_w, in_b, out_w, out_b, w1, b1, w2, b2, n1w, n1b, n2w, n2b."""
+
+    @staticmethod
+    def forward(ctx, x, nhead, p_drop, seed, *P):
+        in_w, in_b, out_w, out_b, w1, b1, w2, b2, n1w, n1b, n2w, n2b = P
+        S, E = x.shape
+        d = E // nhead
+        scale = 1.0 / (d ** 0.5)
+        qkv = ops.linear(x, in_w, in_b)
+        probs, pds = [], []
+        ctxv = torch.empty((S, E), device=x.device, dtype=torch.float32)
+        for h in range(nhead):
+            q, k, v = qkv[:, h * d:(h + 1) * d], qkv[:, E + h * d:E + (h + 1) * d], qkv[:, 2 * E + h * d:2 * E + (h + 1) * d]
+            s = ops.gemm(q, k, trans_b=True, alpha=scale)
+            pr, pd = ops.softmax_fwd(s, p_drop, seed + 16 * h)
+            ops.gemm(pd, v, out=ctxv[:, h * d:(h + 1) * d])
+            probs.append(pr); pds.append(pd if p_drop > 0 else None)
+        sa = ops.linear(ctxv, out_w, out_b)
+        y1, z1, mean1, rstd1 = ops.layernorm_fwd(sa, x, n1w, n1b, 1e-5, p_drop, seed + 1)
+        hff = ops.linear(y1, w1, b1, act="relu")
+        if p_drop > 0:
+            hff = ops.dropout(hff, p_drop, seed + 2)
+        ff = ops.linear(hff, w2, b2)
+        y2, z2, mean2, rstd2 = ops.layernorm_fwd(ff, y1, n2w, n2b, 1e-5, p_drop, seed + 3)
+        ctx.cfg = (nhead, p_drop, seed)
+        ctx.pds = pds
+        ctx.save_for_backward(x, qkv, ctxv, z1, mean1, rstd1, y1, hff, z2, mean2, rstd2, *probs, *P)
+        return y2
+
+    @staticmethod
+    def backward(ctx, dy):
+        nhead, p_drop, seed = ctx.cfg
+        saved = ctx.saved_tensors
+        x, qkv, ctxv, z1, mean1, rstd1, y1, hff, z2, mean2, rstd2 = saved[:11]
+        probs = saved[11:11 + nhead]
+        in_w, in_b, out_w, out_b, w1, b1, w2, b2, n1w, n1b, n2w, n2b = saved[11 + nhead:]
+        S, E = x.shape
+        d = E // nhead
+        scale = 1.0 / (d ** 0.5)
+        inv_keep = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
+        dy = dy.contiguous()
+        dz2, dff, dn2w, dn2b = ops.layernorm_bwd(dy, z2, n2w, mean2, rstd2, p_drop, seed + 3)
+        dw2 = ops.gemm(dff, hff, trans_a=True)
+        db2 = ops.bias_act_bwd(dff, None)
+        dh = ops.gemm(dff, w2)
+        db1 = ops.bias_act_bwd(dh, hff, act="relu", scale=inv_keep)
+        dw1 = ops.gemm(dh, y1, trans_a=True)
+        dy1 = ops.gemm(dh, w1, residual=dz2)
+        dz1, dsa, dn1w, dn1b = ops.layernorm_bwd(dy1, z1, n1w, mean1, rstd1, p_drop, seed + 1)
+        dwo = ops.gemm(dsa, ctxv, trans_a=True)
+        dbo = ops.bias_act_bwd(dsa, None)
+        dctx = ops.gemm(dsa, out_w)
+        dqkv = torch.empty_like(qkv)
+        for h in range(nhead):
+            q, k, v = qkv[:, h * d:(h + 1) * d], qkv[:, E + h * d:E + (h + 1) * d], qkv[:, 2 * E + h * d:2 * E + (h + 1) * d]
+            dch = dctx[:, h * d:(h + 1) * d]
+            pd = ctx.pds[h] if ctx.pds[h] is not None else probs[h]
+            ops.gemm(pd, dch, trans_a=True, out=dqkv[:, 2 * E + h * d:2 * E + (h + 1) * d])
+            dpd = ops.gemm(dch, v, trans_b=True)
+            ds = ops.softmax_bwd(dpd, probs[h], p_drop, seed + 16 * h)
+            ops.gemm(ds, k, alpha=scale, out=dqkv[:, h * d:(h + 1) * d])
+            ops.gemm(ds, q, trans_a=True, alpha=scale, out=dqkv[:, E + h * d:E + (h + 1) * d])
+        dwin = ops.gemm(dqkv, x, trans_a=True)
+        dbin = ops.bias_act_bwd(dqkv, None)
+        dx = ops.gemm(dqkv, in_w, residual=dz1) if ctx.needs_input_grad[0] else None
+        return (dx, None, None, None, dwin, dbin, dwo, dbo, dw1, db1, dw2, db2, dn1w, dn1b, dn2w, dn2b)
+
+
+def transformer_encoder(x, encoder: "torch.nn.TransformerEncoder", nhead: int, training: bool):
+    """nn.TransformerEncoder over x[S, E] (sequence axis = the mini-batch, as the reference calls it with [B,1,F])."""
+    x = x.contiguous()
+    for layer in encoder.layers:
+        p = float(layer.dropout.p) if training else 0.0
+        seed = int(torch.randint(0, 2 ** 60, (1,)).item()) if p > 0 else 0
+        a = layer.self_attn
+        x = _EncoderLayer.apply(x, nhead, p, seed, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
+                                layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias,
+                                layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias)
+    return x

@@ -65,3 +65,80 @@ class DenseMLPModel(nn.Module):
         a = run_sequential(self.fingerprint_fc, fingerprint.float().contiguous())
         b = run_sequential(self.image_fc, image.float().contiguous())
         return run_sequential(self.fc, torch.cat((a, b), dim=1))
+
+
+class MultiModalAttentionFusion(nn.Module):
+    """Fusion block of the wide/deep variant (Models/multi_input_data_regression_opt_transformer_cnn_opt_20250107_network.py:
+    51-105).  Faithful to the reference's arithmetic including its accidental broadcast: ``attention_weights[:, 0:1]`` is
+    [B,1,1] and multiplies ``fingerprint`` [B,512] into [B,B,512]; the following ``mean(dim=1)`` then averages over the
+    BATCH, i.e. row i of the 'weighted' features is a_i * column-mean(features).  Here that is two GEMMs."""
+
+    def __init__(self, fingerprint_dim, image_dim, hidden_dim=128):
+        super().__init__()
+        self.fingerprint_attention = nn.Sequential(nn.Linear(fingerprint_dim, hidden_dim), nn.Tanh(), nn.Linear(hidden_dim, 1))
+        self.image_attention = nn.Sequential(nn.Linear(image_dim, hidden_dim), nn.Tanh(), nn.Linear(hidden_dim, 1))
+        self.cross_modal_attention = nn.Sequential(nn.Linear(fingerprint_dim + image_dim, hidden_dim), nn.Tanh(),
+                                                   nn.Linear(hidden_dim, fingerprint_dim))
+        self.softmax = nn.Softmax(dim=1)
+
+    def forward(self, fingerprint, image):
+        from .functional import matmul, softmax_lastdim
+        B = fingerprint.shape[0]
+        fw = run_sequential(self.fingerprint_attention, fingerprint)          # [B,1]
+        iw = run_sequential(self.image_attention, image)                      # [B,1]
+        cross = run_sequential(self.cross_modal_attention, torch.cat((fingerprint, image), dim=1))
+        aw = softmax_lastdim(torch.cat((fw, iw), dim=1))                      # softmax over the two modality logits
+        ones = torch.full((1, B), 1.0 / B, device=fingerprint.device, dtype=torch.float32)
+        fp_mean = matmul(ones, fingerprint)                                   # [1,512] batch mean of the features
+        img_mean = matmul(ones, image)
+        fpw = matmul(aw[:, 0:1].contiguous(), fp_mean)                        # [B,1] x [1,512]
+        imgw = matmul(aw[:, 1:2].contiguous(), img_mean)
+        return torch.cat((fpw, imgw, cross), dim=1)
+
+
+class WideDeepMixedInputModel(nn.Module):
+    """The wide/deep ``MixedInputModel`` (same file, :109-174): 12-layer encoder (nhead search from 8 down), 3-stage CNN
+    64/128/256, Linear(65536,512), Dropout 0.3, MultiModalAttentionFusion(512,512), 6-layer BatchNorm head from 1536."""
+
+    def __init__(self, fingerprint_size, image_feature_size):
+        super().__init__()
+        nhead = 8
+        while fingerprint_size % nhead != 0 and nhead > 1:
+            nhead -= 1
+        if fingerprint_size % nhead != 0:
+            raise ValueError(f"fingerprint_size={fingerprint_size} must be divisible by nhead={nhead}.")
+        self.nhead = nhead
+        self.fingerprint_transformer = nn.TransformerEncoder(
+            nn.TransformerEncoderLayer(d_model=fingerprint_size, nhead=nhead), num_layers=12, enable_nested_tensor=False)
+        self.fingerprint_fc = nn.Sequential(nn.Linear(fingerprint_size, 512), nn.ReLU(), nn.Dropout(0.3))
+        S = image_feature_size
+        self.image_cnn = nn.Sequential(
+            nn.Conv2d(3, 64, kernel_size=3, stride=1, padding=1), nn.ReLU(), nn.MaxPool2d(kernel_size=2, stride=2),
+            nn.Conv2d(64, 128, kernel_size=3, stride=1, padding=1), nn.ReLU(), nn.MaxPool2d(kernel_size=2, stride=2),
+            nn.Conv2d(128, 256, kernel_size=3, stride=1, padding=1), nn.ReLU(), nn.MaxPool2d(kernel_size=2, stride=2),
+            nn.Flatten(), nn.Linear(256 * (S // 8) * (S // 8), 512), nn.ReLU(), nn.Dropout(0.3))
+        self.attention_fusion = MultiModalAttentionFusion(512, 512)
+        self.fc = nn.Sequential(nn.Linear(512 + 512 + 512, 1024), nn.ReLU(), nn.BatchNorm1d(1024), nn.Linear(1024, 512), nn.ReLU(),
+                                nn.Dropout(0.3), nn.Linear(512, 256), nn.ReLU(), nn.Linear(256, 128), nn.ReLU(),
+                                nn.Linear(128, 64), nn.ReLU(), nn.Linear(64, 1))
+        if S != 128:
+            raise ValueError("image_feature_size must be 128: forward reshapes images to 3x128x128")
+        flatten_parameters(self)
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        flatten_parameters(self)
+        return out
+
+    def forward(self, fingerprint, image):
+        from .functional import conv3x3_relu_pool, transformer_encoder
+        _need_cuda(fingerprint)
+        x = transformer_encoder(fingerprint.float(), self.fingerprint_transformer, self.nhead, self.training)
+        fp_out = run_sequential(self.fingerprint_fc, x)
+        img = image.float().contiguous().view(-1, 3, 128, 128)
+        cnn = self.image_cnn
+        h = conv3x3_relu_pool(img, cnn[0])
+        h = conv3x3_relu_pool(h, cnn[3])
+        h = conv3x3_relu_pool(h, cnn[6])
+        img_out = run_sequential(nn.Sequential(*list(cnn)[10:]), h.flatten(1))
+        return run_sequential(self.fc, self.attention_fusion(fp_out, img_out))

@@ -202,6 +202,44 @@ def dense_mlp_forward(p: Params, fingerprint: torch.Tensor, image: torch.Tensor,
 
 
 # --------------------------------------------------------------------------------------------
+# wide/deep variant: Models/multi_input_data_regression_opt_transformer_cnn_opt_20250107_network.py:51-174 (dropout = identity)
+# --------------------------------------------------------------------------------------------
+def _seq_tanh_head(x, p, pre):
+    return F.linear(torch.tanh(F.linear(x, p[pre + "0.weight"], p[pre + "0.bias"])), p[pre + "2.weight"], p[pre + "2.bias"])
+
+
+def multimodal_attention_fusion(fp: torch.Tensor, img: torch.Tensor, p: Params, prefix: str) -> torch.Tensor:
+    """:71-105 statement by statement, INCLUDING the [B,1,1] * [B,512] -> [B,B,512] broadcast and the mean over dim 1."""
+    fw = _seq_tanh_head(fp, p, prefix + "fingerprint_attention.").unsqueeze(1)        # [B,1,1]
+    iw = _seq_tanh_head(img, p, prefix + "image_attention.").unsqueeze(1)
+    cross = _seq_tanh_head(torch.cat((fp, img), dim=1), p, prefix + "cross_modal_attention.")
+    aw = torch.softmax(torch.cat([fw, iw], dim=1), dim=1)                              # [B,2,1]
+    fpw = (aw[:, 0:1] * fp).mean(dim=1)                                                # [B,B,512] -> [B,512]
+    imgw = (aw[:, 1:2] * img).mean(dim=1)
+    return torch.cat((fpw, imgw, cross), dim=1)
+
+
+def wide_deep_forward(p: Params, fingerprint: torch.Tensor, image: torch.Tensor, *, training: bool = False,
+                      bn_state: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    Fdim = fingerprint.shape[1]
+    nhead = nhead_rule(Fdim, start=8)
+    x = encoder(fingerprint, p, "fingerprint_transformer.", nhead, 12)
+    fp_out = F.relu(F.linear(x, p["fingerprint_fc.0.weight"], p["fingerprint_fc.0.bias"]))
+    h = image.reshape(-1, 3, 128, 128)
+    for i in (0, 3, 6):
+        h = conv3x3_relu_pool(h, p[f"image_cnn.{i}.weight"], p[f"image_cnn.{i}.bias"])
+    img_out = F.relu(F.linear(h.flatten(1), p["image_cnn.10.weight"], p["image_cnn.10.bias"]))
+    fused = multimodal_attention_fusion(fp_out, img_out, p, "attention_fusion.")
+    h = F.relu(F.linear(fused, p["fc.0.weight"], p["fc.0.bias"]))
+    h = batchnorm1d(h, p, "fc.2.", training, bn_state)
+    h = F.relu(F.linear(h, p["fc.3.weight"], p["fc.3.bias"]))
+    h = F.relu(F.linear(h, p["fc.6.weight"], p["fc.6.bias"]))
+    h = F.relu(F.linear(h, p["fc.8.weight"], p["fc.8.bias"]))
+    h = F.relu(F.linear(h, p["fc.10.weight"], p["fc.10.bias"]))
+    return F.linear(h, p["fc.12.weight"], p["fc.12.bias"])
+
+
+# --------------------------------------------------------------------------------------------
 # a13: AdamW (torch.optim.AdamW defaults used at ...20250113.py:172: lr 1e-4, wd 1e-5)
 # --------------------------------------------------------------------------------------------
 def adamw_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor,

@@ -212,3 +212,26 @@ def test_nhead_rule():
     assert [oracle.nhead_rule(f) for f in (167, 64, 128, 2048)] == [1, 8, 16, 256]
     assert [bbbp_amd.reference_nhead(f) for f in (167, 64, 128, 2048)] == [1, 8, 16, 256]
     assert oracle.nhead_rule(167, start=8) == 1 and oracle.nhead_rule(2048, start=8) == 8
+
+
+def test_wide_deep_variant_golden():
+    """Oracle restatement of the wide/deep MixedInputModel (incl. the batch-mean broadcast of its fusion block) against
+    the reference class; the product's module tree reproduces the reference's seeded initial weights."""
+    from bbbp_amd.variants import WideDeepMixedInputModel
+    g = golden("wide_deep_f167")
+    torch.manual_seed(20250107)
+    m = WideDeepMixedInputModel(167, 128)
+    check_param_checksums(g, m.state_dict())
+    assert m.nhead == 1 and len(m.fingerprint_transformer.layers) == 12
+    p = named(m)
+    fp, img, _ = synth_inputs(1003, 3, 167, 49152)
+    with torch.no_grad():
+        assert_close(oracle.wide_deep_forward(p, fp, img, training=False).numpy(), g["eval/B3/out"], rtol=1e-5, what="wide eval")
+    fp, img, y = synth_inputs(1005, 5, 167, 49152)
+    st = {}
+    out = oracle.wide_deep_forward(p, fp, img, training=True, bn_state=st)
+    oracle.mse_loss(out, y).backward()
+    assert_close(out.detach().numpy(), g["train/B5/out"], rtol=1e-5, what="wide train")
+    for k in ("fc.0.weight", "image_cnn.6.weight", "image_cnn.10.weight", "fingerprint_transformer.layers.11.linear1.weight",
+              "attention_fusion.cross_modal_attention.2.weight", "fc.12.weight"):
+        check_summary(g, f"train/B5/{k}", p[k].grad, rtol=2e-4, atol_frac=1e-4)

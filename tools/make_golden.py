@@ -49,7 +49,7 @@ def zero_dropout(model: nn.Module):
 def tensor_summary(t: torch.Tensor):
     d = t.detach().double().flatten()
     n = d.numel()
-    idx = torch.linspace(0, n - 1, steps=min(n, 64)).long()
+    idx = torch.linspace(0, n - 1, steps=min(n, 64)).long().clamp_(max=n - 1)     # float32 linspace can round up to n
     return dict(sum=float(d.sum()), abssum=float(d.abs().sum()), l2=float(d.norm()),
                 head=d[:64].numpy().copy(), idx=idx.numpy().copy(), samp=d[idx].numpy().copy())
 
@@ -222,6 +222,9 @@ def main():
     # dense raw-feature MLP, image width shrunk to 3*16*16 for size
     case_model("dense_mlp", M + "multi_input_data_regression_opt.py",
                167, 768, 768, Bs=(4,), init_seed=5, train_Bs=(6,))
+    # wide/deep variant: 12-layer encoder, 3-conv CNN, MultiModalAttentionFusion (batch-mean broadcast), 6-layer head
+    case_model("wide_deep_f167", M + "multi_input_data_regression_opt_transformer_cnn_opt_20250107_network.py",
+               167, 128, 49152, Bs=(3,), init_seed=20250107, train_Bs=(5,))
     case_ops()
 
 
