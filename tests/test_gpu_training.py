@@ -1,0 +1,76 @@
+"""GPU: end-to-end training equivalence.  The reference's per-fold loop (Models/...20250113.py:165-241, incl. the
+train-once / eval-thereafter quirk) run on the HIP path against the same loop run with the CPU oracle + the oracle's AdamW
+on identical data and batch order: losses, predictions, R^2 and MSE agree far inside the north-star's +-0.002."""
+import numpy as np
+import pytest
+import torch
+
+import bbbp_amd
+from bbbp_amd import training
+from oracle import reference_cpu as oracle
+from helpers import synth_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_train(state, fp, img, y, orders, batch_size, faithful, test):
+    p = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in state.items()}
+    keys = [k for k, v in p.items() if v.requires_grad]
+    m = {k: torch.zeros_like(p[k]) for k in keys}; v2 = {k: torch.zeros_like(p[k]) for k in keys}
+    step, training_mode, losses = 0, True, []
+    for ep, order in enumerate(orders):
+        if not faithful:
+            training_mode = True
+        tot, nb = 0.0, 0
+        for i in range(0, len(order), batch_size):
+            idx = torch.as_tensor(order[i:i + batch_size])
+            for k in keys:
+                p[k].grad = None
+            st = {}
+            loss = oracle.mse_loss(oracle.mixed_input_forward(p, fp[idx], img[idx], training=training_mode, bn_state=st), y[idx])
+            loss.backward()
+            step += 1
+            with torch.no_grad():
+                for k in keys:
+                    oracle.adamw_step(p[k], p[k].grad, m[k], v2[k], step)
+                for k, val in st.items():
+                    p[k] = val
+            tot += float(loss.detach()); nb += 1
+        losses.append(tot / nb)
+        training_mode = False                        # the validation pass leaves the model in eval mode
+    with torch.no_grad():
+        preds = torch.cat([oracle.mixed_input_forward(p, test[0][i:i + batch_size], test[1][i:i + batch_size], training=False).reshape(-1)
+                           for i in range(0, test[0].shape[0], batch_size)])
+    return losses, preds
+
+
+def test_faithful_training_loop_matches_oracle(dev):
+    F, N, NT, BS, EPOCHS = 64, 96, 32, 32, 3
+    fp, img, y = synth_inputs(31, N + NT, F, 49152)
+    torch.manual_seed(5)
+    model = bbbp_amd.MixedInputModel(F, 128)
+    for mod in model.modules():                      # dropout off: epoch 1 runs in train mode and must be comparable
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    state0 = {k: v.clone() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(0)
+    orders = [rng.permutation(N) for _ in range(EPOCHS)]
+    model = model.to(dev)
+    d = lambda t: t.to(dev)
+    hist = training.train_fold(model, (d(fp[:N]), d(img[:N]), d(y[:N])), (d(fp[N:]), d(img[N:]), d(y[N:])), epochs=EPOCHS,
+                               batch_size=BS, faithful_mode=True, batch_orders=orders)
+    assert not model.training                        # the quirk: left in eval mode
+    preds = training.predict(model, d(fp[N:]), d(img[N:]), BS).cpu().numpy()
+    ref_losses, ref_preds = oracle_train(state0, fp[:N], img[:N], y[:N], orders, BS, True, (fp[N:], img[N:]))
+    ref_preds = ref_preds.numpy()
+    for a, b in zip(hist["train_loss"], ref_losses):
+        assert abs(a - b) <= 2e-3 * abs(b) + 1e-6, (hist["train_loss"], ref_losses)
+    yt = y[N:].numpy()
+    r2_a, r2_b = training.r2_score(yt, preds), training.r2_score(yt, ref_preds)
+    mse_a, mse_b = training.mean_squared_error(yt, preds), training.mean_squared_error(yt, ref_preds)
+    assert abs(r2_a - r2_b) <= 0.002 and abs(mse_a - mse_b) <= 0.002, (r2_a, r2_b, mse_a, mse_b)
+    assert np.max(np.abs(preds - ref_preds)) <= 5e-3 * max(1.0, np.max(np.abs(ref_preds)))
+    assert len(hist["val_loss"]) == EPOCHS and all(np.isfinite(hist["val_loss"]))
+    assert int(model.state_dict()["fc.2.num_batches_tracked"]) == 3     # BatchNorm saw train mode in epoch 1 only
