@@ -253,6 +253,41 @@ __global__ __launch_bounds__(1024) void batchnorm_bwd_kernel(const float* dy, co
     }
 }
 
+// Pieces of a BatchNorm1d whose batch is sharded over ranks (exact-global-batch mode, distributed.py): local column
+// moments about a given centre, and the input gradient from GLOBAL sums.  The collectives in between run on the host side.
+__global__ __launch_bounds__(512) void column_moments_kernel(const float* x, const float* centre, float* s1, float* s2,
+                                                            int rows, int cols) {
+    BBBP_HIGH_PRIO();
+    __shared__ float a1[32][16], a2[32][16];
+    const int cl = threadIdx.x % 16, rl = threadIdx.x / 16;
+    const int c = blockIdx.x * 16 + cl;
+    const float m = (centre && c < cols) ? centre[c] : 0.f;
+    float a = 0.f, b = 0.f;
+    if (c < cols)
+        for (int r = rl; r < rows; r += 32) { float d = x[(long)r * cols + c] - m; a += d; b += d * d; }
+    a1[rl][cl] = a; a2[rl][cl] = b;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        float ta = 0.f, tb = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) { ta += a1[i][cl]; tb += a2[i][cl]; }
+        s1[c] = ta; s2[c] = tb;
+    }
+}
+
+// dx = gamma * rstd * (dy - sum_dy / n - xhat * sum_dy_xhat / n) with sums over the GLOBAL batch of n rows
+__global__ __launch_bounds__(256) void batchnorm_bwd_apply_kernel(const float* dy, const float* x, const float* gamma,
+                                                                 const float* mean, const float* rstd, const float* sum_dy,
+                                                                 const float* sum_dy_xhat, float* dx, long total, int cols,
+                                                                 float inv_n) {
+    BBBP_HIGH_PRIO();
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int c = (int)(i % cols);
+        float xh = (x[i] - mean[c]) * rstd[c];
+        dx[i] = gamma[c] * rstd[c] * (dy[i] - sum_dy[c] * inv_n - xh * sum_dy_xhat[c] * inv_n);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // dy <- dy * act'(y) in place (y = the activation's OUTPUT), db[n] = column sums of the result.
 // act: 0 none, 1 relu (y > 0), 2 tanh (1 - y^2).  Leading dims allow column slices.
@@ -478,6 +513,27 @@ extern "C" int bbbp_batchnorm1d_bwd(void* stream, const float* dy, const float* 
     BBBP_CHECK_ARG(cols > 0 && rows >= 0, "batchnorm bwd: bad shape");
     hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3(cdiv(cols, 64)), dim3(1024), g_bbbp_small_lds_pad, ST, dy, x, gamma, save_mean, save_rstd, dx,
                        dgamma, dbeta, rows, cols, training);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+extern "C" int bbbp_column_moments(void* stream, const float* x, const float* centre, float* sum_out, float* sumsq_out, int rows,
+                                   int cols) {
+    BBBP_CHECK_ARG(rows >= 0 && cols > 0 && x && sum_out && sumsq_out, "column_moments: bad arguments");
+    hipLaunchKernelGGL(column_moments_kernel, dim3(cdiv(cols, 16)), dim3(512), g_bbbp_small_lds_pad, ST, x, centre, sum_out, sumsq_out,
+                       rows, cols);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+extern "C" int bbbp_batchnorm1d_bwd_apply(void* stream, const float* dy, const float* x, const float* gamma, const float* mean,
+                                          const float* rstd, const float* sum_dy, const float* sum_dy_xhat, float* dx, int rows,
+                                          int cols, long n_global) {
+    BBBP_CHECK_ARG(rows >= 0 && cols > 0 && n_global >= 1, "batchnorm bwd_apply: bad arguments");
+    if (rows == 0) return BBBP_OK;
+    long total = (long)rows * cols;
+    hipLaunchKernelGGL(batchnorm_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), g_bbbp_small_lds_pad, ST, dy, x, gamma, mean, rstd,
+                       sum_dy, sum_dy_xhat, dx, total, cols, 1.0f / (float)n_global);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }

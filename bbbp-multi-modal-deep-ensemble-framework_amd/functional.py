@@ -262,16 +262,23 @@ class _EncoderLayer(torch.autograd.Function):
     fused engine.  params: in_w, in_b, out_w, out_b, w1, b1, w2, b2, n1w, n1b, n2w, n2b."""
 
     @staticmethod
-    def forward(ctx, x, nhead, p_drop, seed, *P):
+    def forward(ctx, x, nhead, p_drop, seed, group, *P):
         in_w, in_b, out_w, out_b, w1, b1, w2, b2, n1w, n1b, n2w, n2b = P
         S, E = x.shape
         d = E // nhead
         scale = 1.0 / (d ** 0.5)
         qkv = ops.linear(x, in_w, in_b)
+        # exact-global-batch mode: the sequence IS the batch, sharded over ranks; keys and values of all ranks are gathered
+        # (one collective per layer, K|V in one buffer), queries stay local
+        kv = _gather_rows(qkv[:, E:].contiguous(), group) if group is not None else None
         probs, pds = [], []
         ctxv = torch.empty((S, E), device=x.device, dtype=torch.float32)
         for h in range(nhead):
-            q, k, v = qkv[:, h * d:(h + 1) * d], qkv[:, E + h * d:E + (h + 1) * d], qkv[:, 2 * E + h * d:2 * E + (h + 1) * d]
+            q = qkv[:, h * d:(h + 1) * d]
+            if kv is None:
+                k, v = qkv[:, E + h * d:E + (h + 1) * d], qkv[:, 2 * E + h * d:2 * E + (h + 1) * d]
+            else:
+                k, v = kv[:, h * d:(h + 1) * d], kv[:, E + h * d:E + (h + 1) * d]
             s = ops.gemm(q, k, trans_b=True, alpha=scale)
             pr, pd = ops.softmax_fwd(s, p_drop, seed + 16 * h)
             ops.gemm(pd, v, out=ctxv[:, h * d:(h + 1) * d])
@@ -283,14 +290,16 @@ class _EncoderLayer(torch.autograd.Function):
             hff = ops.dropout(hff, p_drop, seed + 2)
         ff = ops.linear(hff, w2, b2)
         y2, z2, mean2, rstd2 = ops.layernorm_fwd(ff, y1, n2w, n2b, 1e-5, p_drop, seed + 3)
-        ctx.cfg = (nhead, p_drop, seed)
+        ctx.cfg = (nhead, p_drop, seed, group)
         ctx.pds = pds
+        ctx.kv = kv
         ctx.save_for_backward(x, qkv, ctxv, z1, mean1, rstd1, y1, hff, z2, mean2, rstd2, *probs, *P)
         return y2
 
     @staticmethod
     def backward(ctx, dy):
-        nhead, p_drop, seed = ctx.cfg
+        nhead, p_drop, seed, group = ctx.cfg
+        kv = ctx.kv
         saved = ctx.saved_tensors
         x, qkv, ctxv, z1, mean1, rstd1, y1, hff, z2, mean2, rstd2 = saved[:11]
         probs = saved[11:11 + nhead]
@@ -312,29 +321,116 @@ class _EncoderLayer(torch.autograd.Function):
         dbo = ops.bias_act_bwd(dsa, None)
         dctx = ops.gemm(dsa, out_w)
         dqkv = torch.empty_like(qkv)
+        dkv = torch.empty_like(kv) if kv is not None else None      # [S_global, 2E]: this rank's queries' share of dK | dV
         for h in range(nhead):
-            q, k, v = qkv[:, h * d:(h + 1) * d], qkv[:, E + h * d:E + (h + 1) * d], qkv[:, 2 * E + h * d:2 * E + (h + 1) * d]
+            q = qkv[:, h * d:(h + 1) * d]
+            if kv is None:
+                k, v = qkv[:, E + h * d:E + (h + 1) * d], qkv[:, 2 * E + h * d:2 * E + (h + 1) * d]
+                dk_out, dv_out = dqkv[:, E + h * d:E + (h + 1) * d], dqkv[:, 2 * E + h * d:2 * E + (h + 1) * d]
+            else:
+                k, v = kv[:, h * d:(h + 1) * d], kv[:, E + h * d:E + (h + 1) * d]
+                dk_out, dv_out = dkv[:, h * d:(h + 1) * d], dkv[:, E + h * d:E + (h + 1) * d]
             dch = dctx[:, h * d:(h + 1) * d]
             pd = ctx.pds[h] if ctx.pds[h] is not None else probs[h]
-            ops.gemm(pd, dch, trans_a=True, out=dqkv[:, 2 * E + h * d:2 * E + (h + 1) * d])
+            ops.gemm(pd, dch, trans_a=True, out=dv_out)
             dpd = ops.gemm(dch, v, trans_b=True)
             ds = ops.softmax_bwd(dpd, probs[h], p_drop, seed + 16 * h)
             ops.gemm(ds, k, alpha=scale, out=dqkv[:, h * d:(h + 1) * d])
-            ops.gemm(ds, q, trans_a=True, alpha=scale, out=dqkv[:, E + h * d:E + (h + 1) * d])
+            ops.gemm(ds, q, trans_a=True, alpha=scale, out=dk_out)
+        if dkv is not None:
+            dqkv[:, E:] = _reduce_scatter_rows(dkv, group)          # sum over ranks, keep the local rows
         dwin = ops.gemm(dqkv, x, trans_a=True)
         dbin = ops.bias_act_bwd(dqkv, None)
         dx = ops.gemm(dqkv, in_w, residual=dz1) if ctx.needs_input_grad[0] else None
-        return (dx, None, None, None, dwin, dbin, dwo, dbo, dw1, db1, dw2, db2, dn1w, dn1b, dn2w, dn2b)
+        return (dx, None, None, None, None, dwin, dbin, dwo, dbo, dw1, db1, dw2, db2, dn1w, dn1b, dn2w, dn2b)
 
 
-def transformer_encoder(x, encoder: "torch.nn.TransformerEncoder", nhead: int, training: bool):
-    """nn.TransformerEncoder over x[S, E] (sequence axis = the mini-batch, as the reference calls it with [B,1,F])."""
+def _gather_rows(t, group):
+    """Concatenate the row shards of all ranks (rank order = global row order)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+    if dist.get_backend(group) == "gloo":          # rehearsal backend: list form
+        dist.all_gather(list(out.chunk(world, dim=0)), t.contiguous(), group=group)
+    else:
+        dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    return out
+
+
+def _reduce_scatter_rows(t, group):
+    """Sum a [world * n, ...] tensor over ranks and return this rank's n rows."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = t.shape[0] // world
+    if dist.get_backend(group) == "gloo":          # no reduce_scatter in gloo (CPU / rehearsal): all-reduce and slice
+        t = t.contiguous()
+        dist.all_reduce(t, group=group)
+        return t[rank * n:(rank + 1) * n]
+    out = torch.empty((n,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+    dist.reduce_scatter_tensor(out, t.contiguous(), group=group)
+    return out
+
+
+class _SyncBatchNorm1d(torch.autograd.Function):
+    """BatchNorm1d over a batch that is sharded across ranks: statistics and the two backward sums are all-reduced
+    ([2 x C] floats per collective), the element-wise work runs in the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, group):
+        import torch.distributed as dist
+        rows, cols = x.shape
+        world = dist.get_world_size(group)
+        n = rows * world
+        L = _lib.lib()
+        st = torch.empty((2, cols), device=x.device, dtype=torch.float32)
+        _lib.check(L.bbbp_column_moments(ops._stream(), x.data_ptr(), None, st[0].data_ptr(), st[1].data_ptr(), rows, cols), "column_moments")
+        dist.all_reduce(st[0], group=group)
+        mean = st[0] / n
+        _lib.check(L.bbbp_column_moments(ops._stream(), x.data_ptr(), mean.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), rows, cols), "column_moments")
+        dist.all_reduce(st[1], group=group)
+        var = st[1] / n                                            # biased, two-pass about the global mean
+        y, save_mean, save_rstd = ops.batchnorm1d_fwd(x, weight, bias, mean, var, False, eps, momentum)   # normalise with the given stats
+        with torch.no_grad():
+            running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+            running_var.mul_(1 - momentum).add_(var * (n / (n - 1)), alpha=momentum)
+        ctx.group, ctx.n = group, n
+        ctx.save_for_backward(x, weight, save_mean, save_rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        x, weight, save_mean, save_rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        rows, cols = x.shape
+        _, dg, db = ops.batchnorm1d_bwd(dy, x, weight, save_mean, save_rstd, True)      # local sums (its dx is not used)
+        sums = torch.stack((db, dg))
+        dist.all_reduce(sums, group=ctx.group)
+        dx = torch.empty_like(x)
+        _lib.check(_lib.lib().bbbp_batchnorm1d_bwd_apply(ops._stream(), dy.data_ptr(), x.data_ptr(), weight.data_ptr(),
+                                                         save_mean.data_ptr(), save_rstd.data_ptr(), sums[0].data_ptr(),
+                                                         sums[1].data_ptr(), dx.data_ptr(), rows, cols, ctx.n), "batchnorm1d_bwd_apply")
+        return dx, dg, db, None, None, None, None, None
+
+
+def sync_batchnorm1d(x, bn: "torch.nn.BatchNorm1d", group):
+    if not bn.training:
+        return batchnorm1d(x, bn)
+    y = _SyncBatchNorm1d.apply(x.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                               0.1 if bn.momentum is None else bn.momentum, group)
+    bn.num_batches_tracked += 1
+    return y
+
+
+def transformer_encoder(x, encoder: "torch.nn.TransformerEncoder", nhead: int, training: bool, group=None):
+    """nn.TransformerEncoder over x[S, E] (sequence axis = the mini-batch, as the reference calls it with [B,1,F]).
+    With ``group`` the rows of x are this rank's shard of the global batch (sequence-parallel attention)."""
     x = x.contiguous()
     for layer in encoder.layers:
         p = float(layer.dropout.p) if training else 0.0
         seed = int(torch.randint(0, 2 ** 60, (1,)).item()) if p > 0 else 0
         a = layer.self_attn
-        x = _EncoderLayer.apply(x, nhead, p, seed, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
+        x = _EncoderLayer.apply(x, nhead, p, seed, group, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
                                 layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias,
                                 layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias)
     return x

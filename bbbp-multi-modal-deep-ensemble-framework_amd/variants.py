@@ -142,3 +142,49 @@ class WideDeepMixedInputModel(nn.Module):
         h = conv3x3_relu_pool(h, cnn[6])
         img_out = run_sequential(nn.Sequential(*list(cnn)[10:]), h.flatten(1))
         return run_sequential(self.fc, self.attention_fusion(fp_out, img_out))
+
+
+class ExactBatchMixedInputModel(nn.Module):
+    """The flagship ``MixedInputModel`` (Models/multi_input_data_regression_opt_transformer_cnn_20250113.py:68-119, same
+    parameters and ``state_dict``) for EXACT-global-batch data parallelism (SURVEY.md 8e mode 2): every rank holds B/N
+    molecules, and the two places where the reference's function couples the molecules of a mini-batch are made global --
+    the encoder attends over the keys/values of ALL ranks (one all-gather of K|V per layer forward, one reduce-scatter of
+    dK|dV backward) and the head's BatchNorm1d uses global batch statistics.  With gradients averaged over ranks
+    (``distributed.allreduce_gradients``) an N-rank step equals the single-GPU step at batch B up to rounding.
+    Composed from per-op autograd nodes on the HIP ops (the fused engine covers the replica mode)."""
+
+    def __init__(self, fingerprint_size, image_feature_size, group=None):
+        super().__init__()
+        from .models import MixedInputModel
+        inner = MixedInputModel(fingerprint_size, image_feature_size)      # same module tree => same keys and seeded init
+        self.nhead = inner.nhead
+        self.fingerprint_transformer = inner.fingerprint_transformer
+        self.fingerprint_fc = inner.fingerprint_fc
+        self.image_cnn = inner.image_cnn
+        self.attention_fusion = inner.attention_fusion
+        self.fc = inner.fc
+        self.group = group
+        flatten_parameters(self)
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        flatten_parameters(self)
+        return out
+
+    def forward(self, fingerprint, image):
+        import torch.distributed as dist
+        from .functional import conv3x3_relu_pool, linear, sync_batchnorm1d, transformer_encoder
+        _need_cuda(fingerprint)
+        group = self.group if (dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1) else None
+        if group is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            group = dist.group.WORLD
+        x = transformer_encoder(fingerprint.float(), self.fingerprint_transformer, self.nhead, self.training, group=group)
+        fp_out = run_sequential(self.fingerprint_fc, x)
+        img = image.float().contiguous().view(-1, 3, 128, 128)
+        h = conv3x3_relu_pool(conv3x3_relu_pool(img, self.image_cnn[0]), self.image_cnn[3])
+        img_out = linear(h.flatten(1), self.image_cnn[7].weight, self.image_cnn[7].bias, "relu")
+        fused = self.attention_fusion(fp_out, img_out)
+        fc = self.fc
+        h = linear(fused, fc[0].weight, fc[0].bias, "relu")
+        h = sync_batchnorm1d(h, fc[2], group) if group is not None else run_sequential(nn.Sequential(fc[2]), h)
+        return run_sequential(nn.Sequential(*list(fc)[3:]), h)

@@ -91,6 +91,13 @@ int bbbp_batchnorm1d_bwd(void* stream, const float* dy, const float* x, const fl
                          const float* save_rstd, float* dx, float* dgamma, float* dbeta, int rows, int cols,
                          int training);
 
+/* Pieces for a BatchNorm1d whose batch is sharded over ranks (exact-global-batch data parallelism): local column sums of
+ * (x - centre) and (x - centre)^2, and dx from sums taken over the global batch of n_global rows. */
+int bbbp_column_moments(void* stream, const float* x, const float* centre, float* sum_out, float* sumsq_out, int rows, int cols);
+int bbbp_batchnorm1d_bwd_apply(void* stream, const float* dy, const float* x, const float* gamma, const float* mean,
+                               const float* rstd, const float* sum_dy, const float* sum_dy_xhat, float* dx, int rows,
+                               int cols, long n_global);
+
 /* ---- backward of "+ bias, activation": dy *= act'(y) * scale in place, dbias = column sums ------ */
 int bbbp_bias_act_bwd(void* stream, float* dy_inout, int lddy, const float* y, int ldy, float* dbias, int rows,
                       int cols, int act, float scale);
