@@ -15,6 +15,9 @@
 // (the MACCS width is the prime 167): 16-byte loads when alignment allows, predicated scalar loads
 // otherwise, zero fill out of range.  Split-K writes raw partial slabs that a second kernel sums
 // in a fixed order (bit-reproducible; no float atomics).
+// Launches below ~1.2 GFLOP (every GEMM of the F = 167 encoder) take a second, latency-oriented kernel further down
+// (gemm_direct_kernel): no LDS staging, 16x16 wave tiles on v_mfma_f32_16x16x4_f32, K slices reduced inside the
+// work-group.  bbbp_gemm_f32 picks the path; results of both agree to rounding (different summation order).
 #include "common.h"
 #include "bbbp_hip.h"
 
@@ -183,17 +186,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         if (it + 1 < nt) load_tiles(kbeg + (it + 1) * BK);
         const float* as = As + buf * BK * LDAS + aoff;
         const float* bs = Bs + buf * BK * LDBS + boff;
+        // Fetch the operands of 8 k-steps at once, then issue their MFMAs: with one wave per SIMD nothing else hides the
+        // LDS latency, and read -> wait -> MFMA per k-step cost ~250 cycles per step (measured by ablation,
+        // tools/exp_gemm_dbg.py: the K loop took 0.8 us per 16-deep stage even with loads, stores and MFMAs removed).
+        constexpr int G = 8;
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float a[TM], b[TN];
+        for (int k0 = 0; k0 < BK / 2; k0 += G) {
+            float a[G][TM], b[G][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = as[kk * LDAS + i * 32];
+            for (int g = 0; g < G; ++g) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bs[kk * LDBS + j * 32];
+                for (int i = 0; i < TM; ++i) a[g][i] = as[(k0 + g) * 2 * LDAS + i * 32];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < TN; ++j) b[g][j] = bs[(k0 + g) * 2 * LDBS + j * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep hipcc from sinking the reads back next to their MFMAs
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[g][i], b[g][j], acc[i][j]);
         }
         if (it + 1 < nt) store_tiles(buf ^ 1);
         __syncthreads();
@@ -250,6 +263,251 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
         float v = apply_act(p.alpha * s + (p.bias ? p.bias[n] : 0.f), p.act);
         if (R) v += R[(long)m * p.ldr + n];
         C[(long)m * p.ldc + n] = v;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Latency path for the SMALL GEMMs (the F = 167 encoder: M = 512, N, K in {167, 501, 512, 2048}).
+// Those launches are not bound by MFMA issue or HBM but by the serial chain inside one work-group of the tiled
+// kernel above: global load -> LDS store -> barrier -> LDS read -> 8 dependent MFMAs, 11 times for K = 167, ~1750
+// cycles per 16-deep stage with one wave per SIMD and 24 of 256 CUs busy (cycle stamps: tools/micro/).  Here every
+// wave fetches its operands STRAIGHT into the MFMA register layout -- no LDS staging, no barrier in the K loop --
+// and the output is cut into 16x16 (or 32x32) wave tiles so that hundreds of waves share the work:
+//   * v_mfma_f32_16x16x4_f32 (lane l holds A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; 32-cycle issue),
+//     one 16-deep K chunk = 4 MFMAs per accumulator;
+//   * a k-contiguous operand ([M][K] / [N][K]) is read with ONE 16-byte load per lane and chunk: lane (i, kq) takes
+//     k = 16c + 4kq .. +3 of its row and feeds element j of that quad to MFMA j.  MFMA j therefore sums
+//     k = 16c + 4kq + j over kq -- a permutation of K, applied to both operands alike, which a dot product does not
+//     see.  gfx950 global loads need only 4-byte alignment, so the prime leading dimension 167 costs nothing;
+//   * a k-major operand ([K][M] / [K][N]) is read as T consecutive columns of row k (T = sub-tiles per wave), which
+//     permutes the wave's output columns instead (column = base + T * (l & 15) + u);
+//   * a 4-deep register ring keeps 4 chunks of loads in flight per wave;
+//   * the LAST chunk (K tail, and the last k row of a k-major operand, where a vector may overrun the buffer) takes
+//     a per-element path with clamped addresses and zero fill.  Rows / columns past M / N are clamped to valid
+//     addresses and never stored: a column of D only depends on its own column of B, so garbage stays there;
+//   * deep K is split over the `ks` waves of the work-group (chunk c -> wave c % ks) and summed through LDS in a
+//     fixed order by wave 0 -- one launch, no slab traffic, bit-reproducible.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+
+struct DirectParams {
+    const float* A; const float* B; float* C;
+    const float* bias; const float* R;
+    int M, N, K;
+    int lda, ldb, ldc, ldr;
+    long sA, sB, sC, sR;
+    float alpha;
+    int act;
+    int wsm, wsn, ks;        // waves of a work-group: wsm x wsn output tiles, each computed by ks K-slices
+};
+
+template <int T>
+__device__ __forceinline__ void ldv(const float* p, float (&out)[T]) {
+    if constexpr (T == 1) out[0] = *p;
+    else if constexpr (T == 2) { f32x2u v = *reinterpret_cast<const f32x2u*>(p); out[0] = v[0]; out[1] = v[1]; }
+    else { f32x4u v = *reinterpret_cast<const f32x4u*>(p); out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3]; }
+}
+
+// One operand of a wave: T sub-tiles of 16 rows (k-contiguous storage) or 16 T-wide column groups (k-major storage).
+template <int T, bool KMAJ>
+struct DirectOperand {
+    const float* X;          // matrix base (batch applied)
+    const float* ptr[KMAJ ? 1 : T];
+    int ld, extent, base, q, kq;
+
+    __device__ __forceinline__ void init(const float* X_, int ld_, int extent_, int base_, int lane) {
+        X = X_; ld = ld_; extent = extent_; base = base_; q = lane & 15; kq = lane >> 4;
+        if constexpr (KMAJ) {
+            const int col = base + T * q;
+            ptr[0] = X + (col < extent ? col : 0) + (long)(4 * kq) * ld;
+        } else {
+#pragma unroll
+            for (int u = 0; u < T; ++u) ptr[u] = X + (long)min(base + 16 * u + q, extent - 1) * ld + 4 * kq;
+        }
+    }
+    // full chunk c (all 16 k inside K, and not the last k row): r[j][u]
+    __device__ __forceinline__ void fetch(int c, float (&r)[4][T]) const {
+        if constexpr (KMAJ) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ldv<T>(ptr[0] + (long)(16 * c + j) * ld, r[j]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < T; ++u) {
+                f32x4u v = *reinterpret_cast<const f32x4u*>(ptr[u] + 16 * c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[j][u] = v[j];
+            }
+        }
+    }
+    // last chunk: element-wise, clamped addresses, zero fill
+    __device__ __forceinline__ void fetch_tail(int c, int K, float (&r)[4][T]) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 16 * c + 4 * kq + j;
+#pragma unroll
+            for (int u = 0; u < T; ++u) {
+                if constexpr (KMAJ) {
+                    const int col = base + T * q + u;
+                    const bool ok = k < K && col < extent;
+                    const float v = X[ok ? (long)k * ld + col : 0];
+                    r[j][u] = ok ? v : 0.f;
+                } else {
+                    const bool ok = k < K;
+                    const float v = (ptr[u] - 4 * kq)[ok ? k : 0];
+                    r[j][u] = ok ? v : 0.f;
+                }
+            }
+        }
+    }
+    // matrix index of (sub-tile u, MFMA index i in 0..15)
+    __device__ __forceinline__ int index(int u, int i) const { return KMAJ ? base + T * i + u : base + 16 * u + i; }
+};
+
+template <int LAYOUT, int TM, int TN>
+__global__ __launch_bounds__(1024) void gemm_direct_kernel(DirectParams p) {
+    BBBP_HIGH_PRIO();
+    constexpr bool A_KMAJ = (LAYOUT == 2), B_KMAJ = (LAYOUT != 0);
+    constexpr int D = 4;                         // chunks in flight per wave
+    extern __shared__ float red[];               // [wave][TM * TN * 4][64] when ks > 1
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ks = wave % p.ks, sp = wave / p.ks;
+    const int wm = sp / p.wsn, wn = sp % p.wsn;
+    const int batch = blockIdx.z;
+    DirectOperand<TM, A_KMAJ> opa;
+    DirectOperand<TN, B_KMAJ> opb;
+    opa.init(p.A + (long)batch * p.sA, p.lda, p.M, (blockIdx.y * p.wsm + wm) * 16 * TM, lane);
+    opb.init(p.B + (long)batch * p.sB, p.ldb, p.N, (blockIdx.x * p.wsn + wn) * 16 * TN, lane);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mfma_chunk = [&](const float (&a)[4][TM], const float (&b)[4][TN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int um = 0; um < TM; ++um)
+#pragma unroll
+                for (int un = 0; un < TN; ++un)
+                    acc[um][un] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][um], b[j][un], acc[um][un], 0, 0, 0);
+    };
+
+    const int nch = (p.K + 15) / 16;
+    // this wave's chunks: c = ks + i * p.ks; all but the globally last one take the vector path
+    const int nfast = (nch - 1 > ks) ? (nch - 1 - ks + p.ks - 1) / p.ks : 0;
+    if (nfast > 0) {
+        float ra[D][4][TM], rb[D][4][TN];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int c = ks + min(d, nfast - 1) * p.ks;
+            opa.fetch(c, ra[d]); opb.fetch(c, rb[d]);
+        }
+        for (int i0 = 0; i0 < nfast; i0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (i0 + d < nfast) mfma_chunk(ra[d], rb[d]);
+                const int c = ks + min(i0 + d + D, nfast - 1) * p.ks;
+                opa.fetch(c, ra[d]); opb.fetch(c, rb[d]);
+            }
+        }
+    }
+    if (nch > 0 && (nch - 1) % p.ks == ks) {
+        float ta[4][TM], tb[4][TN];
+        opa.fetch_tail(nch - 1, p.K, ta); opb.fetch_tail(nch - 1, p.K, tb);
+        mfma_chunk(ta, tb);
+    }
+
+    if (p.ks > 1) {          // K slices -> LDS, summed in slice order by slice 0
+        float* mine = red + (long)wave * (TM * TN * 4 * 64) + lane;
+        if (ks != 0) {
+#pragma unroll
+            for (int um = 0; um < TM; ++um)
+#pragma unroll
+                for (int un = 0; un < TN; ++un)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mine[((um * TN + un) * 4 + r) * 64] = acc[um][un][r];
+        }
+        __syncthreads();
+        if (ks != 0) return;
+        for (int s = 1; s < p.ks; ++s) {
+            const float* other = mine + (long)s * (TM * TN * 4 * 64);
+#pragma unroll
+            for (int um = 0; um < TM; ++um)
+#pragma unroll
+                for (int un = 0; un < TN; ++un)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[um][un][r] += other[((um * TN + un) * 4 + r) * 64];
+        }
+    }
+
+    float* C = p.C + (long)batch * p.sC;
+    const float* R = p.R ? p.R + (long)batch * p.sR : nullptr;
+    const int q = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int un = 0; un < TN; ++un) {
+        const int n = opb.index(un, q);
+        const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int um = 0; um < TM; ++um)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = opa.index(um, 4 * kq + r);
+                if (m < p.M && n < p.N) {
+                    float v = apply_act(p.alpha * acc[um][un][r] + bv, p.act);
+                    if (R) v += R[(long)m * p.ldr + n];
+                    C[(long)m * p.ldc + n] = v;
+                }
+            }
+    }
+}
+
+struct DirectPlan { bool use; int t, wsm, wsn, ks; };
+
+// The direct path serves launches that cannot fill the chip with 64x64 tiles anyway; big GEMMs keep the LDS tiling.
+DirectPlan direct_plan(int M, int N, int K, int batch) {
+    static const int enabled = [] { const char* e = getenv("BBBP_GEMM_DIRECT"); return e ? atoi(e) : 1; }();
+    DirectPlan d{false, 1, 1, 1, 1};
+    const double flops = 2.0 * M * N * (double)K * batch;
+    if (!enabled || flops > 1.2e9 || K > 8192) return d;
+    d.use = true;
+    const int nch = cdiv(K, 16);
+    // work-groups stay at 4 waves (one per SIMD, <= 64 VGPRs for the 16x16 variant): a 16-wave group needs 256 free
+    // VGPRs on every SIMD of one CU and cannot start while the persistent conv work-groups of the other stream hold
+    // theirs (measured: the conv beside it slowed from 0.72 to 1.25 ms and the encoder gained nothing).  Whole training
+    // step, B = 512 (tools/exp_step.py): K slices capped at 1 / 2 / 4 -> 3.95 / 3.75 / 3.78 ms; LDS-tiled path 4.25 ms.
+    static const int max_ks = [] { const char* e = getenv("BBBP_GEMM_DIRECT_KS"); return e ? atoi(e) : 2; }();
+    d.ks = nch <= 12 ? 1 : (cdiv(nch, 8) < max_ks ? cdiv(nch, 8) : max_ks);
+    if (d.ks == 3) d.ks = 4;
+    const long wt = (long)cdiv(M, 16) * cdiv(N, 16) * batch;
+    d.t = (wt * d.ks <= 2048) ? 1 : 2;
+    if (d.ks >= 4) { d.wsm = 1; d.wsn = 1; }
+    else if (d.ks >= 2) { d.wsm = 2; d.wsn = 1; }
+    else { d.wsm = 2; d.wsn = 2; }
+    if ((enabled & 2) && d.ks > 1) d.use = false;      // A/B knobs: BBBP_GEMM_DIRECT=0 off, 3 no K slices, 5 no 32x32 wave tiles
+    if ((enabled & 4) && d.t > 1) d.use = false;
+    return d;
+}
+
+template <int LAYOUT, int T>
+void launch_direct_one(const DirectParams& p, int batch, hipStream_t st) {
+    const int waves = p.wsm * p.wsn * p.ks;
+    dim3 grid(cdiv(p.N, 16 * T * p.wsn), cdiv(p.M, 16 * T * p.wsm), batch);
+    size_t lds = p.ks > 1 ? (size_t)waves * T * T * 4 * 64 * sizeof(float) : 0;
+    if (lds < g_bbbp_small_lds_pad) lds = g_bbbp_small_lds_pad;
+    hipLaunchKernelGGL((gemm_direct_kernel<LAYOUT, T, T>), grid, dim3(64 * waves), lds, st, p);
+}
+
+void launch_direct(const DirectParams& p, int layout, int t, int batch, hipStream_t st) {
+    if (t == 1) {
+        if (layout == 0) launch_direct_one<0, 1>(p, batch, st);
+        else if (layout == 1) launch_direct_one<1, 1>(p, batch, st);
+        else launch_direct_one<2, 1>(p, batch, st);
+    } else {
+        if (layout == 0) launch_direct_one<0, 2>(p, batch, st);
+        else if (layout == 1) launch_direct_one<1, 2>(p, batch, st);
+        else launch_direct_one<2, 2>(p, batch, st);
     }
 }
 
@@ -313,6 +571,7 @@ static void gemm_plan(int M, int N, int K, int batch, int* tile, int* splits, in
 }
 
 extern "C" size_t bbbp_gemm_workspace_bytes(int M, int N, int K, int batch) {
+    if (M <= 0 || N <= 0 || direct_plan(M, N, K, batch).use) return 0;
     int tile, splits, kchunk;
     gemm_plan(M, N, K, batch, &tile, &splits, &kchunk);
     return splits > 1 ? (size_t)batch * splits * M * N * sizeof(float) : 0;
@@ -333,6 +592,18 @@ extern "C" int bbbp_gemm_f32(void* stream, int transA, int transB, int M, int N,
     BBBP_CHECK_ARG(lda >= (transA ? M : K), "gemm: lda %d too small", lda);
     BBBP_CHECK_ARG(ldb >= (transB ? K : N), "gemm: ldb %d too small", ldb);
     BBBP_CHECK_ARG(ldc >= N, "gemm: ldc %d too small", ldc);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const DirectPlan dp = direct_plan(M, N, K, batch);
+    if (dp.use && batch <= 65535 && cdiv(M, 16 * dp.t * dp.wsm) <= 65535) {
+        DirectParams d;
+        d.A = A; d.B = B; d.C = C; d.bias = bias; d.R = residual;
+        d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc; d.ldr = ldr;
+        d.sA = strideA; d.sB = strideB; d.sC = strideC; d.sR = strideR;
+        d.alpha = alpha; d.act = act; d.wsm = dp.wsm; d.wsn = dp.wsn; d.ks = dp.ks;
+        launch_direct(d, layout, dp.t, batch, st);
+        BBBP_CHECK_LAUNCH();
+        return BBBP_OK;
+    }
     GemmParams p;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.R = residual;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
@@ -355,7 +626,6 @@ extern "C" int bbbp_gemm_f32(void* stream, int transA, int transB, int M, int N,
         }
     }
     if (K == 0) { p.splits = 1; p.kchunk = bk_of(tile); }
-    hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid(cdiv(N, tile), cdiv(M, tile), batch * p.splits);
     BBBP_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
     if (tile == 128) launch_tile<128, 128>(p, layout, grid, st);

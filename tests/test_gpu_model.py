@@ -61,7 +61,7 @@ def test_train_step_matches_reference_golden(dev, name, F, seed, B):
     loss = torch.nn.MSELoss()(out.squeeze(), y.to(dev))
     loss.backward()
     assert_close(out.detach().cpu().numpy(), g[f"train/B{B}/out"], rtol=1e-4, atol_frac=2e-5, what="train out")
-    assert abs(float(loss) - float(g[f"train/B{B}/loss"])) <= 1e-4 * abs(float(g[f"train/B{B}/loss"]))
+    assert abs(float(loss.detach()) - float(g[f"train/B{B}/loss"])) <= 1e-4 * abs(float(g[f"train/B{B}/loss"]))
     sd = m.state_dict()
     for k in ("fc.2.running_mean", "fc.2.running_var"):
         assert_close(sd[k].cpu().numpy(), g[f"train/B{B}/bn/{k}"], rtol=1e-4, what=k)
