@@ -24,6 +24,15 @@ class MixedDesc(Structure):
                 ("need_input_grad", c_int)]
 
 
+class GemmDesc(Structure):
+    """bbbp_gemm_desc (include/bbbp_hip.h)."""
+    _fields_ = [("transA", c_int), ("transB", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("alpha", c_float),
+                ("A", c_void_p), ("lda", c_int), ("B", c_void_p), ("ldb", c_int), ("C", c_void_p), ("ldc", c_int),
+                ("bias", c_void_p), ("residual", c_void_p), ("ldr", c_int), ("act", c_int),
+                ("gate", c_void_p), ("ldg", c_int), ("gate_scale", c_float), ("batch", c_int),
+                ("strideA", c_long), ("strideB", c_long), ("strideC", c_long), ("strideR", c_long), ("strideG", c_long)]
+
+
 _FP = c_void_p          # device float*
 _PP = POINTER(c_void_p)  # host array of device pointers
 
@@ -33,6 +42,7 @@ _SIGNATURES = {
     "bbbp_gemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "bbbp_gemm_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, _FP, c_int, _FP, c_int, _FP, c_int,
                               _FP, _FP, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_void_p, c_size_t]),
+    "bbbp_gemm_f32_grouped": (c_int, [c_void_p, POINTER(GemmDesc), c_int, c_void_p, c_size_t]),
     "bbbp_conv3x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "bbbp_conv3x3_relu_pool_fwd": (c_int, [c_void_p, _FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                            c_void_p, c_size_t]),

@@ -51,7 +51,7 @@ struct Bump {
     size_t f(size_t n) { return take(n * sizeof(float)); }
 };
 
-struct LayerOff { size_t qkv, prob, ctx, z1, y1, hff, z2, y2, mean1, rstd1, mean2, rstd2; };
+struct LayerOff { size_t qkv, prob, pd, ctx, z1, y1, hff, z2, y2, mean1, rstd1, mean2, rstd2; };
 // per-layer gradient buffers: weight-gradient kernels read them on a third stream while the dependency
 // chain moves on to the next layer, so they must not be recycled within one backward pass
 struct LayerGrad { size_t dyout, dz2, dz2d, dhff, dy1, dz1, dz1d, dqkv; };
@@ -65,7 +65,7 @@ struct Plan {
     size_t pool1, mask1, pool2, mask2;
     size_t combined, hid, attn, fused, h, hb, bn_mean, bn_rstd, h2, h3;
     // temporaries
-    size_t pd, scratch, scratch_bytes, scratch2, scratch2_bytes;
+    size_t scratch, scratch_bytes, scratch2, scratch2_bytes;
     size_t dA, dB, dqkv, dprob, dctx, dhff, dpool2, dpool1, dcomb, dfused, dlogit, dpre, dh, dhb, dh2, dh3;
     size_t total;
 };
@@ -86,6 +86,9 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     for (int l = 0; l < p->L; ++l) {
         LayerOff& o = p->layer[l];
         o.qkv = b.f(B * 3 * F); o.prob = b.f(NH * B * B); o.ctx = b.f(B * F);
+        // dropped attention weights are KEPT per layer (1 MB at B = 512, one head) rather than recomputed in backward:
+        // every launch on the encoder's chain costs more than the bytes
+        o.pd = p->drop ? b.f(NH * B * B) : o.prob;
         o.z1 = b.f(B * F); o.y1 = b.f(B * F); o.hff = b.f(B * DFF); o.z2 = b.f(B * F); o.y2 = b.f(B * F);
         o.mean1 = b.f(B); o.rstd1 = b.f(B); o.mean2 = b.f(B); o.rstd2 = b.f(B);
     }
@@ -94,7 +97,6 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     p->combined = b.f(B * COMB); p->hid = b.f(NHEADS_FUSION * B * FUS_HID); p->attn = b.f(B * NHEADS_FUSION);
     p->fused = b.f(B * COMB); p->h = b.f(B * H1); p->hb = b.f(B * H1); p->bn_mean = b.f(H1); p->bn_rstd = b.f(H1);
     p->h2 = b.f(B * H2); p->h3 = b.f(B * H3);
-    p->pd = p->drop ? b.f(NH * B * B) : 0;
     size_t cw = bbbp_conv3x3_workspace_bytes(p->B, 32, 64, 64, 64);
     size_t cw1 = bbbp_conv3x3_workspace_bytes(p->B, 3, 32, 128, 128);
     size_t sb = cw > cw1 ? cw : cw1;
@@ -247,6 +249,16 @@ int linear_bwd_weight(const Ctx& c, const float* dy, int lddy, const float* x, i
                          c.scratch_bytes());
 }
 
+bbbp_gemm_desc gemm_desc(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
+                         float* C, int ldc, int batch = 1, long sA = 0, long sB = 0, long sC = 0) {
+    bbbp_gemm_desc g;
+    g.transA = transA; g.transB = transB; g.M = M; g.N = N; g.K = K; g.alpha = alpha;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.bias = nullptr; g.residual = nullptr; g.ldr = 0; g.act = 0; g.gate = nullptr; g.ldg = 0; g.gate_scale = 1.f;
+    g.batch = batch; g.strideA = sA; g.strideB = sB; g.strideC = sC; g.strideR = 0; g.strideG = 0;
+    return g;
+}
+
 uint64_t site_seed(uint64_t seed, int layer, int site) { return seed * 0x9E3779B97F4A7C15ull + (uint64_t)(layer * 8 + site + 1); }
 
 }  // namespace
@@ -339,7 +351,7 @@ extern "C" int bbbp_mixed_forward(void* stream, const bbbp_mixed_desc* d, const 
         // scores_h = scale * Q_h K_h^T
         TRY(bbbp_gemm_f32(ce.st, 0, 1, B, B, D, scale, qkv, 3 * F, qkv + F, 3 * F, prob, B, nullptr, nullptr, 0, 0, NH, D, D,
                           (long)B * B, 0, ce.scratch(), ce.scratch_bytes()));
-        float* pd = plan.drop ? c.f(plan.pd) : prob;
+        float* pd = c.f(o.pd);
         TRY(bbbp_softmax_fwd(ce.st, prob, pd, (long)NH * B, B, p_drop, site_seed(d->seed, l, 0)));
         // ctx_h = Pd_h V_h
         TRY(bbbp_gemm_f32(ce.st, 0, 0, B, D, B, 1.f, pd, B, qkv + 2 * F, 3 * F, ctx, F, nullptr, nullptr, 0, 0, NH, (long)B * B,
@@ -510,9 +522,14 @@ extern "C" int bbbp_mixed_backward(void* stream, const bbbp_mixed_desc* d, const
         TRY(linear_bwd_weight(cl, dff, F, hff, DFF, G[ix.layer(l, L_W2)], B, F, DFF));
         TRY(bbbp_bias_act_bwd(cl.st, dff, F, nullptr, 0, G[ix.layer(l, L_B2)], B, F, 0, 1.f));
         // linear2 input gradient, then ReLU (+ dropout: hff is the post-dropout value, hff > 0 <=> active and kept)
-        TRY(linear_bwd_input(ce, dff, F, P[ix.layer(l, L_W2)], dhff, DFF, B, F, DFF));
-        TRY(bbbp_bias_act_bwd(ce.st, dhff, DFF, hff, DFF, G[ix.layer(l, L_B1)], B, DFF, BBBP_ACT_RELU, inv_keep));
+        // the ReLU / dropout mask rides in the GEMM epilogue; the bias gradient (a column sum) is a leaf
+        {
+            bbbp_gemm_desc g = gemm_desc(0, 0, B, DFF, F, 1.f, dff, F, P[ix.layer(l, L_W2)], DFF, dhff, DFF);
+            g.gate = hff; g.ldg = DFF; g.gate_scale = inv_keep;
+            TRY(bbbp_gemm_f32_grouped(ce.st, &g, 1, ce.scratch(), ce.scratch_bytes()));
+        }
         TRY(leaf_after(ce));
+        TRY(bbbp_bias_act_bwd(cl.st, dhff, DFF, nullptr, 0, G[ix.layer(l, L_B1)], B, DFF, 0, 1.f));
         TRY(linear_bwd_weight(cl, dhff, DFF, y1, F, G[ix.layer(l, L_W1)], B, DFF, F));
         // dy1 = dhff W1 + dz2
         TRY(linear_bwd_input(ce, dhff, DFF, P[ix.layer(l, L_W1)], dy1, F, B, DFF, F, dz2, F));
@@ -526,25 +543,23 @@ extern "C" int bbbp_mixed_backward(void* stream, const bbbp_mixed_desc* d, const
         TRY(bbbp_bias_act_bwd(cl.st, dsa, F, nullptr, 0, G[ix.layer(l, L_OUTB)], B, F, 0, 1.f));
         // out_proj input gradient
         TRY(linear_bwd_input(ce, dsa, F, P[ix.layer(l, L_OUTW)], dctx, F, B, F, F));
-        // attention: Pd (dropped probabilities) is recomputed when dropout is on
-        const float* pdp = prob;
-        if (plan.drop) {
-            float* pd = c.f(plan.pd);
-            TRY(bbbp_dropout(ce.st, prob, pd, (long)NH * B * B, p_drop, site_seed(d->seed, l, 0)));
-            pdp = pd;
+        // attention backward.  Products that become ready together share a launch (bbbp_gemm_f32_grouped):
+        //   dV_h = Pd_h^T dctx_h -> dqkv[:, 2F + hD]   |   dPd_h = dctx_h V_h^T
+        const float* pdp = c.f(o.pd);
+        {
+            bbbp_gemm_desc g[2] = {
+                gemm_desc(1, 0, B, D, B, 1.f, pdp, B, dctx, F, dqkv + 2 * F, 3 * F, NH, (long)B * B, D, D),
+                gemm_desc(0, 1, B, B, D, 1.f, dctx, F, qkv + 2 * F, 3 * F, dprob, B, NH, D, D, (long)B * B)};
+            TRY(bbbp_gemm_f32_grouped(ce.st, g, 2, ce.scratch(), ce.scratch_bytes()));
         }
-        // dV_h = Pd_h^T dctx_h  -> dqkv[:, 2F + hD]
-        TRY(bbbp_gemm_f32(ce.st, 1, 0, B, D, B, 1.f, pdp, B, dctx, F, dqkv + 2 * F, 3 * F, nullptr, nullptr, 0, 0, NH, (long)B * B,
-                          D, D, 0, ce.scratch(), ce.scratch_bytes()));
-        // dPd_h = dctx_h V_h^T
-        TRY(bbbp_gemm_f32(ce.st, 0, 1, B, B, D, 1.f, dctx, F, qkv + 2 * F, 3 * F, dprob, B, nullptr, nullptr, 0, 0, NH, D, D,
-                          (long)B * B, 0, ce.scratch(), ce.scratch_bytes()));
         TRY(bbbp_softmax_bwd(ce.st, dprob, prob, (long)NH * B, B, p_drop, site_seed(d->seed, l, 0)));
-        // dQ_h = scale dS_h K_h ; dK_h = scale dS_h^T Q_h
-        TRY(bbbp_gemm_f32(ce.st, 0, 0, B, D, B, scale, dprob, B, qkv + F, 3 * F, dqkv, 3 * F, nullptr, nullptr, 0, 0, NH,
-                          (long)B * B, D, D, 0, ce.scratch(), ce.scratch_bytes()));
-        TRY(bbbp_gemm_f32(ce.st, 1, 0, B, D, B, scale, dprob, B, qkv, 3 * F, dqkv + F, 3 * F, nullptr, nullptr, 0, 0, NH,
-                          (long)B * B, D, D, 0, ce.scratch(), ce.scratch_bytes()));
+        //   dQ_h = scale dS_h K_h   |   dK_h = scale dS_h^T Q_h
+        {
+            bbbp_gemm_desc g[2] = {
+                gemm_desc(0, 0, B, D, B, scale, dprob, B, qkv + F, 3 * F, dqkv, 3 * F, NH, (long)B * B, D, D),
+                gemm_desc(1, 0, B, D, B, scale, dprob, B, qkv, 3 * F, dqkv + F, 3 * F, NH, (long)B * B, D, D)};
+            TRY(bbbp_gemm_f32_grouped(ce.st, g, 2, ce.scratch(), ce.scratch_bytes()));
+        }
         TRY(leaf_after(ce));
         TRY(linear_bwd_weight(cl, dqkv, 3 * F, xin, F, G[ix.layer(l, L_INW)], B, 3 * F, F));
         TRY(bbbp_bias_act_bwd(cl.st, dqkv, 3 * F, nullptr, 0, G[ix.layer(l, L_INB)], B, 3 * F, 0, 1.f));

@@ -21,6 +21,8 @@
 #include "common.h"
 #include "bbbp_hip.h"
 
+#define TRY_RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
 namespace {
 
 // K depth of one LDS stage.  The 64x64 tile keeps 17 KB of LDS and ~32 VGPRs on purpose: the encoder's small
@@ -40,6 +42,7 @@ struct GemmParams {
     int splits, kchunk;      // split-K: K range per split (multiple of BK)
     float* slab;             // [batch][split][M][N] when splits > 1
     int vecA, vecB;          // 16-byte global loads allowed
+    const float* gate; int ldg; long sG; float gate_scale;      // optional: result *= gate > 0 ? gate_scale : 0
 };
 
 // Four consecutive elements starting at p, `valid` (0..4) of them inside the matrix; the rest read as 0.
@@ -241,6 +244,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 int m = m0 + wm * WM + i * 32 + mfma_row(r, lane);
                 if (m < p.M && n < p.N) {
                     float v = apply_act(p.alpha * acc[i][j][r] + bv, p.act);
+                    if (p.gate) v *= p.gate[(long)batch * p.sG + (long)m * p.ldg + n] > 0.f ? p.gate_scale : 0.f;
                     if (R) v += R[(long)m * p.ldr + n];
                     C[(long)m * p.ldc + n] = v;
                 }
@@ -261,6 +265,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
         for (int k = 0; k < p.splits; ++k) s += S[(long)k * mn + idx];
         int m = (int)(idx / p.N), n = (int)(idx % p.N);
         float v = apply_act(p.alpha * s + (p.bias ? p.bias[n] : 0.f), p.act);
+        if (p.gate) v *= p.gate[(long)batch * p.sG + (long)m * p.ldg + n] > 0.f ? p.gate_scale : 0.f;
         if (R) v += R[(long)m * p.ldr + n];
         C[(long)m * p.ldc + n] = v;
     }
@@ -299,7 +304,9 @@ struct DirectParams {
     long sA, sB, sC, sR;
     float alpha;
     int act;
+    const float* gate; int ldg; long sG; float gate_scale;
     int wsm, wsn, ks;        // waves of a work-group: wsm x wsn output tiles, each computed by ks K-slices
+    int batch, gx, gy;       // grid extent of THIS problem (a grouped launch covers the largest)
 };
 
 template <int T>
@@ -365,15 +372,12 @@ struct DirectOperand {
 };
 
 template <int LAYOUT, int TM, int TN>
-__global__ __launch_bounds__(1024) void gemm_direct_kernel(DirectParams p) {
-    BBBP_HIGH_PRIO();
+__device__ __forceinline__ void gemm_direct_body(const DirectParams& p, int batch, float* red) {
     constexpr bool A_KMAJ = (LAYOUT == 2), B_KMAJ = (LAYOUT != 0);
     constexpr int D = 4;                         // chunks in flight per wave
-    extern __shared__ float red[];               // [wave][TM * TN * 4][64] when ks > 1
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ks = wave % p.ks, sp = wave / p.ks;
     const int wm = sp / p.wsn, wn = sp % p.wsn;
-    const int batch = blockIdx.z;
     DirectOperand<TM, A_KMAJ> opa;
     DirectOperand<TN, B_KMAJ> opb;
     opa.init(p.A + (long)batch * p.sA, p.lda, p.M, (blockIdx.y * p.wsm + wm) * 16 * TM, lane);
@@ -456,10 +460,32 @@ __global__ __launch_bounds__(1024) void gemm_direct_kernel(DirectParams p) {
                 const int m = opa.index(um, 4 * kq + r);
                 if (m < p.M && n < p.N) {
                     float v = apply_act(p.alpha * acc[um][un][r] + bv, p.act);
+                    if (p.gate) v *= p.gate[(long)batch * p.sG + (long)m * p.ldg + n] > 0.f ? p.gate_scale : 0.f;
                     if (R) v += R[(long)m * p.ldr + n];
                     C[(long)m * p.ldc + n] = v;
                 }
             }
+    }
+}
+
+template <int LAYOUT, int TM, int TN>
+__global__ __launch_bounds__(1024) void gemm_direct_kernel(DirectParams p) {
+    BBBP_HIGH_PRIO();
+    extern __shared__ float red[];               // [wave][TM * TN * 4][64] when ks > 1
+    gemm_direct_body<LAYOUT, TM, TN>(p, blockIdx.z, red);
+}
+
+// Two independent products in one launch (dV | dP and dQ | dK of the attention backward, which become ready together):
+// the chain of small launches is bound by per-launch latency, not by work, so halving the launches halves the time.
+// blockIdx.z < p0.batch -> problem 0, else problem 1; work-groups outside a problem's own grid exit at once.
+template <int L0, int T0, int L1, int T1>
+__global__ __launch_bounds__(256) void gemm_direct_pair_kernel(DirectParams p0, DirectParams p1) {
+    BBBP_HIGH_PRIO();
+    extern __shared__ float red[];
+    if ((int)blockIdx.z < p0.batch) {
+        if ((int)blockIdx.x < p0.gx && (int)blockIdx.y < p0.gy) gemm_direct_body<L0, T0, T0>(p0, blockIdx.z, red);
+    } else {
+        if ((int)blockIdx.x < p1.gx && (int)blockIdx.y < p1.gy) gemm_direct_body<L1, T1, T1>(p1, blockIdx.z - p0.batch, red);
     }
 }
 
@@ -490,25 +516,46 @@ DirectPlan direct_plan(int M, int N, int K, int batch) {
     return d;
 }
 
-template <int LAYOUT, int T>
-void launch_direct_one(const DirectParams& p, int batch, hipStream_t st) {
+inline size_t direct_lds(const DirectParams& p, int t) {
     const int waves = p.wsm * p.wsn * p.ks;
-    dim3 grid(cdiv(p.N, 16 * T * p.wsn), cdiv(p.M, 16 * T * p.wsm), batch);
-    size_t lds = p.ks > 1 ? (size_t)waves * T * T * 4 * 64 * sizeof(float) : 0;
-    if (lds < g_bbbp_small_lds_pad) lds = g_bbbp_small_lds_pad;
-    hipLaunchKernelGGL((gemm_direct_kernel<LAYOUT, T, T>), grid, dim3(64 * waves), lds, st, p);
+    size_t lds = p.ks > 1 ? (size_t)waves * t * t * 4 * 64 * sizeof(float) : 0;
+    return lds < g_bbbp_small_lds_pad ? g_bbbp_small_lds_pad : lds;
 }
 
-void launch_direct(const DirectParams& p, int layout, int t, int batch, hipStream_t st) {
+template <int LAYOUT, int T>
+void launch_direct_one(const DirectParams& p, hipStream_t st) {
+    const int waves = p.wsm * p.wsn * p.ks;
+    hipLaunchKernelGGL((gemm_direct_kernel<LAYOUT, T, T>), dim3(p.gx, p.gy, p.batch), dim3(64 * waves), direct_lds(p, T), st, p);
+}
+
+void launch_direct(const DirectParams& p, int layout, int t, hipStream_t st) {
     if (t == 1) {
-        if (layout == 0) launch_direct_one<0, 1>(p, batch, st);
-        else if (layout == 1) launch_direct_one<1, 1>(p, batch, st);
-        else launch_direct_one<2, 1>(p, batch, st);
+        if (layout == 0) launch_direct_one<0, 1>(p, st);
+        else if (layout == 1) launch_direct_one<1, 1>(p, st);
+        else launch_direct_one<2, 1>(p, st);
     } else {
-        if (layout == 0) launch_direct_one<0, 2>(p, batch, st);
-        else if (layout == 1) launch_direct_one<1, 2>(p, batch, st);
-        else launch_direct_one<2, 2>(p, batch, st);
+        if (layout == 0) launch_direct_one<0, 2>(p, st);
+        else if (layout == 1) launch_direct_one<1, 2>(p, st);
+        else launch_direct_one<2, 2>(p, st);
     }
+}
+
+template <int L0, int T0, int L1, int T1>
+void launch_pair_one(const DirectParams& a, const DirectParams& b, hipStream_t st) {
+    const size_t la = direct_lds(a, T0), lb = direct_lds(b, T1);
+    dim3 grid(a.gx > b.gx ? a.gx : b.gx, a.gy > b.gy ? a.gy : b.gy, a.batch + b.batch);
+    hipLaunchKernelGGL((gemm_direct_pair_kernel<L0, T0, L1, T1>), grid, dim3(256), la > lb ? la : lb, st, a, b);
+}
+
+// the pairs the engine issues; anything else runs as two launches
+bool launch_pair(const DirectParams& a, int la, int ta, const DirectParams& b, int lb, int tb, hipStream_t st) {
+    if (a.wsm * a.wsn * a.ks != 4 || b.wsm * b.wsn * b.ks != 4) return false;
+    if ((long)a.batch + b.batch > 65535) return false;
+    if (ta == 1 && tb == 1) {
+        if (la == 2 && lb == 0) { launch_pair_one<2, 1, 0, 1>(a, b, st); return true; }      // dV = Pd^T dO | dPd = dO V^T
+        if (la == 1 && lb == 2) { launch_pair_one<1, 1, 2, 1>(a, b, st); return true; }      // dQ = dS K   | dK = dS^T Q
+    }
+    return false;
 }
 
 template <int BM, int BN, int LAYOUT, bool VEC>
@@ -577,42 +624,59 @@ extern "C" size_t bbbp_gemm_workspace_bytes(int M, int N, int K, int batch) {
     return splits > 1 ? (size_t)batch * splits * M * N * sizeof(float) : 0;
 }
 
-extern "C" int bbbp_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float alpha,
-                             const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                             const float* bias, const float* residual, int ldr, int act,
-                             int batch, long strideA, long strideB, long strideC, long strideR,
-                             void* workspace, size_t workspace_bytes) {
-    BBBP_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && batch >= 1, "gemm: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
-    BBBP_CHECK_ARG(act >= 0 && act <= 2, "gemm: bad act %d", act);
-    BBBP_CHECK_ARG(!(transA && transB), "gemm: layout TT (A^T B^T) is not on the hot path");
-    if (M == 0 || N == 0) return BBBP_OK;
-    BBBP_CHECK_ARG(A && B && C, "gemm: null operand");
-    // layout: NT = (transA 0, transB 1); NN = (0, 0); TN = (1, 0)
-    int layout = transA ? 2 : (transB ? 0 : 1);
-    BBBP_CHECK_ARG(lda >= (transA ? M : K), "gemm: lda %d too small", lda);
-    BBBP_CHECK_ARG(ldb >= (transB ? K : N), "gemm: ldb %d too small", ldb);
-    BBBP_CHECK_ARG(ldc >= N, "gemm: ldc %d too small", ldc);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const DirectPlan dp = direct_plan(M, N, K, batch);
-    if (dp.use && batch <= 65535 && cdiv(M, 16 * dp.t * dp.wsm) <= 65535) {
-        DirectParams d;
-        d.A = A; d.B = B; d.C = C; d.bias = bias; d.R = residual;
-        d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc; d.ldr = ldr;
-        d.sA = strideA; d.sB = strideB; d.sC = strideC; d.sR = strideR;
-        d.alpha = alpha; d.act = act; d.wsm = dp.wsm; d.wsn = dp.wsn; d.ks = dp.ks;
-        launch_direct(d, layout, dp.t, batch, st);
+namespace {
+
+int gemm_validate(const bbbp_gemm_desc& g) {
+    BBBP_CHECK_ARG(g.M >= 0 && g.N >= 0 && g.K >= 0 && g.batch >= 1, "gemm: bad sizes M=%d N=%d K=%d batch=%d", g.M, g.N, g.K, g.batch);
+    BBBP_CHECK_ARG(g.act >= 0 && g.act <= 2, "gemm: bad act %d", g.act);
+    BBBP_CHECK_ARG(!(g.transA && g.transB), "gemm: layout TT (A^T B^T) is not on the hot path");
+    if (g.M == 0 || g.N == 0) return BBBP_OK;
+    BBBP_CHECK_ARG(g.A && g.B && g.C, "gemm: null operand");
+    BBBP_CHECK_ARG(g.lda >= (g.transA ? g.M : g.K), "gemm: lda %d too small", g.lda);
+    BBBP_CHECK_ARG(g.ldb >= (g.transB ? g.K : g.N), "gemm: ldb %d too small", g.ldb);
+    BBBP_CHECK_ARG(g.ldc >= g.N, "gemm: ldc %d too small", g.ldc);
+    BBBP_CHECK_ARG(!g.gate || g.ldg >= g.N, "gemm: ldg %d too small", g.ldg);
+    return BBBP_OK;
+}
+
+// layout: NT = (transA 0, transB 1); NN = (0, 0); TN = (1, 0)
+inline int layout_of(const bbbp_gemm_desc& g) { return g.transA ? 2 : (g.transB ? 0 : 1); }
+
+bool direct_params(const bbbp_gemm_desc& g, DirectParams* d, int* t) {
+    const DirectPlan dp = direct_plan(g.M, g.N, g.K, g.batch);
+    if (!dp.use || g.batch > 65535 || cdiv(g.M, 16 * dp.t * dp.wsm) > 65535) return false;
+    d->A = g.A; d->B = g.B; d->C = g.C; d->bias = g.bias; d->R = g.residual;
+    d->M = g.M; d->N = g.N; d->K = g.K; d->lda = g.lda; d->ldb = g.ldb; d->ldc = g.ldc; d->ldr = g.ldr;
+    d->sA = g.strideA; d->sB = g.strideB; d->sC = g.strideC; d->sR = g.strideR;
+    d->alpha = g.alpha; d->act = g.act;
+    d->gate = g.gate; d->ldg = g.ldg; d->sG = g.strideG; d->gate_scale = g.gate_scale;
+    d->wsm = dp.wsm; d->wsn = dp.wsn; d->ks = dp.ks;
+    d->batch = g.batch; d->gx = cdiv(g.N, 16 * dp.t * dp.wsn); d->gy = cdiv(g.M, 16 * dp.t * dp.wsm);
+    *t = dp.t;
+    return true;
+}
+
+int gemm_run(hipStream_t st, const bbbp_gemm_desc& g, void* workspace, size_t workspace_bytes) {
+    TRY_RC(gemm_validate(g));
+    if (g.M == 0 || g.N == 0) return BBBP_OK;
+    const int layout = layout_of(g);
+    DirectParams d; int t;
+    if (direct_params(g, &d, &t)) {
+        launch_direct(d, layout, t, st);
         BBBP_CHECK_LAUNCH();
         return BBBP_OK;
     }
+    const int M = g.M, N = g.N, K = g.K, batch = g.batch;
     GemmParams p;
-    p.A = A; p.B = B; p.C = C; p.bias = bias; p.R = residual;
-    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
-    p.sA = strideA; p.sB = strideB; p.sC = strideC; p.sR = strideR;
-    p.alpha = alpha; p.act = act;
+    p.A = g.A; p.B = g.B; p.C = g.C; p.bias = g.bias; p.R = g.residual;
+    p.M = M; p.N = N; p.K = K; p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc; p.ldr = g.ldr;
+    p.sA = g.strideA; p.sB = g.strideB; p.sC = g.strideC; p.sR = g.strideR;
+    p.alpha = g.alpha; p.act = g.act;
+    p.gate = g.gate; p.ldg = g.ldg; p.sG = g.strideG; p.gate_scale = g.gate_scale;
     // 16-byte loads need aligned bases/strides AND a contiguous extent that is a multiple of 4 (so that a quad is
     // either fully inside or fully outside the matrix): K for an [M][K] / [N][K] operand, M or N for a [K][.] one
-    p.vecA = aligned16(A) && (lda % 4 == 0) && (strideA % 4 == 0) && ((transA ? M : K) % 4 == 0);
-    p.vecB = aligned16(B) && (ldb % 4 == 0) && (strideB % 4 == 0) && ((transB ? K : N) % 4 == 0);
+    p.vecA = aligned16(g.A) && (g.lda % 4 == 0) && (g.strideA % 4 == 0) && ((g.transA ? M : K) % 4 == 0);
+    p.vecB = aligned16(g.B) && (g.ldb % 4 == 0) && (g.strideB % 4 == 0) && ((g.transB ? K : N) % 4 == 0);
     int tile;
     gemm_plan(M, N, K, batch, &tile, &p.splits, &p.kchunk);
     p.slab = nullptr;
@@ -637,6 +701,47 @@ extern "C" int bbbp_gemm_f32(void* stream, int transA, int transB, int M, int N,
         if (gx > 4096) gx = 4096;
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(gx, batch), dim3(256), g_bbbp_small_lds_pad, st, p);
         BBBP_CHECK_LAUNCH();
+    }
+    return BBBP_OK;
+}
+
+}  // namespace
+
+extern "C" int bbbp_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float alpha,
+                             const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                             const float* bias, const float* residual, int ldr, int act,
+                             int batch, long strideA, long strideB, long strideC, long strideR,
+                             void* workspace, size_t workspace_bytes) {
+    bbbp_gemm_desc g;
+    g.transA = transA; g.transB = transB; g.M = M; g.N = N; g.K = K; g.alpha = alpha;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
+    g.gate = nullptr; g.ldg = 0; g.gate_scale = 1.f;
+    g.batch = batch; g.strideA = strideA; g.strideB = strideB; g.strideC = strideC; g.strideR = strideR; g.strideG = 0;
+    return gemm_run(static_cast<hipStream_t>(stream), g, workspace, workspace_bytes);
+}
+
+extern "C" int bbbp_gemm_f32_grouped(void* stream, const bbbp_gemm_desc* problems, int count, void* workspace,
+                                     size_t workspace_bytes) {
+    BBBP_CHECK_ARG(count >= 0 && (count == 0 || problems), "gemm_grouped: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int i = 0;
+    while (i < count) {
+        if (i + 1 < count) {                       // try to issue problems i and i + 1 as one launch
+            const bbbp_gemm_desc &a = problems[i], &b = problems[i + 1];
+            TRY_RC(gemm_validate(a));
+            TRY_RC(gemm_validate(b));
+            DirectParams da, db; int ta, tb;
+            if (a.M > 0 && a.N > 0 && b.M > 0 && b.N > 0 && direct_params(a, &da, &ta) && direct_params(b, &db, &tb) &&
+                launch_pair(da, layout_of(a), ta, db, layout_of(b), tb, st)) {
+                BBBP_CHECK_LAUNCH();
+                i += 2;
+                continue;
+            }
+        }
+        // the split-K scratch is shared: sequential launches on one stream may reuse it
+        TRY_RC(gemm_run(st, problems[i], workspace, workspace_bytes));
+        ++i;
     }
     return BBBP_OK;
 }

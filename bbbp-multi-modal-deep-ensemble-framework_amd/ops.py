@@ -41,10 +41,8 @@ def _rowmajor_2d(t: torch.Tensor, name: str) -> Tuple[int, int, int]:
     return t.shape[0], t.shape[1], ld
 
 
-def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False, alpha: float = 1.0,
-         bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act=None,
-         out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out = act(alpha * op(a) @ op(b) + bias) + residual  (2-D; or 3-D batched with equal batch dims)."""
+def _gemm_desc(a, b, trans_a, trans_b, alpha, bias, residual, act, out, gate, gate_scale):
+    """Validate one product and describe it as a bbbp_gemm_desc; returns (desc, out, split-K workspace bytes)."""
     _chk(a, "a"); _chk(b, "b")
     batched = a.dim() == 3
     if batched:
@@ -74,17 +72,57 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bo
         _chk(residual, "residual")
         ldr = N if batched else _rowmajor_2d(residual, "residual")[2]
         sr = M * N if batched else 0
+    ldg, sg = 0, 0
+    if gate is not None:
+        _chk(gate, "gate")
+        if tuple(gate.shape) != tuple(out.shape):
+            raise RuntimeError(f"gemm: gate shape {tuple(gate.shape)} != output shape {tuple(out.shape)}")
+        ldg = N if batched else _rowmajor_2d(gate, "gate")[2]
+        sg = M * N if batched else 0
     if bias is not None:
         _chk(bias, "bias")
         if bias.numel() != N:
             raise RuntimeError(f"gemm: bias has {bias.numel()} elements, expected {N}")
-    L = _lib.lib()
-    wsb = L.bbbp_gemm_workspace_bytes(M, N, K, nb)
+    d = _lib.GemmDesc(int(trans_a), int(trans_b), M, N, K, float(alpha), a.data_ptr(), lda, b.data_ptr(), ldb,
+                      out.data_ptr(), ldc, _p(bias), _p(residual), ldr, ACT[act], _p(gate), ldg, float(gate_scale), nb,
+                      sa, sb, sc, sr, sg)
+    return d, out, _lib.lib().bbbp_gemm_workspace_bytes(M, N, K, nb)
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False, alpha: float = 1.0,
+         bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act=None,
+         out: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None, gate_scale: float = 1.0) -> torch.Tensor:
+    """out = gate_mask(act(alpha * op(a) @ op(b) + bias)) + residual  (2-D; or 3-D batched with equal batch dims).
+
+    gate: optional tensor of the output's shape; the result is multiplied by gate_scale where gate > 0, by 0 elsewhere."""
+    if gate is not None:
+        return gemm_grouped([dict(a=a, b=b, trans_a=trans_a, trans_b=trans_b, alpha=alpha, bias=bias, residual=residual,
+                                  act=act, out=out, gate=gate, gate_scale=gate_scale)])[0]
+    d, out, wsb = _gemm_desc(a, b, trans_a, trans_b, alpha, bias, residual, act, out, None, 1.0)
     ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=a.device)
-    _lib.check(L.bbbp_gemm_f32(_stream(), int(trans_a), int(trans_b), M, N, K, float(alpha), a.data_ptr(), lda,
-                               b.data_ptr(), ldb, out.data_ptr(), ldc, _p(bias), _p(residual), ldr, ACT[act], nb, sa, sb,
-                               sc, sr, ws.data_ptr(), wsb), "bbbp_gemm_f32")
+    _lib.check(_lib.lib().bbbp_gemm_f32(_stream(), d.transA, d.transB, d.M, d.N, d.K, d.alpha, d.A, d.lda, d.B, d.ldb,
+                                        d.C, d.ldc, d.bias, d.residual, d.ldr, d.act, d.batch, d.strideA, d.strideB,
+                                        d.strideC, d.strideR, ws.data_ptr(), wsb), "bbbp_gemm_f32")
     return out
+
+
+def gemm_grouped(problems) -> list:
+    """Independent products (dicts of gemm()'s arguments); neighbours that are small enough share one launch."""
+    keys = ("trans_a", "trans_b", "alpha", "bias", "residual", "act", "out", "gate", "gate_scale")
+    defaults = dict(trans_a=False, trans_b=False, alpha=1.0, bias=None, residual=None, act=None, out=None, gate=None,
+                    gate_scale=1.0)
+    descs, outs, wsb = [], [], 0
+    for pr in problems:
+        kw = {k: pr.get(k, defaults[k]) for k in keys}
+        d, out, w = _gemm_desc(pr["a"], pr["b"], kw["trans_a"], kw["trans_b"], kw["alpha"], kw["bias"], kw["residual"],
+                               kw["act"], kw["out"], kw["gate"], kw["gate_scale"])
+        descs.append(d); outs.append(out); wsb = max(wsb, w)
+    if not descs:
+        return []
+    arr = (_lib.GemmDesc * len(descs))(*descs)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=outs[0].device)
+    _lib.check(_lib.lib().bbbp_gemm_f32_grouped(_stream(), arr, len(descs), ws.data_ptr(), wsb), "bbbp_gemm_f32_grouped")
+    return outs
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,

@@ -48,6 +48,27 @@ int bbbp_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, flo
                   int batch, long strideA, long strideB, long strideC, long strideR,
                   void* workspace, size_t workspace_bytes);
 
+/* One product of a grouped launch: the bbbp_gemm_f32 arguments as a struct, plus an optional gate: the result is
+ * multiplied by gate_scale where gate[m][n] > 0 and by 0 elsewhere (after bias/act, before the residual) -- the
+ * ReLU(+dropout) backward of linear1 (R:75-78 under loss.backward(), R:190) folded into the input-gradient GEMM. */
+typedef struct bbbp_gemm_desc {
+    int transA, transB, M, N, K;
+    float alpha;
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    const float* bias;
+    const float* residual; int ldr;
+    int act;
+    const float* gate; int ldg; float gate_scale;
+    int batch;
+    long strideA, strideB, strideC, strideR, strideG;
+} bbbp_gemm_desc;
+/* `count` independent products (outputs must not alias another product's operands).  Products that become ready
+ * together -- dV | dP and dQ | dK of the attention backward -- go out as ONE launch when both are small; anything
+ * else runs back to back on `stream`.  Results are identical to `count` bbbp_gemm_f32 calls. */
+int bbbp_gemm_f32_grouped(void* stream, const bbbp_gemm_desc* problems, int count, void* workspace, size_t workspace_bytes);
+
 /* ---- Conv2d(k3,s1,p1) + ReLU + MaxPool2d(2,2), NCHW ------------------------------------------
  * forward: R:85-87 (3->32, 128x128) and R:88-90 (32->64, 64x64).  y is the pooled output,
  * mask[B][cout][H/2][W/2] (u8) records the arg-max of each 2x2 window (0..3, PyTorch first-max order)

@@ -57,6 +57,28 @@ def test_gemm_epilogues_and_slices(dev):
     assert_close(got.cpu().numpy(), (0.25 * qa.double() @ kb.double().transpose(1, 2)).numpy(), rtol=1e-5, what="batched")
 
 
+@pytest.mark.parametrize("B,D,NH", [(512, 167, 1), (96, 8, 8), (40, 700, 1), (512, 2048, 1)])
+def test_gemm_grouped_pairs_and_gate(dev, B, D, NH):
+    """The attention-backward pairs (TN | NT and NN | TN) through one grouped call == separate float64 products."""
+    F = D * NH
+    pd, dctx, v = rnd(NH, B, B, seed=1), rnd(NH, B, D, seed=2), rnd(NH, B, D, seed=3)
+    got = ops.gemm_grouped([dict(a=pd.to(dev), b=dctx.to(dev), trans_a=True),
+                            dict(a=dctx.to(dev), b=v.to(dev), trans_b=True)])
+    want = [pd.double().transpose(1, 2) @ dctx.double(), dctx.double() @ v.double().transpose(1, 2)]
+    ds, k, q = rnd(NH, B, B, seed=4), rnd(NH, B, D, seed=5), rnd(NH, B, D, seed=6)
+    got += ops.gemm_grouped([dict(a=ds.to(dev), b=k.to(dev), alpha=0.3), dict(a=ds.to(dev), b=q.to(dev), trans_a=True, alpha=0.3)])
+    want += [0.3 * ds.double() @ k.double(), 0.3 * ds.double().transpose(1, 2) @ q.double()]
+    for i, (g_, w_) in enumerate(zip(got, want)):
+        assert_close(g_.cpu().numpy(), w_.numpy(), rtol=2e-5, atol_frac=2e-6, what=f"grouped product {i}")
+    # gate: ReLU/dropout backward folded into the epilogue (both kernel families: small -> latency path, large -> LDS tiles)
+    for (M, N, K) in ((B, 300, 167), (1024, 2048, 512)):
+        a, w, gate, res = rnd(M, K, seed=7), rnd(K, N, seed=8), rnd(M, N, seed=9), rnd(M, N, seed=10)
+        want = (a.double() @ w.double()) * (gate.double() > 0) * 1.25 + res.double()
+        got1 = ops.gemm(a.to(dev), w.to(dev), gate=gate.to(dev), gate_scale=1.25, residual=res.to(dev))
+        assert_close(got1.cpu().numpy(), want.numpy(), rtol=2e-5, atol_frac=2e-6, what=f"gated {M}x{N}x{K}")
+    assert ops.gemm_grouped([]) == []
+
+
 def test_gemm_errors(dev):
     with pytest.raises(RuntimeError):
         ops.gemm(torch.zeros(4, 5), torch.zeros(5, 6))                    # CPU tensors: no fallback
