@@ -43,6 +43,7 @@ _SIGNATURES = {
     "bbbp_gemm_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, _FP, c_int, _FP, c_int, _FP, c_int,
                               _FP, _FP, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_void_p, c_size_t]),
     "bbbp_gemm_f32_grouped": (c_int, [c_void_p, POINTER(GemmDesc), c_int, c_void_p, c_size_t]),
+    "bbbp_conv_last_clock": (c_int, [POINTER(c_uint64), POINTER(c_uint64)]),
     "bbbp_conv3x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "bbbp_conv3x3_relu_pool_fwd": (c_int, [c_void_p, _FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                            c_void_p, c_size_t]),

@@ -83,4 +83,6 @@ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, floa
 
 // Small latency-bound kernels run beside persistent MFMA-bound conv work-groups (engine.hip, two streams); raising
 // their wave priority lets them win issue arbitration against the older conv waves on the same SIMD.
+#ifndef BBBP_HIGH_PRIO
 #define BBBP_HIGH_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif

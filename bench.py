@@ -180,6 +180,11 @@ def main():
         L.bbbp_profile_enable(0)
         L.bbbp_set_overlap(old)
         isolated = {L.bbbp_profile_section_name(i).decode(): ms_sum[i] / cnt[i] for i in range(nsec) if cnt[i]}
+        # the last forward / data-gradient conv launch of a step is conv2's data gradient: its work-group 0 counted
+        # shader cycles and 100 MHz wall ticks (include/bbbp_hip.h: bbbp_conv_last_clock)
+        cyc, ticks = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        _lib.check(L.bbbp_conv_last_clock(ctypes.byref(cyc), ctypes.byref(ticks)), "bbbp_conv_last_clock")
+        clock = dict(cycles=int(cyc.value), ghz=(cyc.value / (ticks.value * 10.0)) if ticks.value else None)
     if world > 1:
         dist.barrier()
 
@@ -205,6 +210,13 @@ def main():
                             ms_per_launch_isolated=round(isolated.get(dom, 0.0), 4),
                             frac_isolated=round(conv2 / (isolated[dom] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if isolated.get(dom) else None,
                             sections_ms={k: round(v, 4) for k, v in sections.items()})
+            if clock.get("ghz"):
+                # one v_mfma_f32_32x32x2_f32 = 4096 flop and occupies its SIMD's matrix pipe for 64 cycles
+                n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+                roofline["conv2_dgrad_isolated_clock"] = dict(
+                    sustained_ghz=round(clock["ghz"], 3), kernel_cycles=clock["cycles"],
+                    mfma_pipe_busy=round(conv2 / 4096 * 64 / n_simd / clock["cycles"], 4),
+                    note="shader clock while the kernel runs alone; the 157.3 TFLOP/s peak assumes 2.4 GHz")
         total_flops = sum(fl.values()) * 3 - fl["conv1"]          # bwd = 2 * fwd - conv1 dgrad
         result = {
             "metric": "molecules/sec fwd+bwd (3-branch ensemble, B=512)", "value": round(value, 1), "unit": "molecules/s",

@@ -75,6 +75,9 @@ int bbbp_gemm_f32_grouped(void* stream, const bbbp_gemm_desc* problems, int coun
  * or 4 where the ReLU is inactive; backward consumes it instead of the pre-pool activation.
  * bwd_data / bwd_weight: autograd of the same statements under loss.backward() (R:190). */
 size_t bbbp_conv3x3_workspace_bytes(int B, int cin, int cout, int H, int W);
+/* Measurement aid (bench.py): shader-clock cycles and 100 MHz wall ticks that work-group 0 of the most recent
+ * forward / data-gradient conv launch ran for (synchronises the device). */
+int bbbp_conv_last_clock(unsigned long long* shader_cycles, unsigned long long* ticks_100mhz);
 int bbbp_conv3x3_relu_pool_fwd(void* stream, const float* x, const float* w, const float* bias,
                                float* y, uint8_t* mask, int B, int cin, int cout, int H, int W,
                                void* workspace, size_t workspace_bytes);
