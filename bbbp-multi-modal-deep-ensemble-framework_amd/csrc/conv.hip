@@ -507,27 +507,43 @@ __global__ __launch_bounds__(512) void conv_wgrad32_kernel(WgradParams p) {
 
 // dW[cob*64+co][cib*32+ci][tap] = sum_g slab[pair][g][co][tap*32+ci]; db[cob*64+co] = sum_g bslab[pair(cib=0)][g][co]
 // grid: (ceil((64*288 + 64) / 64), pairs).  Fixed summation order.
-__global__ __launch_bounds__(256) void conv_wgrad32_reduce_kernel(const float* slab, const float* bslab, float* dw,
+// sum of slab[g * stride] for g in [g0, g1), 8 independent loads in flight, added in slab order
+__device__ __forceinline__ float slab_sum(const float* slab, long stride, int g0, int g1) {
+    float s = 0.f;
+    int g = g0;
+    for (; g + 8 <= g1; g += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = slab[(long)(g + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; g < g1; ++g) s += slab[(long)g * stride];
+    return s;
+}
+
+__global__ __launch_bounds__(1024) void conv_wgrad32_reduce_kernel(const float* slab, const float* bslab, float* dw,
                                                                  float* db, int groups, int cin_total, int cout_total) {
-    __shared__ float part[256];
+    // 16 thread groups each sum a contiguous range of slabs (few, independent loads per thread: the old 4-group version
+    // was a chain of 64 dependent-latency loads and took 19 us for 19 MB), then one group adds the 16 partials in order
+    __shared__ float part[16][64];
     constexpr int CO = 64, total = CO * 288;
     const int pair = blockIdx.y, ncib = cin_total / 32, cob = pair / ncib, cib = pair % ncib;
     const int nl = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + nl;          // [0, total) weights, [total, total + CO) biases
     float s = 0.f;
-    int per = (groups + 3) / 4;
-    int g0 = grp * per, g1 = min(groups, g0 + per);
+    int per = (groups + 15) / 16;
+    int g0 = min(groups, grp * per), g1 = min(groups, g0 + per);
     const float* sl = slab + (long)pair * groups * total;
     const float* bs = bslab + (long)pair * groups * CO;
-    if (n < total) {
-        for (int g = g0; g < g1; ++g) s += sl[(long)g * total + n];
-    } else if (n < total + CO) {
-        for (int g = g0; g < g1; ++g) s += bs[(long)g * CO + (n - total)];
-    }
-    part[threadIdx.x] = s;
+    if (n < total) s = slab_sum(sl + n, total, g0, g1);
+    else if (n < total + CO) s = slab_sum(bs + (n - total), CO, g0, g1);
+    part[grp][nl] = s;
     __syncthreads();
     if (grp == 0 && n < total + CO) {
-        float v = part[nl] + part[64 + nl] + part[128 + nl] + part[192 + nl];
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += part[i][nl];
         if (n < total) {
             int co = n / 288, rem = n % 288, tap = rem / 32, ci = rem % 32;
             dw[((long)(cob * CO + co) * cin_total + cib * 32 + ci) * 9 + tap] = v;
@@ -688,24 +704,24 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradParams p) {
 
 // dW[cob*32+co][27] = sum_g slab[cob][g][co][j], j = ci*9 + tap; db[cob*32+co] = sum_g bslab[cob][g][co].
 // grid (33, cout/32): a block owns 32 outputs; its 8 thread groups each sum a fixed eighth of the slabs.
-__global__ __launch_bounds__(256) void conv_wgrad3_reduce_kernel(const float* slab, const float* bslab, float* dw,
-                                                                float* db, int groups) {
-    __shared__ float part[8][32];
+__global__ __launch_bounds__(1024) void conv_wgrad3_reduce_kernel(const float* slab, const float* bslab, float* dw,
+                                                                 float* db, int groups) {
+    __shared__ float part[32][32];
     const int cob = blockIdx.y;
     const float* sl = slab + (long)cob * groups * 1024;
     const float* bs = bslab + (long)cob * groups * 32;
     const int nl = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int n = blockIdx.x * 32 + nl;          // 0..1023 weights (32 blocks), 1024..1055 biases (block 32)
-    const int per = (groups + 7) / 8, g0 = grp * per, g1 = min(groups, g0 + per);
+    const int per = (groups + 31) / 32, g0 = min(groups, grp * per), g1 = min(groups, g0 + per);
     float s = 0.f;
-    if (n < 1024) for (int g = g0; g < g1; ++g) s += sl[(long)g * 1024 + n];
-    else for (int g = g0; g < g1; ++g) s += bs[(long)g * 32 + (n - 1024)];
+    if (n < 1024) s = slab_sum(sl + n, 1024, g0, g1);
+    else s = slab_sum(bs + (n - 1024), 32, g0, g1);
     part[grp][nl] = s;
     __syncthreads();
     if (grp == 0) {
         float v = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v += part[i][nl];
+        for (int i = 0; i < 32; ++i) v += part[i][nl];
         if (n < 1024) { if ((n & 31) < 27) dw[(cob * 32 + (n >> 5)) * 27 + (n & 31)] = v; }
         else db[cob * 32 + (n - 1024)] = v;
     }
@@ -865,7 +881,7 @@ extern "C" int bbbp_conv3x3_relu_pool_bwd_weight(void* stream, const float* x, c
         if (rc) return rc;
         hipLaunchKernelGGL((conv_wgrad3_kernel<128>), dim3(grid), dim3(512), lds3, st, p);
         BBBP_CHECK_LAUNCH();
-        hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3(33, ncob), dim3(256), 0, st, slab, p.bslab, dw, db, groups);
+        hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3(33, ncob), dim3(1024), 0, st, slab, p.bslab, dw, db, groups);
         BBBP_CHECK_LAUNCH();
     } else {
         const int pairs = (cin / 32) * (cout / 64);
@@ -879,7 +895,7 @@ extern "C" int bbbp_conv3x3_relu_pool_bwd_weight(void* stream, const float* x, c
         int rc = cin == 32 ? launch_wgrad32<64, 32, 64>(p, grid, st)
                : cin == 64 ? launch_wgrad32<64, 64, 128>(p, grid, st) : launch_wgrad32<32, 128, 256>(p, grid, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(conv_wgrad32_reduce_kernel, dim3(cdiv(64 * 289, 64), pairs), dim3(256), 0, st, slab, p.bslab, dw, db,
+        hipLaunchKernelGGL(conv_wgrad32_reduce_kernel, dim3(cdiv(64 * 289, 64), pairs), dim3(1024), 0, st, slab, p.bslab, dw, db,
                            groups, cin, cout);
         BBBP_CHECK_LAUNCH();
     }

@@ -261,8 +261,17 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
     float* C = p.C + (long)batch * p.sC;
     const float* R = p.R ? p.R + (long)batch * p.sR : nullptr;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < mn; idx += (long)gridDim.x * 256) {
+        // 8 independent loads in flight, summed in slab order (the order, hence the result, does not change)
         float s = 0.f;
-        for (int k = 0; k < p.splits; ++k) s += S[(long)k * mn + idx];
+        int k = 0;
+        for (; k + 8 <= p.splits; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = S[(long)(k + u) * mn + idx];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < p.splits; ++k) s += S[(long)k * mn + idx];
         int m = (int)(idx / p.N), n = (int)(idx % p.N);
         float v = apply_act(p.alpha * s + (p.bias ? p.bias[n] : 0.f), p.act);
         if (p.gate) v *= p.gate[(long)batch * p.sG + (long)m * p.ldg + n] > 0.f ? p.gate_scale : 0.f;
