@@ -516,7 +516,17 @@ DirectPlan direct_plan(int M, int N, int K, int batch) {
     d.ks = nch <= 12 ? 1 : (cdiv(nch, 8) < max_ks ? cdiv(nch, 8) : max_ks);
     if (d.ks == 3) d.ks = 4;
     const long wt = (long)cdiv(M, 16) * cdiv(N, 16) * batch;
-    d.t = (wt * d.ks <= 2048) ? 1 : 2;
+    // 32x32 wave tiles (t = 2) need ~100 VGPRs: beside conv_wgrad32 (2 x 224 VGPRs per SIMD) such a wave cannot be
+    // placed until the conv kernel ends -- rocprofv3 showed the dhff GEMM of every layer waiting up to 0.65 ms.  The
+    // 16x16 variant fits the 64 VGPRs that are left, so it serves everything up to 4096 wave tiles (all of B = 512,
+    // F = 167: whole step 3.81 -> 3.75 ms); larger outputs (B = 4096 screening) take 32x32 tiles for the operand reuse.
+    static const int max_t = [] { const char* e = getenv("BBBP_GEMM_DIRECT_T"); return e ? atoi(e) : 2; }();
+    d.t = (wt * d.ks <= 4096 || max_t < 2) ? 1 : 2;
+    // many heads with a tiny head dimension (F = 2048: 256 heads of 8) are hundreds of thousands of nearly empty wave
+    // tiles: those stay on the LDS-tiled kernel
+    const long waves = (long)cdiv(M, 16 * d.t) * cdiv(N, 16 * d.t) * batch * d.ks;
+    const int mind = M < N ? (M < K ? M : K) : (N < K ? N : K);
+    if (waves > 16384 || (batch >= 8 && mind < 16)) d.use = false;
     if (d.ks >= 4) { d.wsm = 1; d.wsn = 1; }
     else if (d.ks >= 2) { d.wsm = 2; d.wsn = 1; }
     else { d.wsm = 2; d.wsn = 2; }

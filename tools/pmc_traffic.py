@@ -1,0 +1,49 @@
+"""HBM traffic per launch of the conv kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
+
+usage: pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv OUT.json
+Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters
+are in KiB; on gfx950 FETCH_SIZE counts 64-byte units of the 128-byte wide reads as one, so fetched bytes = raw x 1024 x 2.
+"""
+import collections
+import csv
+import json
+import sys
+
+KERNELS = {
+    "conv2_fwd": "conv3x3_kernel<32, 64, 64, 0>",
+    "conv2_dgrad": "conv3x3_kernel<64, 32, 64, 1>",
+    "conv2_wgrad": "conv_wgrad32_kernel<64, 64, 32, 64>",
+    "conv1_fwd": "conv3x3_kernel<3, 32, 128, 0>",
+    "conv1_wgrad": "conv_wgrad3_kernel<128>",
+}
+
+
+def mean_counter(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        for key, pat in KERNELS.items():
+            if pat in r["Kernel_Name"]:
+                acc[key].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items() if v}
+
+
+def main():
+    fetch = mean_counter(sys.argv[1], "FETCH_SIZE")
+    write = mean_counter(sys.argv[2], "WRITE_SIZE")
+    out = {"_detail": {}}
+    for k in KERNELS:
+        if k in fetch and k in write:
+            fb, wb = fetch[k] * 1024 * 2, write[k] * 1024
+            out[k] = fb + wb
+            out["_detail"][k] = dict(fetch_bytes_corrected=fb, write_bytes=wb, hbm_bytes=fb + wb, raw_FETCH_SIZE_KiB=fetch[k],
+                                     raw_WRITE_SIZE_KiB=write[k])
+    out["_note"] = ("per launch, B=512; FETCH_SIZE KiB x1024 x2 (gfx950 wide-read correction, MI355X_MICROARCH.md HBM), "
+                    "WRITE_SIZE KiB x1024; separate --pmc passes")
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print({k: round(v / 1e6, 1) for k, v in out.items() if not k.startswith("_")}, "MB per launch")
+
+
+if __name__ == "__main__":
+    main()
