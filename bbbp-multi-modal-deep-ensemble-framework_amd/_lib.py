@@ -43,6 +43,8 @@ _SIGNATURES = {
     "bbbp_gemm_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, _FP, c_int, _FP, c_int, _FP, c_int,
                               _FP, _FP, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_void_p, c_size_t]),
     "bbbp_gemm_f32_grouped": (c_int, [c_void_p, POINTER(GemmDesc), c_int, c_void_p, c_size_t]),
+    "bbbp_set_graphs": (c_int, [c_int]),
+    "bbbp_graph_stats": (c_int, [POINTER(c_long), POINTER(c_long)]),
     "bbbp_conv_last_clock": (c_int, [POINTER(c_uint64), POINTER(c_uint64)]),
     "bbbp_conv3x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "bbbp_conv3x3_relu_pool_fwd": (c_int, [c_void_p, _FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int,
@@ -73,6 +75,7 @@ _SIGNATURES = {
     "bbbp_set_partition": (c_int, [c_int, c_size_t]),
     "bbbp_set_overlap": (c_int, [c_int]),
     "bbbp_profile_enable": (c_int, [c_int]),
+    "bbbp_profile_select": (c_int, [ctypes.c_uint]),
     "bbbp_profile_num_sections": (c_int, []),
     "bbbp_profile_section_name": (c_char_p, [c_int]),
     "bbbp_profile_collect": (c_int, [POINTER(c_float), POINTER(c_int)]),

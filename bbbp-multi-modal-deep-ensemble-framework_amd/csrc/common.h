@@ -72,6 +72,13 @@ __device__ __forceinline__ uint4 philox4(uint64_t seed, uint64_t ctr) {
     }
     return make_uint4(c0, c1, c2, c3);
 }
+// The engine keeps the per-call dropout seed in DEVICE memory (a slot of the forward workspace, written by a one-thread
+// kernel) so that the enqueued work does not depend on it and can be replayed as a HIP graph; kernels then receive the
+// slot's address in `base` and a per-site salt in `seed`.  The op-level C entry points pass base = nullptr.
+extern const unsigned long long* g_bbbp_seed_base;
+__device__ __forceinline__ uint64_t effective_seed(uint64_t seed, const unsigned long long* base) {
+    return base ? (uint64_t)(*base) * 0x9E3779B97F4A7C15ull + seed : seed;
+}
 // keep-scale for element `idx` of dropout stream `seed`: 0 or 1/(1-p)
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
     uint4 r = philox4(seed, idx >> 2);

@@ -62,6 +62,7 @@ struct Plan {
     LayerOff layer[32];
     LayerGrad lgrad[32];
     size_t scratch3, scratch3_bytes;
+    size_t seed_slot;      // the call's dropout seed, in device memory (common.h: effective_seed)
     size_t pool1, mask1, pool2, mask2;
     size_t combined, hid, attn, fused, h, hb, bn_mean, bn_rstd, h2, h3;
     // temporaries
@@ -83,6 +84,7 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     p->drop = d->training && d->dropout_p > 0.f;
     const size_t B = p->B, F = p->F, NH = p->NH, DFF = p->DFF;
     Bump b;
+    p->seed_slot = b.take(256);
     for (int l = 0; l < p->L; ++l) {
         LayerOff& o = p->layer[l];
         o.qkv = b.f(B * 3 * F); o.prob = b.f(NH * B * B); o.ctx = b.f(B * F);
@@ -210,6 +212,7 @@ const char* const kSectionNames[SEC_COUNT] = {"conv1_fwd", "conv2_fwd", "imgfc_f
 constexpr int PROF_MAX = 4096;
 struct ProfState {
     bool on = false;
+    unsigned mask = ~0u;          // sections that record events (bbbp_profile_select)
     int n = 0;
     int sec[PROF_MAX];
     hipEvent_t a[PROF_MAX], b[PROF_MAX];
@@ -219,7 +222,7 @@ struct ProfState {
 struct Section {
     hipStream_t st; int idx;
     Section(hipStream_t s, int sec) : st(s), idx(-1) {
-        if (!g_prof.on || g_prof.n >= PROF_MAX) return;
+        if (!g_prof.on || !((g_prof.mask >> sec) & 1u) || g_prof.n >= PROF_MAX) return;
         idx = g_prof.n++;
         if (idx >= g_prof.created) {
             if (hipEventCreate(&g_prof.a[idx]) != hipSuccess || hipEventCreate(&g_prof.b[idx]) != hipSuccess) { idx = -1; --g_prof.n; return; }
@@ -259,7 +262,73 @@ bbbp_gemm_desc gemm_desc(int transA, int transB, int M, int N, int K, float alph
     return g;
 }
 
-uint64_t site_seed(uint64_t seed, int layer, int site) { return seed * 0x9E3779B97F4A7C15ull + (uint64_t)(layer * 8 + site + 1); }
+// per-site salt; the kernels mix it with the call's seed read from device memory (effective_seed)
+uint64_t site_seed(uint64_t /*seed: lives in the workspace*/, int layer, int site) { return (uint64_t)(layer * 8 + site + 1); }
+
+__global__ void set_seed_kernel(unsigned long long* slot, unsigned long long seed) { *slot = seed; }
+
+struct SeedScope {
+    explicit SeedScope(const unsigned long long* slot) { g_bbbp_seed_base = slot; }
+    ~SeedScope() { g_bbbp_seed_base = nullptr; }
+};
+
+// ---- HIP-graph replay of the two whole-model calls ---------------------------------------------------------------
+// A call enqueues 85 (forward) or 175 (backward) launches plus ~100 event operations: ~0.5 / 0.9 ms of host time.  For
+// fixed arguments the enqueued work is identical from step to step (the dropout seed is read from device memory), so
+// the second time a call arrives with the same arguments its enqueue is captured (all three streams: the fork/join
+// events pull the side streams into the capture) and from then on replayed with one hipGraphLaunch.  Anything that
+// changes an argument (another batch tensor, re-flattened parameters, a different batch size) is a different key;
+// the cache holds a few entries, least recently used first out.  Opt-in (see graphs_mode); section profiling bypasses it.
+struct GraphKey {
+    int kind;                      // 0 forward, 1 backward
+    bbbp_mixed_desc d;             // seed zeroed
+    const void* ptr[6];
+    uint64_t phash;                // hash of the parameter / gradient / BN pointer arrays
+    int overlap;
+    hipStream_t st;
+    bool operator==(const GraphKey& o) const {
+        return kind == o.kind && d.batch == o.d.batch && d.fingerprint_size == o.d.fingerprint_size && d.nhead == o.d.nhead &&
+               d.num_layers == o.d.num_layers && d.dim_feedforward == o.d.dim_feedforward && d.training == o.d.training &&
+               d.dropout_p == o.d.dropout_p && d.need_input_grad == o.d.need_input_grad && phash == o.phash &&
+               overlap == o.overlap && st == o.st && ptr[0] == o.ptr[0] && ptr[1] == o.ptr[1] && ptr[2] == o.ptr[2] &&
+               ptr[3] == o.ptr[3] && ptr[4] == o.ptr[4] && ptr[5] == o.ptr[5];
+    }
+};
+struct GraphEntry { GraphKey key; hipGraphExec_t exec = nullptr; unsigned long long stamp = 0; bool seen_only = true; };
+constexpr int GRAPH_SLOTS = 12;
+GraphEntry g_graphs[GRAPH_SLOTS];
+unsigned long long g_graph_clock = 0;
+long g_graph_replays = 0, g_graph_captures = 0;
+
+// Default OFF: on ROCm 7.2 replaying the captured three-stream graph is SLOWER on the GPU than the hand-scheduled
+// streams (whole step, B = 512: 3.67 ms eager, 4.50 ms replayed; the host loop is not shorter either, hipGraphLaunch of
+// a 260-node graph costs about what the eager enqueue does).  Kept as an opt-in (BBBP_GRAPHS=1 / bbbp_set_graphs) with a
+// bit-exactness test, for runtimes where graph launch is cheaper.
+int g_graphs_mode = -1;
+int graphs_mode() {
+    if (g_graphs_mode < 0) { const char* e = getenv("BBBP_GRAPHS"); g_graphs_mode = e ? atoi(e) : 0; }
+    return g_graphs_mode;
+}
+uint64_t hash_ptrs(const void* const* a, int n, uint64_t h = 1469598103934665603ull) {
+    for (int i = 0; i < n; ++i) { h ^= (uint64_t)reinterpret_cast<uintptr_t>(a[i]); h *= 1099511628211ull; }
+    return h;
+}
+// 0: run eagerly; 1: capture now into *slot; 2: replay *slot
+int graph_lookup(const GraphKey& k, GraphEntry** slot) {
+    if (!graphs_mode() || g_prof.on) return 0;
+    ++g_graph_clock;
+    GraphEntry* lru = &g_graphs[0];
+    for (auto& e : g_graphs) {
+        if (e.stamp && e.key == k) {
+            e.stamp = g_graph_clock; *slot = &e;
+            return e.seen_only ? 1 : 2;
+        }
+        if (e.stamp < lru->stamp) lru = &e;
+    }
+    if (lru->exec) { (void)hipGraphExecDestroy(lru->exec); lru->exec = nullptr; }
+    lru->key = k; lru->stamp = g_graph_clock; lru->seen_only = true;       // first sighting: eager
+    return 0;
+}
 
 }  // namespace
 
@@ -268,6 +337,7 @@ extern "C" int bbbp_set_overlap(int on) { int old = overlap_enabled() ? 1 : 0; g
 
 // Profiling: enable, run steps, synchronise the stream, then collect {sum of ms, launches} per section.
 extern "C" int bbbp_profile_enable(int on) { g_prof.on = on != 0; g_prof.n = 0; return BBBP_OK; }
+extern "C" int bbbp_profile_select(unsigned section_mask) { g_prof.mask = section_mask ? section_mask : ~0u; return BBBP_OK; }
 extern "C" int bbbp_profile_num_sections(void) { return SEC_COUNT; }
 extern "C" const char* bbbp_profile_section_name(int i) { return (i >= 0 && i < SEC_COUNT) ? kSectionNames[i] : ""; }
 extern "C" int bbbp_profile_collect(float* ms_sum, int* count) {
@@ -293,11 +363,12 @@ extern "C" size_t bbbp_mixed_workspace_bytes(const bbbp_mixed_desc* d) {
     return p.total;
 }
 
-extern "C" int bbbp_mixed_forward(void* stream, const bbbp_mixed_desc* d, const float* const* P, float* const* bn_running,
-                                  const float* fingerprint, const float* image, float* out, void* workspace,
-                                  size_t workspace_bytes) {
+static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* const* P, float* const* bn_running,
+                           const float* fingerprint, const float* image, float* out, void* workspace,
+                           size_t workspace_bytes) {
     Plan plan;
     TRY(make_plan(d, &plan));
+    SeedScope seed_scope(reinterpret_cast<const unsigned long long*>(static_cast<char*>(workspace) + plan.seed_slot));
     BBBP_CHECK_ARG(P && fingerprint && image && out && workspace && bn_running, "mixed_forward: null pointer");
     if (workspace_bytes < plan.total) {
         bbbp_set_error("mixed_forward: workspace %zu < %zu bytes", workspace_bytes, plan.total);
@@ -398,11 +469,12 @@ extern "C" int bbbp_mixed_forward(void* stream, const bbbp_mixed_desc* d, const 
     return BBBP_OK;
 }
 
-extern "C" int bbbp_mixed_backward(void* stream, const bbbp_mixed_desc* d, const float* const* P, float* const* G,
-                                   const float* fingerprint, const float* image, const float* dout, void* workspace,
-                                   size_t workspace_bytes) {
+static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* const* P, float* const* G,
+                            const float* fingerprint, const float* image, const float* dout, void* workspace,
+                            size_t workspace_bytes) {
     Plan plan;
     TRY(make_plan(d, &plan));
+    SeedScope seed_scope(reinterpret_cast<const unsigned long long*>(static_cast<char*>(workspace) + plan.seed_slot));
     BBBP_CHECK_ARG(P && G && fingerprint && image && dout && workspace, "mixed_backward: null pointer");
     if (workspace_bytes < plan.total) {
         bbbp_set_error("mixed_backward: workspace %zu < %zu bytes", workspace_bytes, plan.total);
@@ -572,4 +644,107 @@ extern "C" int bbbp_mixed_backward(void* stream, const bbbp_mixed_desc* d, const
         BBBP_CHECK_HIP(hipStreamWaitEvent(c.st, ss->join2, 0));
     }
     return BBBP_OK;
+}
+
+namespace {
+
+hipStream_t capture_stream() {
+    static hipStream_t cs = nullptr;       // captures never run on the caller's stream: the legacy default stream cannot be captured
+    if (!cs && hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) cs = nullptr;
+    return cs;
+}
+
+// Run `enqueue(stream)` eagerly, or capture it on the library's capture stream and replay the graph on `st`.
+template <typename F>
+int run_or_replay(const GraphKey& key, hipStream_t st, F&& enqueue) {
+    GraphEntry* slot = nullptr;
+    const int mode = graph_lookup(key, &slot);
+    if (mode == 2) {
+        BBBP_CHECK_HIP(hipGraphLaunch(slot->exec, st));
+        ++g_graph_replays;
+        return BBBP_OK;
+    }
+    hipStream_t cs = mode == 1 ? capture_stream() : nullptr;
+    if (cs && hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed) == hipSuccess) {
+        const int rc = enqueue(cs);
+        hipGraph_t graph = nullptr;
+        const hipError_t e = hipStreamEndCapture(cs, &graph);
+        bool ok = rc == BBBP_OK && e == hipSuccess && graph != nullptr;
+        if (ok) ok = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (ok) {
+            slot->seen_only = false;
+            ++g_graph_captures;
+            BBBP_CHECK_HIP(hipGraphLaunch(slot->exec, st));
+            return BBBP_OK;
+        }
+        (void)hipGetLastError();
+        slot->exec = nullptr; slot->stamp = 0;       // do not try this key again soon; run it eagerly below
+        if (rc) return rc;
+    }
+    return enqueue(st);
+}
+
+GraphKey make_key(int kind, const bbbp_mixed_desc* d, const void* a, const void* b, const void* c, const void* ws, uint64_t phash) {
+    GraphKey k{};
+    k.kind = kind; k.d = *d; k.d.seed = 0;
+    k.ptr[0] = a; k.ptr[1] = b; k.ptr[2] = c; k.ptr[3] = ws;
+    k.phash = phash; k.overlap = overlap_enabled() ? 1 : 0; k.st = nullptr;
+    return k;
+}
+
+}  // namespace
+
+extern "C" int bbbp_set_graphs(int on) { const int old = graphs_mode(); g_graphs_mode = on ? 1 : 0; return old; }
+
+extern "C" int bbbp_graph_stats(long* captures, long* replays) {
+    if (captures) *captures = g_graph_captures;
+    if (replays) *replays = g_graph_replays;
+    return BBBP_OK;
+}
+
+extern "C" int bbbp_mixed_forward(void* stream, const bbbp_mixed_desc* d, const float* const* P, float* const* bn_running,
+                                  const float* fingerprint, const float* image, float* out, void* workspace,
+                                  size_t workspace_bytes) {
+    Plan plan;
+    TRY(make_plan(d, &plan));
+    BBBP_CHECK_ARG(P && fingerprint && image && out && workspace && bn_running, "mixed_forward: null pointer");
+    if (workspace_bytes < plan.total) {
+        bbbp_set_error("mixed_forward: workspace %zu < %zu bytes", workspace_bytes, plan.total);
+        return BBBP_ERR_WORKSPACE;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // the call's dropout seed goes to device memory first (never part of a graph: it changes every call)
+    if (plan.drop) {
+        hipLaunchKernelGGL(set_seed_kernel, dim3(1), dim3(1), 0, st,
+                           reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + plan.seed_slot), (unsigned long long)d->seed);
+        BBBP_CHECK_LAUNCH();
+    }
+    const int np = PIdx(d->num_layers).count();
+    uint64_t h = hash_ptrs(reinterpret_cast<const void* const*>(P), np);
+    h = hash_ptrs(reinterpret_cast<const void* const*>(bn_running), 2, h);
+    const GraphKey key = make_key(0, d, fingerprint, image, out, workspace, h);
+    return run_or_replay(key, st, [&](hipStream_t s) {
+        return forward_enqueue(s, d, P, bn_running, fingerprint, image, out, workspace, workspace_bytes);
+    });
+}
+
+extern "C" int bbbp_mixed_backward(void* stream, const bbbp_mixed_desc* d, const float* const* P, float* const* G,
+                                   const float* fingerprint, const float* image, const float* dout, void* workspace,
+                                   size_t workspace_bytes) {
+    Plan plan;
+    TRY(make_plan(d, &plan));
+    BBBP_CHECK_ARG(P && G && fingerprint && image && dout && workspace, "mixed_backward: null pointer");
+    if (workspace_bytes < plan.total) {
+        bbbp_set_error("mixed_backward: workspace %zu < %zu bytes", workspace_bytes, plan.total);
+        return BBBP_ERR_WORKSPACE;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int np = PIdx(d->num_layers).count();
+    uint64_t h = hash_ptrs(reinterpret_cast<const void* const*>(P), np);
+    h = hash_ptrs(reinterpret_cast<const void* const*>(G), np, h);
+    const GraphKey key = make_key(1, d, fingerprint, image, dout, workspace, h);
+    return run_or_replay(key, st, [&](hipStream_t s) {
+        return backward_enqueue(s, d, P, G, fingerprint, image, dout, workspace, workspace_bytes);
+    });
 }

@@ -27,7 +27,8 @@ __device__ __forceinline__ float wave_max(float v) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(float* x, const float* r, float* y, const float* gamma,
                                                            const float* beta, float* mean_out, float* rstd_out,
-                                                           int rows, int cols, float eps, float p, uint64_t seed) {
+                                                           int rows, int cols, float eps, float p, uint64_t seed_in, const unsigned long long* seed_base) {
+    const uint64_t seed = effective_seed(seed_in, seed_base);
     BBBP_HIGH_PRIO();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -56,7 +57,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(float* x, const floa
 // residual input; dx (optional, when dropout was applied to x) = dz * keep-scale.
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dy, const float* z, const float* gamma,
                                                            const float* mean, const float* rstd, float* dz, float* dx,
-                                                           int rows, int cols, float p, uint64_t seed) {
+                                                           int rows, int cols, float p, uint64_t seed_in, const unsigned long long* seed_base) {
+    const uint64_t seed = effective_seed(seed_in, seed_base);
     BBBP_HIGH_PRIO();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -113,7 +115,8 @@ __global__ __launch_bounds__(512) void layernorm_param_grad_kernel(const float* 
 // ---------------------------------------------------------------------------------------------
 // softmax over the last dim, one wave per row, in place; optional dropout copy pd = dropout(p).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void softmax_fwd_kernel(float* x, float* pd, long rows, int cols, float p, uint64_t seed) {
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(float* x, float* pd, long rows, int cols, float p, uint64_t seed_in, const unsigned long long* seed_base) {
+    const uint64_t seed = effective_seed(seed_in, seed_base);
     BBBP_HIGH_PRIO();
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -134,7 +137,8 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(float* x, float* pd, l
 }
 
 // ds = P * (dP - sum(dP * P)), dP = dpd * keep-scale.  In place over dpd.
-__global__ __launch_bounds__(256) void softmax_bwd_kernel(float* dpd, const float* prob, long rows, int cols, float p, uint64_t seed) {
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(float* dpd, const float* prob, long rows, int cols, float p, uint64_t seed_in, const unsigned long long* seed_base) {
+    const uint64_t seed = effective_seed(seed_in, seed_base);
     BBBP_HIGH_PRIO();
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -153,7 +157,8 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(float* dpd, const floa
 }
 
 // y = x * keep-scale (forward and backward of nn.Dropout share this kernel and the seed)
-__global__ __launch_bounds__(256) void dropout_kernel(const float* x, float* y, long n, float p, uint64_t seed) {
+__global__ __launch_bounds__(256) void dropout_kernel(const float* x, float* y, long n, float p, uint64_t seed_in, const unsigned long long* seed_base) {
+    const uint64_t seed = effective_seed(seed_in, seed_base);
     BBBP_HIGH_PRIO();
     const float inv_keep = 1.f / (1.f - p);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
@@ -438,7 +443,7 @@ extern "C" int bbbp_layernorm_fwd(void* stream, float* x_inout_z, const float* r
     BBBP_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "layernorm: bad dropout %f", dropout_p);
     if (rows == 0) return BBBP_OK;
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), g_bbbp_small_lds_pad, ST, x_inout_z, residual, y, gamma, beta,
-                       mean, rstd, rows, cols, eps, dropout_p, seed);
+                       mean, rstd, rows, cols, eps, dropout_p, seed, g_bbbp_seed_base);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }
@@ -451,7 +456,7 @@ extern "C" int bbbp_layernorm_bwd(void* stream, const float* dy, const float* z,
     // halves on different streams: the parameter gradients are off the critical dependency chain)
     if (rows > 0 && dz) {
         hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), g_bbbp_small_lds_pad, ST, dy, z, gamma, mean, rstd, dz, dx,
-                           rows, cols, dropout_p, seed);
+                           rows, cols, dropout_p, seed, g_bbbp_seed_base);
         BBBP_CHECK_LAUNCH();
     }
     if (dgamma) {
@@ -467,7 +472,7 @@ extern "C" int bbbp_softmax_fwd(void* stream, float* x_inout, float* dropped_out
     BBBP_CHECK_ARG(rows >= 0 && cols > 0, "softmax: bad shape");
     if (rows == 0) return BBBP_OK;
     hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), g_bbbp_small_lds_pad, ST, x_inout,
-                       dropout_p > 0.f ? dropped_out : nullptr, rows, cols, dropout_p, seed);
+                       dropout_p > 0.f ? dropped_out : nullptr, rows, cols, dropout_p, seed, g_bbbp_seed_base);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }
@@ -477,7 +482,7 @@ extern "C" int bbbp_softmax_bwd(void* stream, float* dprob_inout, const float* p
     BBBP_CHECK_ARG(rows >= 0 && cols > 0, "softmax bwd: bad shape");
     if (rows == 0) return BBBP_OK;
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), g_bbbp_small_lds_pad, ST, dprob_inout, prob, rows, cols,
-                       dropout_p, seed);
+                       dropout_p, seed, g_bbbp_seed_base);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }
@@ -489,7 +494,7 @@ extern "C" int bbbp_dropout(void* stream, const float* x, float* y, long n, floa
         if (x != y) BBBP_CHECK_HIP(hipMemcpyAsync(y, x, n * sizeof(float), hipMemcpyDeviceToDevice, ST));
         return BBBP_OK;
     }
-    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), g_bbbp_small_lds_pad, ST, x, y, n, p, seed);
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), g_bbbp_small_lds_pad, ST, x, y, n, p, seed, g_bbbp_seed_base);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }

@@ -14,6 +14,7 @@ autograd node per model call (``bbbp_mixed_forward`` / ``bbbp_mixed_backward``).
 from __future__ import annotations
 
 import ctypes
+import weakref
 from typing import List
 
 import torch
@@ -96,6 +97,20 @@ class MultiHeadAttentionFusion(nn.Module):
         return attention_fusion(self, x1, x2)
 
 
+def _cached_ptrs(model, attr, tensors):
+    """ctypes array of the tensors' device pointers, rebuilt only when the storage moved (e.g. after .to())."""
+    key = (tensors[0].data_ptr(), tensors[-1].data_ptr(), len(tensors))
+    cache = _PTR_CACHE.setdefault(model, {})          # kept off the module so that pickle.dump(model) still works
+    hit = cache.get(attr)
+    if hit is None or hit[0] != key:
+        hit = (key, _lib.ptr_array([t.data_ptr() for t in tensors]))
+        cache[attr] = hit
+    return hit[1]
+
+
+_PTR_CACHE = weakref.WeakKeyDictionary()
+
+
 class _MixedFn(torch.autograd.Function):
     """One autograd node for the whole model: forward and backward are single C-ABI calls."""
 
@@ -109,12 +124,12 @@ class _MixedFn(torch.autograd.Function):
             _lib.check(1, "bbbp_mixed_workspace_bytes")
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=fingerprint.device)
         out = torch.empty((B, 1), dtype=torch.float32, device=fingerprint.device)
-        pp = _lib.ptr_array([p.data_ptr() for p in params])
+        pp = _cached_ptrs(model, "_pp", params)
         bn = model.fc[2]
-        bnp = _lib.ptr_array([bn.running_mean.data_ptr(), bn.running_var.data_ptr()])
+        bnp = _cached_ptrs(model, "_bnp", (bn.running_mean, bn.running_var))
         _lib.check(L.bbbp_mixed_forward(ops._stream(), ctypes.byref(desc), pp, bnp, fingerprint.data_ptr(), image.data_ptr(),
                                         out.data_ptr(), ws.data_ptr(), ws_bytes), "bbbp_mixed_forward")
-        ctx.desc, ctx.ws, ctx.ws_bytes = desc, ws, ws_bytes
+        ctx.desc, ctx.ws, ctx.ws_bytes, ctx.pp = desc, ws, ws_bytes, pp
         ctx.save_for_backward(fingerprint, image, *params)
         return out
 
@@ -129,9 +144,11 @@ class _MixedFn(torch.autograd.Function):
         for p in params:
             grads.append(gflat[off:off + p.numel()].view(p.shape))
             off += p.numel()
-        pp = _lib.ptr_array([p.data_ptr() for p in params])
-        gp = _lib.ptr_array([g.data_ptr() for g in grads])
-        _lib.check(L.bbbp_mixed_backward(ops._stream(), ctypes.byref(ctx.desc), pp, gp, fingerprint.data_ptr(),
+        base, gp, off = gflat.data_ptr(), (ctypes.c_void_p * len(params))(), 0
+        for i, p in enumerate(params):
+            gp[i] = base + 4 * off
+            off += p.numel()
+        _lib.check(L.bbbp_mixed_backward(ops._stream(), ctypes.byref(ctx.desc), ctx.pp, gp, fingerprint.data_ptr(),
                                          image.data_ptr(), dout.data_ptr(), ctx.ws.data_ptr(), ctx.ws_bytes),
                    "bbbp_mixed_backward")
         return (None, None, None, *grads)

@@ -186,7 +186,13 @@ int bbbp_mixed_backward(void* stream, const bbbp_mixed_desc* d, const float* con
  * enable(1), run steps, synchronise the stream, collect(ms_sum[n], count[n]) with n = num_sections(). */
 int bbbp_set_partition(int reserved_cus, size_t small_lds_pad);   /* CU partition knob, see csrc/common.h */
 int bbbp_set_overlap(int on);   /* two/three-stream branch overlap inside bbbp_mixed_forward/backward (default on) */
+/* HIP-graph replay of bbbp_mixed_forward / bbbp_mixed_backward: the second call with identical arguments is captured,
+ * later ones are replayed with one hipGraphLaunch.  Opt-in (env BBBP_GRAPHS=1 or bbbp_set_graphs(1), which returns the
+ * previous setting): measured slower than the eager three-stream enqueue on ROCm 7.2.  Counters since load. */
+int bbbp_set_graphs(int on);
+int bbbp_graph_stats(long* captures, long* replays);
 int bbbp_profile_enable(int on);
+int bbbp_profile_select(unsigned section_mask);   /* bit i = section i records events; 0 = all (the default) */
 int bbbp_profile_num_sections(void);
 const char* bbbp_profile_section_name(int i);
 int bbbp_profile_collect(float* ms_sum, int* count);

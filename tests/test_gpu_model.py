@@ -79,7 +79,7 @@ def test_eval_mode_gradients(dev):
     fp, img, y = synth_inputs(1002, 2, 167, 49152)
     loss = torch.nn.MSELoss()(m(fp.to(dev), img.to(dev)).squeeze(), y.to(dev))
     loss.backward()
-    assert abs(float(loss) - float(g["evalgrad/B2/loss"])) <= 1e-4 * abs(float(g["evalgrad/B2/loss"]))
+    assert abs(float(loss.detach()) - float(g["evalgrad/B2/loss"])) <= 1e-4 * abs(float(g["evalgrad/B2/loss"]))
     for k, p in m.named_parameters():
         if not k.startswith(FUSION):
             check_summary(g, f"evalgrad/B2/{k}", p.grad, rtol=5e-4, atol_frac=grad_atol(k))
@@ -221,3 +221,45 @@ def test_screening_batch_1024_eval(dev):
     with torch.no_grad():
         want = oracle.mixed_input_forward(p, fp, img, training=False)
     assert_close(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol_frac=2e-5, what="B=1024 eval")
+
+
+def test_graph_replay_is_bit_identical_to_eager(dev):
+    """bbbp_mixed_forward/backward capture their enqueue into a HIP graph on the second call with identical arguments and
+    replay it afterwards (dropout seed read from device memory).  Replayed steps must equal eager steps bit for bit:
+    same seeds => same dropout masks, same kernels, same order."""
+    import ctypes
+    from bbbp_amd import _lib
+    from bbbp_amd.optim import AdamW
+    L = _lib.lib()
+    B, F, steps = 24, 167, 6
+    fp, img, y = synth_inputs(77, 2 * B, F, 49152)
+    fp, img, y = fp.to(dev), img.to(dev), y.to(dev)
+
+    def run(graphs):
+        old = L.bbbp_set_graphs(1 if graphs else 0)
+        m = build(F, 5, dev).train()
+        opt = AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+        losses = []
+        torch.manual_seed(123)                 # seeds of the dropout streams come from torch's CPU generator
+        for i in range(steps):
+            s = (i % 2) * B
+            loss = torch.nn.functional.mse_loss(m(fp[s:s + B], img[s:s + B]).squeeze(), y[s:s + B])
+            loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            losses.append(float(loss.detach()))
+        L.bbbp_set_graphs(old)
+        return losses, torch.cat([p.detach().flatten() for p in m.parameters()]).cpu()
+
+    cap0, rep0 = ctypes.c_long(0), ctypes.c_long(0)
+    L.bbbp_graph_stats(ctypes.byref(cap0), ctypes.byref(rep0))
+    loss_e, par_e = run(graphs=False)
+    cap1, rep1 = ctypes.c_long(0), ctypes.c_long(0)
+    L.bbbp_graph_stats(ctypes.byref(cap1), ctypes.byref(rep1))
+    assert rep1.value == rep0.value and cap1.value == cap0.value, "graphs off must not capture or replay"
+    loss_g, par_g = run(graphs=True)
+    cap2, rep2 = ctypes.c_long(0), ctypes.c_long(0)
+    L.bbbp_graph_stats(ctypes.byref(cap2), ctypes.byref(rep2))
+    assert loss_e == loss_g, (loss_e, loss_g)
+    assert torch.equal(par_e, par_g)
+    assert cap2.value > cap1.value and rep2.value > rep1.value, "no graph was captured/replayed: check the cache key"
