@@ -33,6 +33,17 @@ class GemmDesc(Structure):
                 ("strideA", c_long), ("strideB", c_long), ("strideC", c_long), ("strideR", c_long), ("strideG", c_long)]
 
 
+class MlpModel(Structure):
+    """bbbp_mlp_model (include/bbbp_hip.h)."""
+    _fields_ = [("n_layers", c_int), ("units", c_int * 5), ("activation", c_int), ("batch_size", c_int), ("n_train", c_int),
+                ("n_iter_no_change", c_int), ("max_iter", c_int),
+                ("lr_init", ctypes.c_double), ("alpha", ctypes.c_double), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double),
+                ("eps", ctypes.c_double), ("tol", ctypes.c_double),
+                ("params", c_void_p), ("adam_m", c_void_p), ("adam_v", c_void_p), ("grads", c_void_p),
+                ("act", c_void_p), ("delta", c_void_p), ("order", c_void_p), ("loss_curve", c_void_p),
+                ("t", c_long), ("best_loss", ctypes.c_double), ("no_improve", c_int), ("n_iter", c_int), ("done", c_int)]
+
+
 _FP = c_void_p          # device float*
 _PP = POINTER(c_void_p)  # host array of device pointers
 
@@ -44,6 +55,8 @@ _SIGNATURES = {
                               _FP, _FP, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_void_p, c_size_t]),
     "bbbp_gemm_f32_grouped": (c_int, [c_void_p, POINTER(GemmDesc), c_int, c_void_p, c_size_t]),
     "bbbp_set_graphs": (c_int, [c_int]),
+    "bbbp_mlp_train_epochs": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int]),
+    "bbbp_mlp_predict_proba": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "bbbp_graph_stats": (c_int, [POINTER(c_long), POINTER(c_long)]),
     "bbbp_conv_last_clock": (c_int, [POINTER(c_uint64), POINTER(c_uint64)]),
     "bbbp_conv3x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

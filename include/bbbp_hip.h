@@ -182,6 +182,34 @@ int bbbp_mixed_backward(void* stream, const bbbp_mixed_desc* d, const float* con
                         const float* fingerprint, const float* image, const float* dout, void* workspace,
                         size_t workspace_bytes);
 
+/* ---- batched trainer for scikit-learn style MLP classifiers (Models/model_opt_maccs.py:133,170-181: MLPClassifier under
+ * GridSearchCV).  One persistent work-group trains one model; float64, scikit-learn's
+ * arithmetic (binary log-loss + L2, Adam, training-loss stopping rule).  The array of models lives in DEVICE memory; the
+ * host fills it (including the device pointers), supplies `order` = the global row ids of each of the next `epochs`
+ * epochs in visiting order, launches, and reads back n_iter / done / loss_curve.  parameter layout: [W0|b0|W1|b1|...],
+ * W[l] is [units[l]][units[l+1]] row-major (scikit-learn's coefs_). */
+typedef struct bbbp_mlp_model {
+    int n_layers;                 /* weight layers: hidden layers + 1 (2 or 3 for the reference grid; at most 4) */
+    int units[5];                 /* units[0] = n_features ... units[n_layers] = 1 */
+    int activation;               /* hidden activation: 0 relu, 1 tanh */
+    int batch_size;
+    int n_train;                  /* rows visited per epoch */
+    int n_iter_no_change, max_iter;
+    double lr_init, alpha, beta1, beta2, eps, tol;
+    double* params; double* adam_m; double* adam_v; double* grads;
+    double* act; double* delta;   /* scratch: batch_size * (sum of units[1..n_layers]) each */
+    const int* order;             /* [epochs][n_train] */
+    double* loss_curve;           /* [max_iter] */
+    long t;                       /* Adam step count */
+    double best_loss;             /* +inf at start */
+    int no_improve, n_iter, done;
+} bbbp_mlp_model;
+int bbbp_mlp_train_epochs(void* stream, bbbp_mlp_model* models_dev, int n_models, const double* X, const double* y,
+                          int n_features, int epochs);
+/* out[i] = P(class 1 | X[i]) under models_dev[model]; hidden layers up to 256 units */
+int bbbp_mlp_predict_proba(void* stream, const bbbp_mlp_model* models_dev, int model, const double* X, int n, int n_features,
+                           int max_units, double* out);
+
 /* ---- optional per-section timing (HIP events on the launch stream; used by bench.py's roofline leg) ----
  * enable(1), run steps, synchronise the stream, collect(ms_sum[n], count[n]) with n = num_sections(). */
 int bbbp_set_partition(int reserved_cus, size_t small_lds_pad);   /* CU partition knob, see csrc/common.h */
