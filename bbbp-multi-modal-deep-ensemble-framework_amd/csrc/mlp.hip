@@ -19,10 +19,10 @@
 
 namespace {
 
-constexpr int NT = 256;
+constexpr int NT = 1024;      // 16 waves per model: the loops are latency-bound chains of f64 FMAs over L2-resident operands
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
-    // fixed-order tree over the 256 threads of the work-group
+    // fixed-order tree over the threads of the work-group
     red[threadIdx.x] = v;
     __syncthreads();
     for (int s = NT / 2; s > 0; s >>= 1) {

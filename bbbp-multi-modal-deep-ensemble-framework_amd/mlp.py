@@ -94,7 +94,6 @@ class GridMLPTrainer:
         return np.concatenate(parts)
 
     def fit(self, configs: Sequence[MLPConfig], epochs_per_launch: int = 8) -> List[FittedMLP]:
-        from sklearn.utils import shuffle as sk_shuffle
         L = _lib.lib()
         nm = len(configs)
         if nm == 0:
@@ -147,7 +146,11 @@ class GridMLPTrainer:
                 h = host[i]
                 chunk = np.empty((epochs_per_launch, len(h["rows"])), dtype=np.int32)
                 for e in range(epochs_per_launch):
-                    h["idx"] = sk_shuffle(h["idx"], random_state=h["rs"])
+                    # == sample_idx = sklearn.utils.shuffle(sample_idx, random_state=rs): resample() shuffles arange(n)
+                    # with the RandomState and indexes the array with it
+                    perm = np.arange(len(h["idx"]))
+                    h["rs"].shuffle(perm)
+                    h["idx"] = h["idx"][perm]
                     chunk[e] = h["rows"][h["idx"]]
                 h["t"]["order"].copy_(torch.from_numpy(chunk))
             if first:
