@@ -223,3 +223,29 @@ class MixedInputModel(nn.Module):
         if self.training:
             self.fc[2].num_batches_tracked += 1
         return out
+
+
+class _MSEFn(torch.autograd.Function):
+    """loss and d loss / d pred from ONE kernel (bbbp_mse); backward scales the stored gradient."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        loss, dpred = ops.mse(pred, target)
+        ctx.save_for_backward(dpred)
+        ctx.shape = pred.shape
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (dpred,) = ctx.saved_tensors
+        return (dpred * grad_out).view(ctx.shape), None
+
+
+class MSELoss(nn.Module):
+    """Drop-in for ``nn.MSELoss()`` (reduction 'mean'; ...20250113.py:173,189) for predictions / targets on the GPU: value
+    and gradient come from one fused kernel instead of seven elementwise/reduction launches.  The target gets no gradient."""
+
+    def forward(self, pred, target):
+        if pred.shape != target.shape:
+            raise RuntimeError(f"MSELoss: shapes differ: {tuple(pred.shape)} vs {tuple(target.shape)}")
+        return _MSEFn.apply(pred, target)

@@ -17,6 +17,8 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
+from .models import MSELoss
+
 from .optim import AdamW
 
 
@@ -55,7 +57,7 @@ def train_fold(model, train, test=None, *, epochs: int = 50, batch_size: int = 3
         raise RuntimeError("train_fold expects device-resident tensors")
     y = y.to(torch.float32)
     opt = optimizer if optimizer is not None else AdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
-    crit = torch.nn.MSELoss()
+    crit = MSELoss()                      # nn.MSELoss semantics, fused value + gradient kernel
     N = fp.shape[0]
     hist = {"train_loss": [], "val_loss": []}
     model.train()                                   # reference :179 -- once, outside the epoch loop

@@ -125,7 +125,7 @@ def main():
     torch.manual_seed(20250113)           # same initial weights on every rank
     model = bbbp_amd.MixedInputModel(F_DIM, 128).to(dev).train()
     opt = AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5)
-    crit = torch.nn.MSELoss()
+    crit = bbbp_amd.MSELoss()             # nn.MSELoss semantics, value + gradient in one kernel
     fp, img, y = synthetic_b3db(2 * BATCH, F_DIM, 20250113 + rank, dev)
     params = list(model.parameters())
 

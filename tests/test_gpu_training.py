@@ -74,3 +74,20 @@ def test_faithful_training_loop_matches_oracle(dev):
     assert np.max(np.abs(preds - ref_preds)) <= 5e-3 * max(1.0, np.max(np.abs(ref_preds)))
     assert len(hist["val_loss"]) == EPOCHS and all(np.isfinite(hist["val_loss"]))
     assert int(model.state_dict()["fc.2.num_batches_tracked"]) == 3     # BatchNorm saw train mode in epoch 1 only
+
+
+def test_fused_mse_loss_matches_torch(dev):
+    import bbbp_amd
+    torch.manual_seed(0)
+    for n in (1, 7, 512, 4099):
+        pred = torch.randn(n, device=dev, requires_grad=True)
+        ref_pred = pred.detach().clone().requires_grad_(True)
+        y = torch.randn(n, device=dev)
+        loss = bbbp_amd.MSELoss()(pred, y)
+        ref = torch.nn.MSELoss()(ref_pred, y)
+        (3.0 * loss).backward(); (3.0 * ref).backward()
+        assert loss.shape == ref.shape == ()
+        torch.testing.assert_close(loss, ref, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(pred.grad, ref_pred.grad, rtol=1e-5, atol=1e-8)
+    with pytest.raises(RuntimeError):
+        bbbp_amd.MSELoss()(torch.zeros(3, device=dev), torch.zeros(4, device=dev))
