@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
 
     // ---- stage loader (register staged): input strip chunk + (streamed) weight chunk ----
     constexpr int QW = (MODE == MODE_FWD) ? W / 4 : W / 8;      // work items per row
-    constexpr int ITEMS = CC * ROWS * QW;
+    constexpr int LCH = CIN < CC ? CIN : CC;                    // planes actually staged (the 4th plane of an RGB input stays zero)
+    constexpr int ITEMS = LCH * ROWS * QW;
     constexpr int NIT = (ITEMS + NT - 1) / NT;
     constexpr int WQ = WRES ? 0 : WCHUNK / 4;                   // float4 of weights per stage
     constexpr int WNIT = (WQ + NT - 1) / NT;
@@ -194,6 +195,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     const int xbase = kh2 * PLANE + r0 * LDW + c0 + j + PADL - 1;
     const int wbase = kh2 * COUT + j;
 
+    // CIN = 3: per-lane offsets of the flattened K walk; k = 2 * step + (lane >> 5), row of Wt[tap][4][co] and LDS offset
+    int koff_w[14], koff_x[14];
+    if (CIN == 3) {
+#pragma unroll
+        for (int st = 0; st < 14; ++st) {
+            const int k = 2 * st + kh2;
+            const int tap = k < 27 ? k / 3 : 0, ci = k < 27 ? k % 3 : 3;          // k = 27: the zero row (tap 0, plane 3)
+            koff_w[st] = (tap * CC + ci) * COUT;
+            koff_x[st] = ci * PLANE + (tap / 3) * LDW + (tap % 3);
+        }
+    }
+
     f32x16 acc[MT][2];
 
     int strip = blockIdx.x;
@@ -225,16 +238,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
 
             const float* xs = smem + buf * STAGE + xbase;
             const float* ws = (WRES ? Wres : smem + buf * STAGE + XCHUNK) + wbase;
+            const float* xs3 = smem + buf * STAGE + r0 * LDW + c0 + j + PADL - 1;      // CIN = 3: the k half is in koff_x
+            const float* ws3 = Wres + j;
             // 9 taps x CC/2 channel pairs = NS k-steps, software pipelined: the LDS reads of step s+1 are issued
-            // BEFORE the MFMAs of step s (hipcc otherwise issues them after, exposing the LDS latency every step)
-            constexpr int NS = 9 * (CC / 2);
+            // BEFORE the MFMAs of step s (hipcc otherwise issues them after, exposing the LDS latency every step).
+            // RGB input (CIN = 3): K = 27 is walked flat, k = tap * 3 + ci, 14 steps instead of 9 x 2 = 18 over a
+            // zero-padded 4th plane; the two k of a step are then different (tap, ci) pairs, so each lane keeps its
+            // 14 weight-row and 14 input offsets in registers (koff_w / koff_x, set up once before the strip loop).
+            constexpr int NS = (CIN == 3) ? 14 : 9 * (CC / 2);
             float a[2][MT], bb[2][2];
             auto ld = [&](int st, float* av, float* bv) __attribute__((always_inline)) {
-                const int tap = st / (CC / 2), cp = st % (CC / 2), kh = tap / 3, kw = tap % 3;
+                if constexpr (CIN == 3) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) av[mt] = ws[(tap * CC + 2 * cp) * COUT + mt * 32];
+                    for (int mt = 0; mt < MT; ++mt) av[mt] = ws3[koff_w[st] + mt * 32];
 #pragma unroll
-                for (int n = 0; n < 2; ++n) bv[n] = xs[(2 * cp) * PLANE + (n + kh) * LDW + kw];
+                    for (int n = 0; n < 2; ++n) bv[n] = xs3[koff_x[st] + n * LDW];
+                } else {
+                    const int tap = st / (CC / 2), cp = st % (CC / 2), kh = tap / 3, kw = tap % 3;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) av[mt] = ws[(tap * CC + 2 * cp) * COUT + mt * 32];
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) bv[n] = xs[(2 * cp) * PLANE + (n + kh) * LDW + kw];
+                }
             };
             ld(0, a[0], bb[0]);
 #pragma unroll
