@@ -588,11 +588,6 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         // norm2: dz2 (residual gradient, flows to y1) and its dropped copy dff (gradient of the FFN output)
         TRY(bbbp_layernorm_bwd(ce.st, dyout, z2, P[ix.layer(l, L_N2W)], c.f(o.mean2), c.f(o.rstd2), dz2, plan.drop ? dff : nullptr,
                                nullptr, nullptr, B, F, p_drop, site_seed(d->seed, l, 3)));
-        TRY(leaf_after(ce));
-        TRY(bbbp_layernorm_bwd(cl.st, dyout, z2, P[ix.layer(l, L_N2W)], c.f(o.mean2), c.f(o.rstd2), nullptr, nullptr,
-                               G[ix.layer(l, L_N2W)], G[ix.layer(l, L_N2B)], B, F, p_drop, 0));
-        TRY(linear_bwd_weight(cl, dff, F, hff, DFF, G[ix.layer(l, L_W2)], B, F, DFF));
-        TRY(bbbp_bias_act_bwd(cl.st, dff, F, nullptr, 0, G[ix.layer(l, L_B2)], B, F, 0, 1.f));
         // linear2 input gradient, then ReLU (+ dropout: hff is the post-dropout value, hff > 0 <=> active and kept)
         // the ReLU / dropout mask rides in the GEMM epilogue; the bias gradient (a column sum) is a leaf
         {
@@ -600,7 +595,12 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
             g.gate = hff; g.ldg = DFF; g.gate_scale = inv_keep;
             TRY(bbbp_gemm_f32_grouped(ce.st, &g, 1, ce.scratch(), ce.scratch_bytes()));
         }
+        // leaves of this half layer (they only read per-layer buffers, so ONE event per half layer orders them all)
         TRY(leaf_after(ce));
+        TRY(bbbp_layernorm_bwd(cl.st, dyout, z2, P[ix.layer(l, L_N2W)], c.f(o.mean2), c.f(o.rstd2), nullptr, nullptr,
+                               G[ix.layer(l, L_N2W)], G[ix.layer(l, L_N2B)], B, F, p_drop, 0));
+        TRY(linear_bwd_weight(cl, dff, F, hff, DFF, G[ix.layer(l, L_W2)], B, F, DFF));
+        TRY(bbbp_bias_act_bwd(cl.st, dff, F, nullptr, 0, G[ix.layer(l, L_B2)], B, F, 0, 1.f));
         TRY(bbbp_bias_act_bwd(cl.st, dhff, DFF, nullptr, 0, G[ix.layer(l, L_B1)], B, DFF, 0, 1.f));
         TRY(linear_bwd_weight(cl, dhff, DFF, y1, F, G[ix.layer(l, L_W1)], B, DFF, F));
         // dy1 = dhff W1 + dz2
@@ -608,11 +608,6 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         // norm1
         TRY(bbbp_layernorm_bwd(ce.st, dy1, z1, P[ix.layer(l, L_N1W)], c.f(o.mean1), c.f(o.rstd1), dz1, plan.drop ? dsa : nullptr,
                                nullptr, nullptr, B, F, p_drop, site_seed(d->seed, l, 1)));
-        TRY(leaf_after(ce));
-        TRY(bbbp_layernorm_bwd(cl.st, dy1, z1, P[ix.layer(l, L_N1W)], c.f(o.mean1), c.f(o.rstd1), nullptr, nullptr,
-                               G[ix.layer(l, L_N1W)], G[ix.layer(l, L_N1B)], B, F, p_drop, 0));
-        TRY(linear_bwd_weight(cl, dsa, F, ctx, F, G[ix.layer(l, L_OUTW)], B, F, F));
-        TRY(bbbp_bias_act_bwd(cl.st, dsa, F, nullptr, 0, G[ix.layer(l, L_OUTB)], B, F, 0, 1.f));
         // out_proj input gradient
         TRY(linear_bwd_input(ce, dsa, F, P[ix.layer(l, L_OUTW)], dctx, F, B, F, F));
         // attention backward.  Products that become ready together share a launch (bbbp_gemm_f32_grouped):
@@ -633,6 +628,10 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
             TRY(bbbp_gemm_f32_grouped(ce.st, g, 2, ce.scratch(), ce.scratch_bytes()));
         }
         TRY(leaf_after(ce));
+        TRY(bbbp_layernorm_bwd(cl.st, dy1, z1, P[ix.layer(l, L_N1W)], c.f(o.mean1), c.f(o.rstd1), nullptr, nullptr,
+                               G[ix.layer(l, L_N1W)], G[ix.layer(l, L_N1B)], B, F, p_drop, 0));
+        TRY(linear_bwd_weight(cl, dsa, F, ctx, F, G[ix.layer(l, L_OUTW)], B, F, F));
+        TRY(bbbp_bias_act_bwd(cl.st, dsa, F, nullptr, 0, G[ix.layer(l, L_OUTB)], B, F, 0, 1.f));
         TRY(linear_bwd_weight(cl, dqkv, 3 * F, xin, F, G[ix.layer(l, L_INW)], B, 3 * F, F));
         TRY(bbbp_bias_act_bwd(cl.st, dqkv, 3 * F, nullptr, 0, G[ix.layer(l, L_INB)], B, 3 * F, 0, 1.f));
         if (l > 0) TRY(linear_bwd_input(ce, dqkv, 3 * F, P[ix.layer(l, L_INW)], c.f(plan.lgrad[l - 1].dyout), F, B, 3 * F, F, dz1, F));

@@ -21,6 +21,7 @@ class AdamW(torch.optim.Optimizer):
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._flat_state = {}
+        self._flat_params = {}
 
     def _init_group_state(self, gi, params):
         total = sum(p.numel() for p in params)
@@ -51,9 +52,32 @@ class AdamW(torch.optim.Optimizer):
             for p in params:
                 self.state[p]["step"] += 1
             step = self.state[params[0]]["step"]
-            all_params = list(group["params"])
-            pflat = flat_view_of(all_params) if len(params) == len(all_params) else None
-            gflat = flat_view_of([p.grad for p in all_params]) if pflat is not None else None
+            all_params = group["params"]
+            pflat = gflat = None
+            if len(params) == len(all_params):
+                # the flat parameter view is cached while the first / last parameter stay where they were
+                key = (all_params[0].data_ptr(), all_params[-1].data_ptr(), len(all_params))
+                hit = self._flat_params.get(gi)
+                if hit is None or hit[0] != key:
+                    hit = (key, flat_view_of(all_params))
+                    self._flat_params[gi] = hit
+                pflat = hit[1]
+                if pflat is not None:
+                    # gradients written by the fused backward are consecutive views of one buffer: recognise that by the
+                    # shared base and the running offset (cheaper than re-deriving the layout from data pointers)
+                    g0 = all_params[0].grad
+                    base = g0._base
+                    if base is not None and g0.storage_offset() == 0 and base.numel() == pflat.numel() and base.is_contiguous():
+                        off = 0
+                        for q in all_params:
+                            g = q.grad
+                            if g._base is not base or g.storage_offset() != off:
+                                base = None
+                                break
+                            off += g.numel()
+                        gflat = base
+                    if gflat is None:
+                        gflat = flat_view_of([q.grad for q in all_params])
             same_step = all(self.state[p]["step"] == step for p in params)
             if pflat is not None and gflat is not None and same_step:
                 m, v = self._flat_state[gi]
