@@ -25,3 +25,25 @@ run(167, 512, True)
 run(167, 256, True)
 run(2048, 512, True)
 run(167, 4096, False)
+
+
+def run_variant(name, make, B, steps=3):
+    """The other model scripts (bbbp_amd.variants), composed from per-op autograd nodes on the same HIP kernels."""
+    torch.manual_seed(0)
+    m = make().to(dev).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=1e-5)
+    F = m.fingerprint_size if hasattr(m, "fingerprint_size") else 167
+    fp = torch.randn(B, F, device=dev); img = torch.randn(B, 49152, device=dev); y = torch.randn(B, device=dev)
+    def step():
+        torch.nn.MSELoss()(m(fp, img).squeeze(), y).backward(); opt.step(); opt.zero_grad(set_to_none=True)
+    for _ in range(2): step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps): step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    print(f"{name} B={B} train: {dt*1e3:8.2f} ms/step  {B/dt:10.0f} molecules/s  peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
+    del m, opt; torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+
+
+if os.environ.get("BBBP_TIME_VARIANTS", "1") != "0":
+    from bbbp_amd import variants
+    run_variant("wide/deep (12-layer encoder, 3-stage CNN)", lambda: variants.WideDeepMixedInputModel(167, 128), 256)
