@@ -54,6 +54,8 @@ _SIGNATURES = {
     "bbbp_gemm_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, _FP, c_int, _FP, c_int, _FP, c_int,
                               _FP, _FP, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_void_p, c_size_t]),
     "bbbp_gemm_f32_grouped": (c_int, [c_void_p, POINTER(GemmDesc), c_int, c_void_p, c_size_t]),
+    "bbbp_mixed_backward_wait_bucket": (c_int, [c_void_p, c_int]),
+    "bbbp_mixed_bucket_param": (c_int, [POINTER(MixedDesc), c_int]),
     "bbbp_set_graphs": (c_int, [c_int]),
     "bbbp_mlp_train_epochs": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int]),
     "bbbp_mlp_predict_proba": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -147,6 +147,11 @@ constexpr int NEV = 32;
 struct SideStream { hipStream_t s = nullptr; hipStream_t leaf = nullptr; hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr;
                     hipEvent_t ev[NEV]; int next = 0; };
 SideStream g_side[64];
+// recorded on the caller's stream when the image-FC weight gradient (33.5 MB of the 53.9 MB of gradients at F = 167) is
+// final, i.e. after the first GEMM of the image branch's backward: a data-parallel caller can start reducing that bucket
+// while the remaining ~2 ms of the backward pass run (bbbp_mixed_backward_wait_bucket)
+hipEvent_t g_bucket_event[64];
+bool g_bucket_recorded[64];
 int g_overlap = -1;
 bool overlap_enabled() {
     if (g_overlap < 0) { const char* e = getenv("BBBP_SINGLE_STREAM"); g_overlap = (e && e[0] == '1') ? 0 : 1; }
@@ -558,6 +563,21 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
     float* dpool2 = c.f(plan.dpool2); float* dpool1 = c.f(plan.dpool1);
     next_section(SEC_IMGFC_BWD);
     TRY(linear_bwd_weight(c, dcomb + FC, COMB, pool2, IMG_FLAT, G[ix.ifc_w()], B, FC, IMG_FLAT));
+    {
+        int dev = 0;
+        BBBP_CHECK_HIP(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64) {
+            if (!g_bucket_event[dev]) BBBP_CHECK_HIP(hipEventCreateWithFlags(&g_bucket_event[dev], hipEventDisableTiming));
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(c.st, &cap);
+            if (cap == hipStreamCaptureStatusNone) {        // an event recorded inside a graph capture means nothing outside it
+                BBBP_CHECK_HIP(hipEventRecord(g_bucket_event[dev], c.st));
+                g_bucket_recorded[dev] = true;
+            } else {
+                g_bucket_recorded[dev] = false;
+            }
+        }
+    }
     TRY(linear_bwd_input(c, dcomb + FC, COMB, P[ix.ifc_w()], dpool2, IMG_FLAT, B, FC, IMG_FLAT));
     next_section(SEC_CONV2_WGRAD);
     TRY(bbbp_conv3x3_relu_pool_bwd_weight(c.st, pool1, dpool2, c.u8(plan.mask2), G[ix.c2_w()], G[ix.c2_b()], B, C1, C2, IMG / 2,
@@ -693,6 +713,22 @@ GraphKey make_key(int kind, const bbbp_mixed_desc* d, const void* a, const void*
 }
 
 }  // namespace
+
+// Make `stream` wait until gradient bucket `bucket` of the most recent bbbp_mixed_backward on this device is final.
+// bucket 0 = the image-FC weight (parameter index bbbp_mixed_bucket_param(d, 0)).  Returns BBBP_ERR_ARG when no such
+// event exists (no backward yet, or the backward was replayed from a graph): the caller then waits for the whole stream.
+extern "C" int bbbp_mixed_backward_wait_bucket(void* stream, int bucket) {
+    BBBP_CHECK_ARG(bucket == 0, "wait_bucket: unknown bucket %d", bucket);
+    int dev = 0;
+    BBBP_CHECK_HIP(hipGetDevice(&dev));
+    BBBP_CHECK_ARG(dev >= 0 && dev < 64 && g_bucket_event[dev] && g_bucket_recorded[dev], "wait_bucket: no bucket event on device %d", dev);
+    BBBP_CHECK_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), g_bucket_event[dev], 0));
+    return BBBP_OK;
+}
+extern "C" int bbbp_mixed_bucket_param(const bbbp_mixed_desc* d, int bucket) {
+    if (!d || bucket != 0) return -1;
+    return PIdx(d->num_layers).ifc_w();
+}
 
 extern "C" int bbbp_set_graphs(int on) { const int old = graphs_mode(); g_graphs_mode = on ? 1 : 0; return old; }
 

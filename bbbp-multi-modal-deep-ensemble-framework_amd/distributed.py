@@ -95,6 +95,53 @@ def allreduce_gradients(module_or_params, average: bool = True, group=None, buck
     return n_coll
 
 
+class OverlappedGradAllReduce:
+    """Gradient all-reduce for the fused ``MixedInputModel`` that starts before the backward pass has finished.
+
+    The fused backward writes all gradients into one flat buffer; the image-FC weight's slice (62 % of the bytes at
+    F = 167) is final after the first GEMM of the image branch.  Call this right after ``loss.backward()`` returns (the
+    GPU is then still ~2 ms from the end of the pass): the big slice is reduced on a communication stream that waits only
+    for the engine's bucket event, the two remaining slices are reduced on the current stream, i.e. after the pass.
+    Falls back to ``allreduce_gradients`` whenever the layout or the event is not what it expects."""
+
+    def __init__(self, model, group=None):
+        self.model, self.group = model, group
+        self.early = model.image_cnn[7].weight
+        self.comm = None
+
+    def __call__(self, params, average: bool = False) -> int:
+        from . import _lib
+        world = world_size(self.group)
+        if world == 1:
+            return 0
+        params = _params_with_grad(list(params))
+        flat = flat_view_of([p.grad for p in params]) if params else None
+        g = self.early.grad
+        if flat is None or g is None or not flat.is_cuda:
+            return allreduce_gradients(params, average=average, group=self.group)
+        a0 = (g.data_ptr() - flat.data_ptr()) // flat.element_size()
+        a1 = a0 + g.numel()
+        if a0 < 0 or a1 > flat.numel() or not g.is_contiguous():
+            return allreduce_gradients(params, average=average, group=self.group)
+        if self.comm is None:
+            self.comm = torch.cuda.Stream(device=flat.device)
+        if _lib.lib().bbbp_mixed_backward_wait_bucket(self.comm.cuda_stream, 0) != 0:
+            return allreduce_gradients(params, average=average, group=self.group)     # no bucket event: plain path
+        early = flat[a0:a1]
+        with torch.cuda.stream(self.comm):
+            work = dist.all_reduce(early, group=self.group, async_op=True)
+        n = 1
+        for lo, hi in ((0, a0), (a1, flat.numel())):
+            if hi > lo:
+                dist.all_reduce(flat[lo:hi], group=self.group)
+                n += 1
+        work.wait()                              # the current stream waits for the early bucket
+        early.record_stream(torch.cuda.current_stream())
+        if average:
+            flat.div_(world)
+        return n
+
+
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
     """Make every rank start from rank ``src``'s parameters and buffers (one collective when the parameters are flat)."""
     if world_size(group) == 1:

@@ -128,15 +128,23 @@ def main():
     crit = bbbp_amd.MSELoss()             # nn.MSELoss semantics, value + gradient in one kernel
     fp, img, y = synthetic_b3db(2 * BATCH, F_DIM, 20250113 + rank, dev)
     params = list(model.parameters())
+    # N > 1: the image-FC weight gradient (62 % of the bytes) is all-reduced under the rest of the backward pass, the
+    # remainder after it (distributed.OverlappedGradAllReduce); BBBP_BENCH_PLAIN_ALLREDUCE=1 selects the single collective
+    reducer = None
+    if world > 1 and os.environ.get("BBBP_BENCH_PLAIN_ALLREDUCE", "0") != "1":
+        reducer = D.OverlappedGradAllReduce(model)
 
-    def step(i):
+    def step(i, collective=True):
         s = (i % 2) * BATCH
         out = model(fp[s:s + BATCH], img[s:s + BATCH]).squeeze()
         loss = crit(out, y[s:s + BATCH])
         loss.backward()
-        if world > 1:
+        if world > 1 and collective:
             # ONE RCCL sum over xGMI when the gradients are one flat buffer (they are); 1/world folded into AdamW
-            D.allreduce_gradients(params, average=False)
+            if reducer is not None:
+                reducer(params, average=False)
+            else:
+                D.allreduce_gradients(params, average=False)
         opt.step(grad_scale=1.0 / world)
         opt.zero_grad(set_to_none=True)
         return loss
@@ -175,7 +183,7 @@ def main():
     if rank == 0:
         L.bbbp_profile_enable(1)
         for i in range(5):
-            step(i)
+            step(i, collective=False)        # rank 0 only: no collective here, the other ranks wait in the barrier below
         torch.cuda.synchronize()
         _lib.check(L.bbbp_profile_collect(ms_sum, cnt), "bbbp_profile_collect")
         L.bbbp_profile_enable(0)
@@ -187,10 +195,10 @@ def main():
     if rank == 0:
         old = L.bbbp_set_overlap(0)
         for i in range(2):
-            step(i)
+            step(i, collective=False)
         L.bbbp_profile_enable(1)
         for i in range(5):
-            step(i)
+            step(i, collective=False)
         torch.cuda.synchronize()
         _lib.check(L.bbbp_profile_collect(ms_sum, cnt), "bbbp_profile_collect")
         L.bbbp_profile_enable(0)

@@ -214,6 +214,12 @@ int bbbp_mlp_predict_proba(void* stream, const bbbp_mlp_model* models_dev, int m
  * enable(1), run steps, synchronise the stream, collect(ms_sum[n], count[n]) with n = num_sections(). */
 int bbbp_set_partition(int reserved_cus, size_t small_lds_pad);   /* CU partition knob, see csrc/common.h */
 int bbbp_set_overlap(int on);   /* two/three-stream branch overlap inside bbbp_mixed_forward/backward (default on) */
+/* Data-parallel overlap: the gradient of the image-FC weight (62 % of all gradient bytes at F = 167) is final after the
+ * first GEMM of the image branch's backward.  wait_bucket(stream, 0) makes `stream` wait for exactly that point of the
+ * most recent bbbp_mixed_backward on the current device, so an all-reduce of that bucket can run under the remaining
+ * ~2 ms of the backward pass; bucket_param gives the bucket's index in the parameter order. */
+int bbbp_mixed_backward_wait_bucket(void* stream, int bucket);
+int bbbp_mixed_bucket_param(const bbbp_mixed_desc* d, int bucket);
 /* HIP-graph replay of bbbp_mixed_forward / bbbp_mixed_backward: the second call with identical arguments is captured,
  * later ones are replayed with one hipGraphLaunch.  Opt-in (env BBBP_GRAPHS=1 or bbbp_set_graphs(1), which returns the
  * previous setting): measured slower than the eager three-stream enqueue on ROCm 7.2.  Counters since load. */
