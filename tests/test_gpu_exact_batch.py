@@ -74,14 +74,24 @@ def _worker(rank, world, port, q):
 
 
 def test_two_ranks_equal_single_process_full_batch(dev):
-    world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=300) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-    for rank, msg in sorted(res):
+    out = None
+    for attempt in range(3):             # retry the LAUNCH on a rendezvous failure (port taken between probe and bind), never the maths
+        port = _free_port()
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        try:
+            out = [q.get(timeout=300) for _ in procs]
+        except Exception:                # noqa: BLE001
+            out = None
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+        if out is not None and not any("Address already in use" in str(m) or "connect" in str(m).lower() and "refused" in str(m).lower() for _, m in out):
+            break
+    assert out is not None, "the two ranks did not report in three launches"
+    for rank, msg in sorted(out):
         assert msg == "ok", f"rank {rank}:\n{msg}"
