@@ -46,6 +46,13 @@ int bbbp_num_cus();   // cached multiProcessorCount of the current device
 // grids left free.  Measured without it: a 5 us kernel sharing CUs with a conv kernel takes 35-85 us.
 extern int g_bbbp_reserved_cus;
 extern size_t g_bbbp_small_lds_pad;
+// head.hip: fused fusion-block + regression-head forward (two launches); `partial`: ceil(B/16) * 2 * 256 floats
+int bbbp_head_forward_fused(hipStream_t st, const float* comb, const float* const* fw1, const float* const* fb1,
+                            const float* const* fw2, const float* const* fb2, const float* w0, const float* b0, const float* gamma,
+                            const float* beta, float* running_mean, float* running_var, const float* w3, const float* b3,
+                            const float* w5, const float* b5, const float* w7, const float* b7, float* hid, float* attn, float* fused,
+                            float* h, float* hb, float* bn_mean, float* bn_rstd, float* h2, float* h3, float* out, float* partial,
+                            int B, int training);
 constexpr size_t BBBP_CONV_MIN_LDS = 120 * 1024;
 
 // exact f32 MFMA: D[32x32] += A[32x2] * B[2x32]; lane l holds A[l&31][l>>5], B[l>>5][l&31];

@@ -64,7 +64,7 @@ struct Plan {
     size_t scratch3, scratch3_bytes;
     size_t seed_slot;      // the call's dropout seed, in device memory (common.h: effective_seed)
     size_t pool1, mask1, pool2, mask2;
-    size_t combined, hid, attn, fused, h, hb, bn_mean, bn_rstd, h2, h3;
+    size_t combined, hid, attn, fused, h, hb, bn_mean, bn_rstd, h2, h3, head_partial;
     // temporaries
     size_t scratch, scratch_bytes, scratch2, scratch2_bytes;
     size_t dA, dB, dqkv, dprob, dctx, dhff, dpool2, dpool1, dcomb, dfused, dlogit, dpre, dh, dhb, dh2, dh3;
@@ -99,6 +99,7 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     p->combined = b.f(B * COMB); p->hid = b.f(NHEADS_FUSION * B * FUS_HID); p->attn = b.f(B * NHEADS_FUSION);
     p->fused = b.f(B * COMB); p->h = b.f(B * H1); p->hb = b.f(B * H1); p->bn_mean = b.f(H1); p->bn_rstd = b.f(H1);
     p->h2 = b.f(B * H2); p->h3 = b.f(B * H3);
+    p->head_partial = b.f(((B + 15) / 16) * 2 * H1);
     size_t cw = bbbp_conv3x3_workspace_bytes(p->B, 32, 64, 64, 64);
     size_t cw1 = bbbp_conv3x3_workspace_bytes(p->B, 3, 32, 128, 128);
     size_t sb = cw > cw1 ? cw : cw1;
@@ -452,6 +453,17 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
     delete part; part = nullptr;
     Section sec_head(c.st, SEC_HEAD_FWD);
 
+    static const int fused_head = [] { const char* e = getenv("BBBP_FUSED_HEAD"); return e ? atoi(e) : 1; }();
+    if (fused_head && NHEADS_FUSION == 4) {
+        // fusion block + head in two launches (head.hip)
+        const float *fw1[4], *fb1[4], *fw2[4], *fb2[4];
+        for (int h = 0; h < 4; ++h) { fw1[h] = P[ix.fus(h, 0)]; fb1[h] = P[ix.fus(h, 1)]; fw2[h] = P[ix.fus(h, 2)]; fb2[h] = P[ix.fus(h, 3)]; }
+        return bbbp_head_forward_fused(c.st, comb, fw1, fb1, fw2, fb2, P[ix.fc0_w()], P[ix.fc0_b()], P[ix.bn_w()], P[ix.bn_b()],
+                                       bn_running[0], bn_running[1], P[ix.fc3_w()], P[ix.fc3_b()], P[ix.fc5_w()], P[ix.fc5_b()],
+                                       P[ix.fc7_w()], P[ix.fc7_b()], c.f(plan.hid), c.f(plan.attn), c.f(plan.fused), c.f(plan.h),
+                                       c.f(plan.hb), c.f(plan.bn_mean), c.f(plan.bn_rstd), c.f(plan.h2), c.f(plan.h3), out,
+                                       c.f(plan.head_partial), B, d->training);
+    }
     // ---- attention fusion (R:60-65, 117) -------------------------------------------------------
     float* hid = c.f(plan.hid);
     const float* w2[NHEADS_FUSION]; const float* b2[NHEADS_FUSION];

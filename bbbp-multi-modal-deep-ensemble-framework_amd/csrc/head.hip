@@ -1,0 +1,300 @@
+// Fused forward of the fusion block and the regression head (R:60-65 MultiHeadAttentionFusion.forward, R:98-107 fc):
+//   combined[B,256] -> 4 x (Linear(256,128) -> Tanh -> Linear(128,1)) -> softmax over heads -> sum_h w_h * combined
+//   -> Linear(256,256)+ReLU -> BatchNorm1d(256) -> Linear(256,128)+ReLU -> Linear(128,64)+ReLU -> Linear(64,1)
+// Between the join of the two branches and the loss nothing else runs on the GPU, and as ten separate launches (eight
+// GEMMs of a few MFLOP, the head-softmax kernel, BatchNorm) this stretch cost 0.10 ms of pure launch latency per step.
+// Here it is TWO launches, split where BatchNorm needs statistics over the whole batch:
+//   head_a: one work-group per 16 rows keeps its rows in LDS and runs fusion hidden layers, head softmax, weighted sum
+//           and fc.0; it also leaves per-block (mean, M2) of every fc.0 column for the BatchNorm;
+//   head_b: every work-group merges those partials in block order (Chan's parallel-variance update: no E[x^2]-E[x]^2
+//           cancellation), normalises its 16 rows and runs fc.3, fc.5, fc.7.
+// GEMMs use v_mfma_f32_16x16x4_f32 as in gemm.hip's direct kernel: a wave owns 16-column output tiles, the A operand
+// (the block's rows) comes from LDS as one ds_read_b128 per 16-deep chunk, the B operand (Linear weight [out][in]) as
+// one 16-byte global load per lane and chunk, both in the k-permuted order (lane (i, kq) holds k = 16c + 4kq .. +3).
+// Every intermediate the backward pass reads (hid, attn, fused, h, hb, BN mean / rstd, h2, h3) is still written.
+#include "common.h"
+#include "bbbp_hip.h"
+
+namespace {
+
+constexpr int ROWS = 16;         // rows per work-group = MFMA M
+constexpr int NTH = 512;         // 8 waves: the tiles of a layer are spread over them, 2 waves per SIMD hide each other's latencies
+constexpr int NW = NTH / 64;
+constexpr int COMB = 256, FHID = 128, NHEADS = 4, H1 = 256, H2 = 256 / 2, H3 = 64;
+constexpr int LD = COMB + 4;     // LDS row stride (16-byte aligned rows)
+typedef float f32x4g __attribute__((ext_vector_type(4), aligned(4)));      // parameters are only 4-byte aligned
+static_assert(NTH >= H1, "one thread per BatchNorm column");
+
+struct HeadParams {
+    const float* comb;                                   // [B][256]
+    const float* fw1[NHEADS]; const float* fb1[NHEADS]; const float* fw2[NHEADS]; const float* fb2[NHEADS];
+    const float* w0; const float* b0;                    // fc.0 [256][256]
+    const float* gamma; const float* beta; float* running_mean; float* running_var;
+    const float* w3; const float* b3;                    // fc.3 [128][256]
+    const float* w5; const float* b5;                    // fc.5 [64][128]
+    const float* w7; const float* b7;                    // fc.7 [1][64]
+    float* hid; float* attn; float* fused; float* h; float* hb; float* bn_mean; float* bn_rstd; float* h2; float* h3; float* out;
+    float* partial;                                      // [blocks][2][256]: per-block mean and M2 of h
+    int B, training;
+    float eps, momentum;
+};
+
+// B fragments of one 16-column tile: W rows n = 16 * tile + (lane & 15), k = 16c + 4 (lane >> 4) .. +3
+template <int NCH>
+__device__ __forceinline__ void load_b(f32x4 (&bf)[NCH], const float* Wrow /* W + n * K + 4 * kq */) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { f32x4g v = *reinterpret_cast<const f32x4g*>(Wrow + 16 * c); bf[c] = f32x4{v[0], v[1], v[2], v[3]}; }
+}
+// 16 x 16 tile of rows * W^T over K = 16 * NCH; two accumulator chains (the MFMA's dependent latency exceeds its issue time)
+template <int NCH>
+__device__ __forceinline__ f32x4 mma_tile(const f32x4 (&af)[NCH], const f32x4 (&bf)[NCH]) {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c][j], bf[c][j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c][j + 1], bf[c][j + 1], acc1, 0, 0, 0);
+        }
+    return acc0 + acc1;
+}
+
+template <int NCH>
+__device__ __forceinline__ void load_a(f32x4 (&af)[NCH], const float* s, int ld, int lane) {
+    const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) af[c] = *reinterpret_cast<const f32x4*>(s + i * ld + 16 * c + 4 * kq);
+}
+
+// sum over the 16 lanes that share (lane >> 4)
+__device__ __forceinline__ float sum16(float v) {
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+    return v;
+}
+
+__global__ __launch_bounds__(NTH) void head_a_kernel(HeadParams p) {
+    __shared__ __attribute__((aligned(16))) float sC[ROWS * LD];          // combined, later fused
+    __shared__ float sLogit[NW][NHEADS][ROWS];
+    __shared__ float sP[ROWS][NHEADS];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int q = lane & 15, kq = lane >> 4;
+    const int r0 = blockIdx.x * ROWS, nrows = min(ROWS, p.B - r0);
+    // ---- rows of `combined` -> LDS (rows past B: zeros) ----
+    for (int idx = t; idx < ROWS * (COMB / 4); idx += NTH) {
+        const int r = idx / (COMB / 4), c4 = idx % (COMB / 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < nrows) v = *reinterpret_cast<const f32x4*>(p.comb + (long)(r0 + r) * COMB + c4 * 4);
+        *reinterpret_cast<f32x4*>(sC + r * LD + c4 * 4) = v;
+    }
+    __syncthreads();
+    f32x4 af[COMB / 16];
+    load_a<COMB / 16>(af, sC, LD, lane);
+    // ---- fusion hidden layers: 4 heads x 8 column tiles; wave w owns tile w of every head.  The B fragments of the
+    //      next tile are in flight while the current tile's MFMAs run. ----
+    float lg[NHEADS][4];
+    f32x4 bf[2][COMB / 16];
+    const int n = wave * 16 + q;
+    load_b<COMB / 16>(bf[0], p.fw1[0] + (long)n * COMB + 4 * kq);
+#pragma unroll
+    for (int h = 0; h < NHEADS; ++h) {
+        if (h + 1 < NHEADS) load_b<COMB / 16>(bf[(h + 1) & 1], p.fw1[h + 1] + (long)n * COMB + 4 * kq);
+        else load_b<COMB / 16>(bf[(h + 1) & 1], p.w0 + (long)n * COMB + 4 * kq);          // first fc.0 tile of this wave
+        f32x4 acc = mma_tile<COMB / 16>(af, bf[h & 1]);
+        const float b = p.fb1[h][n], w2 = p.fw2[h][n];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * kq + r;
+            const float v = tanhf(acc[r] + b);
+            if (row < nrows) p.hid[((long)h * p.B + r0 + row) * FHID + n] = v;
+            lg[h][r] = sum16(v * w2);
+        }
+    }
+    if (q == 0) {
+#pragma unroll
+        for (int h = 0; h < NHEADS; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sLogit[wave][h][4 * kq + r] = lg[h][r];
+    }
+    __syncthreads();
+    // ---- softmax over the heads, one thread per row ----
+    if (t < ROWS) {
+        float a[NHEADS], m = -INFINITY;
+#pragma unroll
+        for (int h = 0; h < NHEADS; ++h) {
+            float z = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) z += sLogit[w][h][t];          // fixed order
+            a[h] = z + p.fb2[h][0];
+            m = fmaxf(m, a[h]);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int h = 0; h < NHEADS; ++h) { a[h] = __expf(a[h] - m); den += a[h]; }
+#pragma unroll
+        for (int h = 0; h < NHEADS; ++h) {
+            a[h] /= den;
+            sP[t][h] = a[h];
+            if (t < nrows) p.attn[(long)(r0 + t) * NHEADS + h] = a[h];
+        }
+    }
+    __syncthreads();
+    // ---- fused = sum_h a_h * combined (in place in LDS) ----
+    for (int idx = t; idx < ROWS * COMB; idx += NTH) {
+        const int r = idx / COMB, c = idx % COMB;
+        const float x = sC[r * LD + c];
+        float s = 0.f;
+#pragma unroll
+        for (int h = 0; h < NHEADS; ++h) s += sP[r][h] * x;
+        sC[r * LD + c] = s;
+        if (r < nrows) p.fused[(long)(r0 + r) * COMB + c] = s;
+    }
+    __syncthreads();
+    load_a<COMB / 16>(af, sC, LD, lane);
+    // ---- fc.0 + ReLU, and the block's (mean, M2) per column for the BatchNorm: 16 tiles, 2 per wave ----
+    // (bf[0] already holds this wave's first fc.0 tile: it was requested under the last fusion tile)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int n0 = (wave + NW * tt) * 16 + q;
+        if (tt == 0) load_b<COMB / 16>(bf[1], p.w0 + (long)((wave + NW) * 16 + q) * COMB + 4 * kq);
+        f32x4 acc = mma_tile<COMB / 16>(af, bf[tt & 1]);
+        const float b = p.b0[n0];
+        float v[4], s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * kq + r;
+            v[r] = fmaxf(acc[r] + b, 0.f);
+            if (row < nrows) { p.h[(long)(r0 + row) * H1 + n0] = v[r]; s += v[r]; }
+        }
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        const float mean = s / nrows;
+        float m2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (4 * kq + r < nrows) { const float d = v[r] - mean; m2 += d * d; }
+        m2 += __shfl_xor(m2, 16); m2 += __shfl_xor(m2, 32);
+        if (kq == 0) {
+            p.partial[((long)blockIdx.x * 2 + 0) * H1 + n0] = mean;
+            p.partial[((long)blockIdx.x * 2 + 1) * H1 + n0] = m2;
+        }
+    }
+}
+
+__global__ __launch_bounds__(NTH) void head_b_kernel(HeadParams p) {
+    __shared__ __attribute__((aligned(16))) float sA[ROWS * LD];          // hb
+    __shared__ __attribute__((aligned(16))) float sB[ROWS * (H2 + 4)];    // h2
+    __shared__ __attribute__((aligned(16))) float sD[ROWS * (H3 + 4)];    // h3
+    __shared__ float sMean[H1], sRstd[H1];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int q = lane & 15, kq = lane >> 4;
+    const int r0 = blockIdx.x * ROWS, nrows = min(ROWS, p.B - r0);
+    const int nblocks = (p.B + ROWS - 1) / ROWS;
+    // the weights of the first GEMM do not depend on anything computed here: request them before the statistics
+    f32x4 bf3[H1 / 16];
+    load_b<H1 / 16>(bf3, p.w3 + (long)(wave * 16 + q) * H1 + 4 * kq);
+    // ---- batch statistics of column t: merge the blocks' (count, mean, M2) in block order ----
+    if (t < H1) {
+        const int c = t;
+        float mean, rstd;
+        if (p.training) {
+            float na = 0.f, ma = 0.f, m2a = 0.f;
+            for (int b = 0; b < nblocks; ++b) {
+                const float nb = (float)min(ROWS, p.B - b * ROWS);
+                const float mb = p.partial[((long)b * 2 + 0) * H1 + c], m2b = p.partial[((long)b * 2 + 1) * H1 + c];
+                const float d = mb - ma, n = na + nb;
+                ma += d * (nb / n);
+                m2a += m2b + d * d * (na * nb / n);
+                na = n;
+            }
+            const float var = m2a / (float)p.B;
+            mean = ma; rstd = rsqrtf(var + p.eps);
+            if (blockIdx.x == 0) {
+                p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * mean;
+                p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * var * ((float)p.B / (float)(p.B - 1));
+            }
+        } else {
+            mean = p.running_mean[c]; rstd = rsqrtf(p.running_var[c] + p.eps);
+        }
+        sMean[c] = mean; sRstd[c] = rstd;
+        if (blockIdx.x == 0) { p.bn_mean[c] = mean; p.bn_rstd[c] = rstd; }
+    }
+    __syncthreads();
+    // ---- BatchNorm of this block's rows ----
+    for (int idx = t; idx < ROWS * H1; idx += NTH) {
+        const int r = idx / H1, c = idx % H1;
+        float v = 0.f;
+        if (r < nrows) {
+            v = (p.h[(long)(r0 + r) * H1 + c] - sMean[c]) * sRstd[c] * p.gamma[c] + p.beta[c];
+            p.hb[(long)(r0 + r) * H1 + c] = v;
+        }
+        sA[r * LD + c] = v;
+    }
+    __syncthreads();
+    // ---- fc.3 + ReLU: 8 column tiles, 1 per wave ----
+    {
+        f32x4 af[H1 / 16];
+        load_a<H1 / 16>(af, sA, LD, lane);
+        const int n = wave * 16 + q;
+        f32x4 acc = mma_tile<H1 / 16>(af, bf3);
+        const float b = p.b3[n];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * kq + r;
+            const float v = fmaxf(acc[r] + b, 0.f);
+            sB[row * (H2 + 4) + n] = v;
+            if (row < nrows) p.h2[(long)(r0 + row) * H2 + n] = v;
+        }
+    }
+    __syncthreads();
+    // ---- fc.5 + ReLU: 4 column tiles, waves 0..3 ----
+    if (wave < H3 / 16) {
+        f32x4 af[H2 / 16], bf[H2 / 16];
+        const int n = wave * 16 + q;
+        load_b<H2 / 16>(bf, p.w5 + (long)n * H2 + 4 * kq);
+        load_a<H2 / 16>(af, sB, H2 + 4, lane);
+        f32x4 acc = mma_tile<H2 / 16>(af, bf);
+        const float b = p.b5[n];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * kq + r;
+            const float v = fmaxf(acc[r] + b, 0.f);
+            sD[row * (H3 + 4) + n] = v;
+            if (row < nrows) p.h3[(long)(r0 + row) * H3 + n] = v;
+        }
+    }
+    __syncthreads();
+    // ---- fc.7: one wave, 4 lanes per row ----
+    if (wave == 0) {
+        const int row = lane >> 2, part = lane & 3;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < H3 / 4; ++k) s += sD[row * (H3 + 4) + part * (H3 / 4) + k] * p.w7[part * (H3 / 4) + k];
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+        if (part == 0 && row < nrows) p.out[r0 + row] = s + p.b7[0];
+    }
+}
+
+}  // namespace
+
+// Internal entry point (engine.hip): enqueue the fused fusion-block + head forward.  `partial` needs
+// ceil(B / 16) * 2 * 256 floats.
+int bbbp_head_forward_fused(hipStream_t st, const float* comb, const float* const* fw1, const float* const* fb1,
+                            const float* const* fw2, const float* const* fb2, const float* w0, const float* b0, const float* gamma,
+                            const float* beta, float* running_mean, float* running_var, const float* w3, const float* b3,
+                            const float* w5, const float* b5, const float* w7, const float* b7, float* hid, float* attn, float* fused,
+                            float* h, float* hb, float* bn_mean, float* bn_rstd, float* h2, float* h3, float* out, float* partial,
+                            int B, int training) {
+    BBBP_CHECK_ARG(B >= 1, "head: empty batch");
+    BBBP_CHECK_ARG(!(training && B <= 1), "Expected more than 1 value per channel when training, got input size [%d, %d]", B, H1);
+    HeadParams p;
+    p.comb = comb;
+    for (int i = 0; i < NHEADS; ++i) { p.fw1[i] = fw1[i]; p.fb1[i] = fb1[i]; p.fw2[i] = fw2[i]; p.fb2[i] = fb2[i]; }
+    p.w0 = w0; p.b0 = b0; p.gamma = gamma; p.beta = beta; p.running_mean = running_mean; p.running_var = running_var;
+    p.w3 = w3; p.b3 = b3; p.w5 = w5; p.b5 = b5; p.w7 = w7; p.b7 = b7;
+    p.hid = hid; p.attn = attn; p.fused = fused; p.h = h; p.hb = hb; p.bn_mean = bn_mean; p.bn_rstd = bn_rstd; p.h2 = h2; p.h3 = h3;
+    p.out = out; p.partial = partial; p.B = B; p.training = training; p.eps = 1e-5f; p.momentum = 0.1f;
+    const int blocks = cdiv(B, ROWS);
+    hipLaunchKernelGGL(head_a_kernel, dim3(blocks), dim3(NTH), 0, st, p);
+    BBBP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(head_b_kernel, dim3(blocks), dim3(NTH), 0, st, p);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
