@@ -30,7 +30,8 @@ class GemmDesc(Structure):
                 ("A", c_void_p), ("lda", c_int), ("B", c_void_p), ("ldb", c_int), ("C", c_void_p), ("ldc", c_int),
                 ("bias", c_void_p), ("residual", c_void_p), ("ldr", c_int), ("act", c_int),
                 ("gate", c_void_p), ("ldg", c_int), ("gate_scale", c_float), ("batch", c_int),
-                ("strideA", c_long), ("strideB", c_long), ("strideC", c_long), ("strideR", c_long), ("strideG", c_long)]
+                ("strideA", c_long), ("strideB", c_long), ("strideC", c_long), ("strideR", c_long), ("strideG", c_long),
+                ("gate_after_residual", c_int)]
 
 
 class MlpModel(Structure):

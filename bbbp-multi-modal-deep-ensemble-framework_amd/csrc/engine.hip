@@ -264,6 +264,7 @@ bbbp_gemm_desc gemm_desc(int transA, int transB, int M, int N, int K, float alph
     g.transA = transA; g.transB = transB; g.M = M; g.N = N; g.K = K; g.alpha = alpha;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.bias = nullptr; g.residual = nullptr; g.ldr = 0; g.act = 0; g.gate = nullptr; g.ldg = 0; g.gate_scale = 1.f;
+    g.gate_after_residual = 0;
     g.batch = batch; g.strideA = sA; g.strideB = sB; g.strideC = sC; g.strideR = 0; g.strideG = 0;
     return g;
 }
@@ -530,13 +531,22 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
     // fc.7: out = h3 W7^T + b7
     TRY(linear_bwd_weight(cl, dout, 1, h3, H3, G[ix.fc7_w()], B, 1, H3));
     TRY(bbbp_bias_act_bwd(cl.st, const_cast<float*>(dout), 1, nullptr, 0, G[ix.fc7_b()], B, 1, 0, 1.f));   // act 0: dy untouched
-    TRY(linear_bwd_input(c, dout, 1, P[ix.fc7_w()], dh3, H3, B, 1, H3));
-    TRY(bbbp_bias_act_bwd(c.st, dh3, H3, h3, H3, G[ix.fc5_b()], B, H3, BBBP_ACT_RELU, 1.f));
+    // the ReLU masks ride in the input-gradient GEMMs' epilogues; the bias gradients (column sums) are leaves
+    {
+        bbbp_gemm_desc g = gemm_desc(0, 0, B, H3, 1, 1.f, dout, 1, P[ix.fc7_w()], H3, dh3, H3);
+        g.gate = h3; g.ldg = H3;
+        TRY(bbbp_gemm_f32_grouped(c.st, &g, 1, c.scratch(), c.scratch_bytes()));
+    }
     TRY(leaf_after(c));
+    TRY(bbbp_bias_act_bwd(cl.st, dh3, H3, nullptr, 0, G[ix.fc5_b()], B, H3, 0, 1.f));
     TRY(linear_bwd_weight(cl, dh3, H3, h2, H2, G[ix.fc5_w()], B, H3, H2));
-    TRY(linear_bwd_input(c, dh3, H3, P[ix.fc5_w()], dh2, H2, B, H3, H2));
-    TRY(bbbp_bias_act_bwd(c.st, dh2, H2, h2, H2, G[ix.fc3_b()], B, H2, BBBP_ACT_RELU, 1.f));
+    {
+        bbbp_gemm_desc g = gemm_desc(0, 0, B, H2, H3, 1.f, dh3, H3, P[ix.fc5_w()], H2, dh2, H2);
+        g.gate = h2; g.ldg = H2;
+        TRY(bbbp_gemm_f32_grouped(c.st, &g, 1, c.scratch(), c.scratch_bytes()));
+    }
     TRY(leaf_after(c));
+    TRY(bbbp_bias_act_bwd(cl.st, dh2, H2, nullptr, 0, G[ix.fc3_b()], B, H2, 0, 1.f));
     TRY(linear_bwd_weight(cl, dh2, H2, hb, H1, G[ix.fc3_w()], B, H2, H1));
     TRY(linear_bwd_input(c, dh2, H2, P[ix.fc3_w()], dhb, H1, B, H2, H1));
     TRY(bbbp_batchnorm1d_bwd(c.st, dhb, h, P[ix.bn_w()], c.f(plan.bn_mean), c.f(plan.bn_rstd), dh, G[ix.bn_w()], G[ix.bn_b()], B,
@@ -560,11 +570,16 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         TRY(bbbp_bias_act_bwd(cl.st, dl, 1, nullptr, 0, G[ix.fus(hh, 3)], B, 1, 0, 1.f));
         TRY(linear_bwd_weight(cl, dp, FUS_HID, comb, COMB, G[ix.fus(hh, 0)], B, FUS_HID, COMB));
         TRY(bbbp_bias_act_bwd(cl.st, dp, FUS_HID, nullptr, 0, G[ix.fus(hh, 1)], B, FUS_HID, 0, 1.f));
-        TRY(linear_bwd_input(c, dp, FUS_HID, P[ix.fus(hh, 0)], dcomb, COMB, B, FUS_HID, COMB, dcomb, COMB));
+        // dcomb += dp W1_h; the last of the four also applies the ReLU mask of both branch outputs (combined = [fp_out | img_out])
+        bbbp_gemm_desc g = gemm_desc(0, 0, B, COMB, FUS_HID, 1.f, dp, FUS_HID, P[ix.fus(hh, 0)], COMB, dcomb, COMB);
+        g.residual = dcomb; g.ldr = COMB;
+        if (hh == NHEADS_FUSION - 1) { g.gate = comb; g.ldg = COMB; g.gate_after_residual = 1; }
+        TRY(bbbp_gemm_f32_grouped(c.st, &g, 1, c.scratch(), c.scratch_bytes()));
     }
-    // ReLU of both branch outputs + their bias gradients (combined = [fp_out | img_out])
-    TRY(bbbp_bias_act_bwd(c.st, dcomb, COMB, comb, COMB, G[ix.fpfc_b()], B, FC, BBBP_ACT_RELU, 1.f));
-    TRY(bbbp_bias_act_bwd(c.st, dcomb + FC, COMB, comb + FC, COMB, G[ix.ifc_b()], B, FC, BBBP_ACT_RELU, 1.f));
+    // bias gradients of the two branch outputs: column sums of the masked dcomb, leaves
+    TRY(leaf_after(c));
+    TRY(bbbp_bias_act_bwd(cl.st, dcomb, COMB, nullptr, 0, G[ix.fpfc_b()], B, FC, 0, 1.f));
+    TRY(bbbp_bias_act_bwd(cl.st, dcomb + FC, COMB, nullptr, 0, G[ix.ifc_b()], B, FC, 0, 1.f));
 
     // both branches only READ dcomb from here on
     if (ss) { TRY(after(ss, c.st, ce.st)); TRY(after(ss, c.st, cl.st)); }

@@ -43,6 +43,7 @@ struct GemmParams {
     float* slab;             // [batch][split][M][N] when splits > 1
     int vecA, vecB;          // 16-byte global loads allowed
     const float* gate; int ldg; long sG; float gate_scale;      // optional: result *= gate > 0 ? gate_scale : 0
+    int gate_after;          // gate applied after the residual add
 };
 
 // Four consecutive elements starting at p, `valid` (0..4) of them inside the matrix; the rest read as 0.
@@ -244,8 +245,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 int m = m0 + wm * WM + i * 32 + mfma_row(r, lane);
                 if (m < p.M && n < p.N) {
                     float v = apply_act(p.alpha * acc[i][j][r] + bv, p.act);
-                    if (p.gate) v *= p.gate[(long)batch * p.sG + (long)m * p.ldg + n] > 0.f ? p.gate_scale : 0.f;
+                    const float gsel = p.gate ? (p.gate[(long)batch * p.sG + (long)m * p.ldg + n] > 0.f ? p.gate_scale : 0.f) : 1.f;
+                    if (!p.gate_after) v *= gsel;
                     if (R) v += R[(long)m * p.ldr + n];
+                    if (p.gate_after) v *= gsel;
                     C[(long)m * p.ldc + n] = v;
                 }
             }
@@ -274,8 +277,10 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
         for (; k < p.splits; ++k) s += S[(long)k * mn + idx];
         int m = (int)(idx / p.N), n = (int)(idx % p.N);
         float v = apply_act(p.alpha * s + (p.bias ? p.bias[n] : 0.f), p.act);
-        if (p.gate) v *= p.gate[(long)batch * p.sG + (long)m * p.ldg + n] > 0.f ? p.gate_scale : 0.f;
+        const float gsel = p.gate ? (p.gate[(long)batch * p.sG + (long)m * p.ldg + n] > 0.f ? p.gate_scale : 0.f) : 1.f;
+        if (!p.gate_after) v *= gsel;
         if (R) v += R[(long)m * p.ldr + n];
+        if (p.gate_after) v *= gsel;
         C[(long)m * p.ldc + n] = v;
     }
 }
@@ -313,7 +318,7 @@ struct DirectParams {
     long sA, sB, sC, sR;
     float alpha;
     int act;
-    const float* gate; int ldg; long sG; float gate_scale;
+    const float* gate; int ldg; long sG; float gate_scale; int gate_after;
     int wsm, wsn, ks;        // waves of a work-group: wsm x wsn output tiles, each computed by ks K-slices
     int batch, gx, gy;       // grid extent of THIS problem (a grouped launch covers the largest)
 };
@@ -469,8 +474,10 @@ __device__ __forceinline__ void gemm_direct_body(const DirectParams& p, int batc
                 const int m = opa.index(um, 4 * kq + r);
                 if (m < p.M && n < p.N) {
                     float v = apply_act(p.alpha * acc[um][un][r] + bv, p.act);
-                    if (p.gate) v *= p.gate[(long)batch * p.sG + (long)m * p.ldg + n] > 0.f ? p.gate_scale : 0.f;
+                    const float gsel = p.gate ? (p.gate[(long)batch * p.sG + (long)m * p.ldg + n] > 0.f ? p.gate_scale : 0.f) : 1.f;
+                    if (!p.gate_after) v *= gsel;
                     if (R) v += R[(long)m * p.ldr + n];
+                    if (p.gate_after) v *= gsel;
                     C[(long)m * p.ldc + n] = v;
                 }
             }
@@ -668,7 +675,7 @@ bool direct_params(const bbbp_gemm_desc& g, DirectParams* d, int* t) {
     d->M = g.M; d->N = g.N; d->K = g.K; d->lda = g.lda; d->ldb = g.ldb; d->ldc = g.ldc; d->ldr = g.ldr;
     d->sA = g.strideA; d->sB = g.strideB; d->sC = g.strideC; d->sR = g.strideR;
     d->alpha = g.alpha; d->act = g.act;
-    d->gate = g.gate; d->ldg = g.ldg; d->sG = g.strideG; d->gate_scale = g.gate_scale;
+    d->gate = g.gate; d->ldg = g.ldg; d->sG = g.strideG; d->gate_scale = g.gate_scale; d->gate_after = g.gate_after_residual;
     d->wsm = dp.wsm; d->wsn = dp.wsn; d->ks = dp.ks;
     d->batch = g.batch; d->gx = cdiv(g.N, 16 * dp.t * dp.wsn); d->gy = cdiv(g.M, 16 * dp.t * dp.wsm);
     *t = dp.t;
@@ -691,7 +698,7 @@ int gemm_run(hipStream_t st, const bbbp_gemm_desc& g, void* workspace, size_t wo
     p.M = M; p.N = N; p.K = K; p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc; p.ldr = g.ldr;
     p.sA = g.strideA; p.sB = g.strideB; p.sC = g.strideC; p.sR = g.strideR;
     p.alpha = g.alpha; p.act = g.act;
-    p.gate = g.gate; p.ldg = g.ldg; p.sG = g.strideG; p.gate_scale = g.gate_scale;
+    p.gate = g.gate; p.ldg = g.ldg; p.sG = g.strideG; p.gate_scale = g.gate_scale; p.gate_after = g.gate_after_residual;
     // 16-byte loads need aligned bases/strides AND a contiguous extent that is a multiple of 4 (so that a quad is
     // either fully inside or fully outside the matrix): K for an [M][K] / [N][K] operand, M or N for a [K][.] one
     p.vecA = aligned16(g.A) && (g.lda % 4 == 0) && (g.strideA % 4 == 0) && ((g.transA ? M : K) % 4 == 0);
@@ -735,7 +742,7 @@ extern "C" int bbbp_gemm_f32(void* stream, int transA, int transB, int M, int N,
     g.transA = transA; g.transB = transB; g.M = M; g.N = N; g.K = K; g.alpha = alpha;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
-    g.gate = nullptr; g.ldg = 0; g.gate_scale = 1.f;
+    g.gate = nullptr; g.ldg = 0; g.gate_scale = 1.f; g.gate_after_residual = 0;
     g.batch = batch; g.strideA = strideA; g.strideB = strideB; g.strideC = strideC; g.strideR = strideR; g.strideG = 0;
     return gemm_run(static_cast<hipStream_t>(stream), g, workspace, workspace_bytes);
 }

@@ -41,7 +41,7 @@ def _rowmajor_2d(t: torch.Tensor, name: str) -> Tuple[int, int, int]:
     return t.shape[0], t.shape[1], ld
 
 
-def _gemm_desc(a, b, trans_a, trans_b, alpha, bias, residual, act, out, gate, gate_scale):
+def _gemm_desc(a, b, trans_a, trans_b, alpha, bias, residual, act, out, gate, gate_scale, gate_after_residual=False):
     """Validate one product and describe it as a bbbp_gemm_desc; returns (desc, out, split-K workspace bytes)."""
     _chk(a, "a"); _chk(b, "b")
     batched = a.dim() == 3
@@ -85,19 +85,21 @@ def _gemm_desc(a, b, trans_a, trans_b, alpha, bias, residual, act, out, gate, ga
             raise RuntimeError(f"gemm: bias has {bias.numel()} elements, expected {N}")
     d = _lib.GemmDesc(int(trans_a), int(trans_b), M, N, K, float(alpha), a.data_ptr(), lda, b.data_ptr(), ldb,
                       out.data_ptr(), ldc, _p(bias), _p(residual), ldr, ACT[act], _p(gate), ldg, float(gate_scale), nb,
-                      sa, sb, sc, sr, sg)
+                      sa, sb, sc, sr, sg, int(bool(gate_after_residual)))
     return d, out, _lib.lib().bbbp_gemm_workspace_bytes(M, N, K, nb)
 
 
 def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False, alpha: float = 1.0,
          bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act=None,
-         out: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None, gate_scale: float = 1.0) -> torch.Tensor:
+         out: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None, gate_scale: float = 1.0,
+         gate_after_residual: bool = False) -> torch.Tensor:
     """out = gate_mask(act(alpha * op(a) @ op(b) + bias)) + residual  (2-D; or 3-D batched with equal batch dims).
 
-    gate: optional tensor of the output's shape; the result is multiplied by gate_scale where gate > 0, by 0 elsewhere."""
+    gate: optional tensor of the output's shape; the result is multiplied by gate_scale where gate > 0, by 0 elsewhere
+    (before the residual is added, or after it with gate_after_residual)."""
     if gate is not None:
         return gemm_grouped([dict(a=a, b=b, trans_a=trans_a, trans_b=trans_b, alpha=alpha, bias=bias, residual=residual,
-                                  act=act, out=out, gate=gate, gate_scale=gate_scale)])[0]
+                                  act=act, out=out, gate=gate, gate_scale=gate_scale, gate_after_residual=gate_after_residual)])[0]
     d, out, wsb = _gemm_desc(a, b, trans_a, trans_b, alpha, bias, residual, act, out, None, 1.0)
     ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=a.device)
     _lib.check(_lib.lib().bbbp_gemm_f32(_stream(), d.transA, d.transB, d.M, d.N, d.K, d.alpha, d.A, d.lda, d.B, d.ldb,
@@ -108,14 +110,14 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bo
 
 def gemm_grouped(problems) -> list:
     """Independent products (dicts of gemm()'s arguments); neighbours that are small enough share one launch."""
-    keys = ("trans_a", "trans_b", "alpha", "bias", "residual", "act", "out", "gate", "gate_scale")
+    keys = ("trans_a", "trans_b", "alpha", "bias", "residual", "act", "out", "gate", "gate_scale", "gate_after_residual")
     defaults = dict(trans_a=False, trans_b=False, alpha=1.0, bias=None, residual=None, act=None, out=None, gate=None,
-                    gate_scale=1.0)
+                    gate_scale=1.0, gate_after_residual=False)
     descs, outs, wsb = [], [], 0
     for pr in problems:
         kw = {k: pr.get(k, defaults[k]) for k in keys}
         d, out, w = _gemm_desc(pr["a"], pr["b"], kw["trans_a"], kw["trans_b"], kw["alpha"], kw["bias"], kw["residual"],
-                               kw["act"], kw["out"], kw["gate"], kw["gate_scale"])
+                               kw["act"], kw["out"], kw["gate"], kw["gate_scale"], kw["gate_after_residual"])
         descs.append(d); outs.append(out); wsb = max(wsb, w)
     if not descs:
         return []

@@ -63,6 +63,7 @@ typedef struct bbbp_gemm_desc {
     const float* gate; int ldg; float gate_scale;
     int batch;
     long strideA, strideB, strideC, strideR, strideG;
+    int gate_after_residual;      /* 0: gate(act(..)) + residual;  1: gate(act(..) + residual) */
 } bbbp_gemm_desc;
 /* `count` independent products (outputs must not alias another product's operands).  Products that become ready
  * together -- dV | dP and dQ | dK of the attention backward -- go out as ONE launch when both are small; anything

@@ -76,6 +76,9 @@ def test_gemm_grouped_pairs_and_gate(dev, B, D, NH):
         want = (a.double() @ w.double()) * (gate.double() > 0) * 1.25 + res.double()
         got1 = ops.gemm(a.to(dev), w.to(dev), gate=gate.to(dev), gate_scale=1.25, residual=res.to(dev))
         assert_close(got1.cpu().numpy(), want.numpy(), rtol=2e-5, atol_frac=2e-6, what=f"gated {M}x{N}x{K}")
+        want2 = ((a.double() @ w.double()) + res.double()) * (gate.double() > 0) * 1.25
+        got2 = ops.gemm(a.to(dev), w.to(dev), gate=gate.to(dev), gate_scale=1.25, residual=res.to(dev), gate_after_residual=True)
+        assert_close(got2.cpu().numpy(), want2.numpy(), rtol=2e-5, atol_frac=2e-6, what=f"gate after residual {M}x{N}x{K}")
     assert ops.gemm_grouped([]) == []
 
 
