@@ -153,6 +153,10 @@ SideStream g_side[64];
 // while the remaining ~2 ms of the backward pass run (bbbp_mixed_backward_wait_bucket)
 hipEvent_t g_bucket_event[64];
 bool g_bucket_recorded[64];
+// bucket 1: everything except the image-FC weight and the four conv tensors -- final when the fingerprint branch's chain
+// and all weight-gradient leaves are done (~0.25 ms before the image branch's last kernel); recorded on the leaf stream
+hipEvent_t g_bucket1_event[64];
+bool g_bucket1_recorded[64];
 int g_overlap = -1;
 bool overlap_enabled() {
     if (g_overlap < 0) { const char* e = getenv("BBBP_SINGLE_STREAM"); g_overlap = (e && e[0] == '1') ? 0 : 1; }
@@ -684,6 +688,19 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         if (l > 0) TRY(linear_bwd_input(ce, dqkv, 3 * F, P[ix.layer(l, L_INW)], c.f(plan.lgrad[l - 1].dyout), F, B, 3 * F, F, dz1, F));
         else if (d->need_input_grad) TRY(linear_bwd_input(ce, dqkv, 3 * F, P[ix.layer(l, L_INW)], c.f(plan.dA), F, B, 3 * F, F, dz1, F));
     }
+    {
+        // bucket 1 is final when the chain AND the leaves are: make the leaf stream wait for the chain's tail, record there
+        int dev = 0;
+        BBBP_CHECK_HIP(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64) {
+            if (!g_bucket1_event[dev]) BBBP_CHECK_HIP(hipEventCreateWithFlags(&g_bucket1_event[dev], hipEventDisableTiming));
+            if (ss) TRY(after(ss, ce.st, cl.st));
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(cl.st, &cap);
+            g_bucket1_recorded[dev] = cap == hipStreamCaptureStatusNone;
+            if (g_bucket1_recorded[dev]) BBBP_CHECK_HIP(hipEventRecord(g_bucket1_event[dev], cl.st));
+        }
+    }
     if (ss) {
         TRY(join_side(c.st, ss));
         BBBP_CHECK_HIP(hipEventRecord(ss->join2, ss->leaf));
@@ -742,14 +759,18 @@ GraphKey make_key(int kind, const bbbp_mixed_desc* d, const void* a, const void*
 }  // namespace
 
 // Make `stream` wait until gradient bucket `bucket` of the most recent bbbp_mixed_backward on this device is final.
-// bucket 0 = the image-FC weight (parameter index bbbp_mixed_bucket_param(d, 0)).  Returns BBBP_ERR_ARG when no such
+// bucket 0 = the image-FC weight (parameter index bbbp_mixed_bucket_param(d, 0)); bucket 1 = every parameter except
+// that weight and the four conv tensors.  Returns BBBP_ERR_ARG when no such
 // event exists (no backward yet, or the backward was replayed from a graph): the caller then waits for the whole stream.
 extern "C" int bbbp_mixed_backward_wait_bucket(void* stream, int bucket) {
-    BBBP_CHECK_ARG(bucket == 0, "wait_bucket: unknown bucket %d", bucket);
+    BBBP_CHECK_ARG(bucket == 0 || bucket == 1, "wait_bucket: unknown bucket %d", bucket);
     int dev = 0;
     BBBP_CHECK_HIP(hipGetDevice(&dev));
-    BBBP_CHECK_ARG(dev >= 0 && dev < 64 && g_bucket_event[dev] && g_bucket_recorded[dev], "wait_bucket: no bucket event on device %d", dev);
-    BBBP_CHECK_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), g_bucket_event[dev], 0));
+    BBBP_CHECK_ARG(dev >= 0 && dev < 64, "wait_bucket: device %d", dev);
+    hipEvent_t ev = bucket == 0 ? g_bucket_event[dev] : g_bucket1_event[dev];
+    const bool ok = bucket == 0 ? g_bucket_recorded[dev] : g_bucket1_recorded[dev];
+    BBBP_CHECK_ARG(ev && ok, "wait_bucket: no event for bucket %d on device %d", bucket, dev);
+    BBBP_CHECK_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), ev, 0));
     return BBBP_OK;
 }
 extern "C" int bbbp_mixed_bucket_param(const bbbp_mixed_desc* d, int bucket) {

@@ -98,15 +98,18 @@ def allreduce_gradients(module_or_params, average: bool = True, group=None, buck
 class OverlappedGradAllReduce:
     """Gradient all-reduce for the fused ``MixedInputModel`` that starts before the backward pass has finished.
 
-    The fused backward writes all gradients into one flat buffer; the image-FC weight's slice (62 % of the bytes at
-    F = 167) is final after the first GEMM of the image branch.  Call this right after ``loss.backward()`` returns (the
-    GPU is then still ~2 ms from the end of the pass): the big slice is reduced on a communication stream that waits only
-    for the engine's bucket event, the two remaining slices are reduced on the current stream, i.e. after the pass.
-    Falls back to ``allreduce_gradients`` whenever the layout or the event is not what it expects."""
+    The fused backward writes all gradients into one flat buffer.  Two slices are final early: the image-FC weight (62 % of
+    the bytes at F = 167) after the first GEMM of the image branch, and everything except it and the four conv tensors
+    when the fingerprint branch and its weight-gradient leaves are done (the image branch's last kernel is still
+    running).  Call this right after ``loss.backward()`` returns (the GPU is then still ~2 ms from the end of the pass):
+    those slices are reduced on a communication stream that waits only for the engine's bucket events, the conv tensors
+    (76 KB) on the current stream, i.e. after the pass.  Every rank issues the same collectives in the same order.
+    Falls back to ``allreduce_gradients`` whenever the layout or the events are not what it expects."""
 
     def __init__(self, model, group=None):
         self.model, self.group = model, group
         self.early = model.image_cnn[7].weight
+        self.late = [model.image_cnn[0].weight, model.image_cnn[0].bias, model.image_cnn[3].weight, model.image_cnn[3].bias]
         self.comm = None
 
     def __call__(self, params, average: bool = False) -> int:
@@ -117,26 +120,38 @@ class OverlappedGradAllReduce:
         params = _params_with_grad(list(params))
         flat = flat_view_of([p.grad for p in params]) if params else None
         g = self.early.grad
-        if flat is None or g is None or not flat.is_cuda:
+        if flat is None or g is None or not flat.is_cuda or any(p.grad is None for p in self.late):
             return allreduce_gradients(params, average=average, group=self.group)
-        a0 = (g.data_ptr() - flat.data_ptr()) // flat.element_size()
+        es = flat.element_size()
+        a0 = (g.data_ptr() - flat.data_ptr()) // es
         a1 = a0 + g.numel()
-        if a0 < 0 or a1 > flat.numel() or not g.is_contiguous():
+        c0 = (self.late[0].grad.data_ptr() - flat.data_ptr()) // es
+        c1 = (self.late[-1].grad.data_ptr() - flat.data_ptr()) // es + self.late[-1].grad.numel()
+        # expected order in the flat buffer: [ ... | conv tensors | image-FC weight | ... ]
+        if not (0 <= c0 < c1 == a0 < a1 <= flat.numel()) or c1 - c0 != sum(p.grad.numel() for p in self.late):
             return allreduce_gradients(params, average=average, group=self.group)
+        L = _lib.lib()
         if self.comm is None:
             self.comm = torch.cuda.Stream(device=flat.device)
-        if _lib.lib().bbbp_mixed_backward_wait_bucket(self.comm.cuda_stream, 0) != 0:
+        if L.bbbp_mixed_backward_wait_bucket(self.comm.cuda_stream, 0) != 0:
             return allreduce_gradients(params, average=average, group=self.group)     # no bucket event: plain path
-        early = flat[a0:a1]
+        works, n = [], 0
         with torch.cuda.stream(self.comm):
-            work = dist.all_reduce(early, group=self.group, async_op=True)
-        n = 1
-        for lo, hi in ((0, a0), (a1, flat.numel())):
+            works.append(dist.all_reduce(flat[a0:a1], group=self.group, async_op=True)); n += 1
+        second_early = L.bbbp_mixed_backward_wait_bucket(self.comm.cuda_stream, 1) == 0
+        rest = [(0, c0), (a1, flat.numel())]
+        if second_early:
+            with torch.cuda.stream(self.comm):
+                for lo, hi in rest:
+                    if hi > lo:
+                        works.append(dist.all_reduce(flat[lo:hi], group=self.group, async_op=True)); n += 1
+            rest = []
+        for lo, hi in rest + [(c0, c1)]:            # on the current stream: after the whole pass
             if hi > lo:
-                dist.all_reduce(flat[lo:hi], group=self.group)
-                n += 1
-        work.wait()                              # the current stream waits for the early bucket
-        early.record_stream(torch.cuda.current_stream())
+                dist.all_reduce(flat[lo:hi], group=self.group); n += 1
+        for w in works:
+            w.wait()                             # the current stream waits for the early buckets
+        flat.record_stream(torch.cuda.current_stream())
         if average:
             flat.div_(world)
         return n

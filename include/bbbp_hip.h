@@ -218,7 +218,9 @@ int bbbp_set_overlap(int on);   /* two/three-stream branch overlap inside bbbp_m
 /* Data-parallel overlap: the gradient of the image-FC weight (62 % of all gradient bytes at F = 167) is final after the
  * first GEMM of the image branch's backward.  wait_bucket(stream, 0) makes `stream` wait for exactly that point of the
  * most recent bbbp_mixed_backward on the current device, so an all-reduce of that bucket can run under the remaining
- * ~2 ms of the backward pass; bucket_param gives the bucket's index in the parameter order. */
+ * ~2 ms of the backward pass; bucket_param gives the bucket's index in the parameter order.  Bucket 1 = every other
+ * gradient except the four conv tensors: final when the fingerprint branch and all weight-gradient leaves are (the image
+ * branch's last kernel is then still running); the conv tensors are final only at the end of the pass. */
 int bbbp_mixed_backward_wait_bucket(void* stream, int bucket);
 int bbbp_mixed_bucket_param(const bbbp_mixed_desc* d, int bucket);
 /* HIP-graph replay of bbbp_mixed_forward / bbbp_mixed_backward: the second call with identical arguments is captured,

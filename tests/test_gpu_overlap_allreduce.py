@@ -45,7 +45,7 @@ def _worker(rank, world, port, q):
                     p.grad = None
             results.append((n, g.cpu()))
         (n0, g0), (n1, g1) = results
-        assert n0 == 1 and n1 == 3, (n0, n1)                       # one collective vs early bucket + two remainders
+        assert n0 == 1 and n1 == 4, (n0, n1)                       # one collective vs image-FC weight + two early remainders + conv tensors
         assert torch.equal(g0, g1), f"rank {rank}: max diff {float((g0 - g1).abs().max()):.3e}"
         # and it really is the mean over ranks: rank 1's view equals rank 0's
         ref = g1.to(dev).clone()
