@@ -76,6 +76,7 @@ _SIGNATURES = {
     "bbbp_dropout": (c_int, [c_void_p, _FP, _FP, c_long, c_float, c_uint64]),
     "bbbp_batchnorm1d_fwd": (c_int, [c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_float, c_float, c_int]),
     "bbbp_batchnorm1d_bwd": (c_int, [c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int]),
+    "bbbp_batchnorm1d_bwd_relu": (c_int, [c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int]),
     "bbbp_column_moments": (c_int, [c_void_p, _FP, _FP, _FP, _FP, c_int, c_int]),
     "bbbp_batchnorm1d_bwd_apply": (c_int, [c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_long]),
     "bbbp_bias_act_bwd": (c_int, [c_void_p, _FP, c_int, _FP, c_int, _FP, c_int, c_int, c_int, c_float]),

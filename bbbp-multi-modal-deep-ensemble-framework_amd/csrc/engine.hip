@@ -553,10 +553,10 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
     TRY(bbbp_bias_act_bwd(cl.st, dh2, H2, nullptr, 0, G[ix.fc3_b()], B, H2, 0, 1.f));
     TRY(linear_bwd_weight(cl, dh2, H2, hb, H1, G[ix.fc3_w()], B, H2, H1));
     TRY(linear_bwd_input(c, dh2, H2, P[ix.fc3_w()], dhb, H1, B, H2, H1));
-    TRY(bbbp_batchnorm1d_bwd(c.st, dhb, h, P[ix.bn_w()], c.f(plan.bn_mean), c.f(plan.bn_rstd), dh, G[ix.bn_w()], G[ix.bn_b()], B,
-                             H1, d->training));
-    TRY(bbbp_bias_act_bwd(c.st, dh, H1, h, H1, G[ix.fc0_b()], B, H1, BBBP_ACT_RELU, 1.f));
+    TRY(bbbp_batchnorm1d_bwd_relu(c.st, dhb, h, P[ix.bn_w()], c.f(plan.bn_mean), c.f(plan.bn_rstd), dh, G[ix.bn_w()], G[ix.bn_b()],
+                                  B, H1, d->training));
     TRY(leaf_after(c));
+    TRY(bbbp_bias_act_bwd(cl.st, dh, H1, nullptr, 0, G[ix.fc0_b()], B, H1, 0, 1.f));
     TRY(linear_bwd_weight(cl, dh, H1, fused, COMB, G[ix.fc0_w()], B, H1, COMB));
     TRY(linear_bwd_input(c, dh, H1, P[ix.fc0_w()], dfused, COMB, B, H1, COMB));
 

@@ -224,7 +224,8 @@ __global__ __launch_bounds__(1024) void batchnorm_fwd_kernel(const float* x, flo
 
 __global__ __launch_bounds__(1024) void batchnorm_bwd_kernel(const float* dy, const float* x, const float* gamma,
                                                             const float* save_mean, const float* save_rstd, float* dx,
-                                                            float* dgamma, float* dbeta, int rows, int cols, int training) {
+                                                            float* dgamma, float* dbeta, int rows, int cols, int training,
+                                                            int relu_gate) {
     BBBP_HIGH_PRIO();
     __shared__ float r1[16][64], r2[16][64];
     __shared__ float t1[64], t2[64];
@@ -252,7 +253,9 @@ __global__ __launch_bounds__(1024) void batchnorm_bwd_kernel(const float* dy, co
         const float g = gamma[c], sa = t1[cl] / rows, sb = t2[cl] / rows;
         for (int r = rl; r < rows; r += 16) {
             float d = dy[(long)r * cols + c];
-            float v = training ? g * rs * (d - sb - (x[(long)r * cols + c] - mu) * rs * sa) : d * g * rs;
+            const float xv = x[(long)r * cols + c];
+            float v = training ? g * rs * (d - sb - (xv - mu) * rs * sa) : d * g * rs;
+            if (relu_gate) v = xv > 0.f ? v : 0.f;       // x is the output of a ReLU: its backward rides along
             dx[(long)r * cols + c] = v;
         }
     }
@@ -517,7 +520,18 @@ extern "C" int bbbp_batchnorm1d_bwd(void* stream, const float* dy, const float* 
                                     int training) {
     BBBP_CHECK_ARG(cols > 0 && rows >= 0, "batchnorm bwd: bad shape");
     hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3(cdiv(cols, 64)), dim3(1024), g_bbbp_small_lds_pad, ST, dy, x, gamma, save_mean, save_rstd, dx,
-                       dgamma, dbeta, rows, cols, training);
+                       dgamma, dbeta, rows, cols, training, 0);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+// the same, followed by the backward of the ReLU that produced x (dx = 0 where x <= 0): nn.Sequential(..., ReLU, BatchNorm1d)
+extern "C" int bbbp_batchnorm1d_bwd_relu(void* stream, const float* dy, const float* x, const float* gamma, const float* save_mean,
+                                         const float* save_rstd, float* dx, float* dgamma, float* dbeta, int rows, int cols,
+                                         int training) {
+    BBBP_CHECK_ARG(cols > 0 && rows >= 0, "batchnorm bwd: bad shape");
+    hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3(cdiv(cols, 64)), dim3(1024), g_bbbp_small_lds_pad, ST, dy, x, gamma, save_mean, save_rstd, dx,
+                       dgamma, dbeta, rows, cols, training, 1);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }

@@ -115,6 +115,10 @@ int bbbp_batchnorm1d_fwd(void* stream, const float* x, float* y, const float* ga
 int bbbp_batchnorm1d_bwd(void* stream, const float* dy, const float* x, const float* gamma, const float* save_mean,
                          const float* save_rstd, float* dx, float* dgamma, float* dbeta, int rows, int cols,
                          int training);
+/* ... followed by the backward of the ReLU that produced x (fc.1 -> fc.2 of the head, R:99-100): dx = 0 where x <= 0 */
+int bbbp_batchnorm1d_bwd_relu(void* stream, const float* dy, const float* x, const float* gamma, const float* save_mean,
+                         const float* save_rstd, float* dx, float* dgamma, float* dbeta, int rows, int cols,
+                         int training);
 
 /* Pieces for a BatchNorm1d whose batch is sharded over ranks (exact-global-batch data parallelism): local column sums of
  * (x - centre) and (x - centre)^2, and dx from sums taken over the global batch of n_global rows. */
