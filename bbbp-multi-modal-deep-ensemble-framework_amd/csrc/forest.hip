@@ -1,0 +1,64 @@
+// Random-forest regression inference (the rf base learner of the stacked ensemble,
+// Models/multi_input_data_regression_opt_transformer_cnn_20250113.py:262-266 and :394-403: RandomForestRegressor(300 trees,
+// max_depth 30) over hstack([fingerprint, image]) = 49 319 features) for screening-scale batches.
+// scikit-learn's arithmetic (sklearn/tree/_tree.pyx, ensemble/_forest.py), restated: X is float32; a node sends a sample
+// left when (double)x[feature] <= threshold (thresholds are float64); a tree's prediction is the float64 value of the
+// leaf; the forest's prediction is the sum over trees divided by the number of trees, in float64.
+// The trees of a forest are concatenated into five node arrays; tree t owns nodes [root[t], root[t+1]).  One thread walks
+// one sample through one group of trees (the walk is a chain of dependent, scattered loads: latency-bound, so many
+// independent walks per CU), a second kernel adds the groups' partial sums in group order (deterministic).
+#include "common.h"
+#include "bbbp_hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void forest_walk_kernel(const float* X, long n, int n_features, const int* left, const int* right,
+                                                         const int* feature, const double* threshold, const double* value,
+                                                         const int* root, int n_trees, int groups, double* partial) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y;
+    if (i >= n) return;
+    const float* x = X + i * (long)n_features;
+    const int t0 = (int)((long)n_trees * g / groups), t1 = (int)((long)n_trees * (g + 1) / groups);
+    double s = 0.0;
+    for (int t = t0; t < t1; ++t) {
+        int node = root[t];
+        int l = left[node];
+        while (l >= 0) {                                   // children_left == -1 marks a leaf
+            node = (double)x[feature[node]] <= threshold[node] ? l : right[node];
+            l = left[node];
+        }
+        s += value[node];
+    }
+    partial[(long)g * n + i] = s;
+}
+
+__global__ __launch_bounds__(256) void forest_reduce_kernel(const double* partial, long n, int groups, int n_trees, double* out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int g = 0; g < groups; ++g) s += partial[(long)g * n + i];
+    out[i] = s / n_trees;
+}
+
+}  // namespace
+
+extern "C" int bbbp_forest_groups(int n_trees) { return n_trees < 1 ? 0 : (n_trees < 32 ? n_trees : 32); }
+
+extern "C" int bbbp_forest_predict(void* stream, const float* X, long n, int n_features, const int* left, const int* right,
+                                   const int* feature, const double* threshold, const double* value, const int* root, int n_trees,
+                                   double* partial, double* out) {
+    BBBP_CHECK_ARG(n >= 0 && n_features >= 1 && n_trees >= 1, "forest_predict: bad sizes");
+    if (n == 0) return BBBP_OK;
+    BBBP_CHECK_ARG(X && left && right && feature && threshold && value && root && partial && out, "forest_predict: null pointer");
+    const int groups = bbbp_forest_groups(n_trees);
+    const long blocks = (n + 255) / 256;
+    BBBP_CHECK_ARG(blocks <= 0x7fffffffL, "forest_predict: too many rows");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(forest_walk_kernel, dim3((unsigned)blocks, groups), dim3(256), 0, st, X, n, n_features, left, right, feature, threshold,
+                       value, root, n_trees, groups, partial);
+    BBBP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(forest_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, partial, n, groups, n_trees, out);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}

@@ -215,6 +215,15 @@ int bbbp_mlp_train_epochs(void* stream, bbbp_mlp_model* models_dev, int n_models
 int bbbp_mlp_predict_proba(void* stream, const bbbp_mlp_model* models_dev, int model, const double* X, int n, int n_features,
                            int max_units, double* out);
 
+/* ---- random-forest regression inference (rf base learner of the stack, ...20250113.py:262-266, 394-403) -------------
+ * scikit-learn's semantics: float32 X, go left when (double)x[feature] <= threshold, leaf value in float64, mean over
+ * trees in float64.  Node arrays are the trees' arrays concatenated (child indices rebased), root[t] = first node of
+ * tree t (n_trees + 1 entries); partial: bbbp_forest_groups(n_trees) * n doubles of scratch. */
+int bbbp_forest_groups(int n_trees);
+int bbbp_forest_predict(void* stream, const float* X, long n, int n_features, const int* left, const int* right,
+                        const int* feature, const double* threshold, const double* value, const int* root, int n_trees,
+                        double* partial, double* out);
+
 /* ---- optional per-section timing (HIP events on the launch stream; used by bench.py's roofline leg) ----
  * enable(1), run steps, synchronise the stream, collect(ms_sum[n], count[n]) with n = num_sections(). */
 int bbbp_set_partition(int reserved_cus, size_t small_lds_pad);   /* CU partition knob, see csrc/common.h */

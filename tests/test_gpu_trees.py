@@ -1,0 +1,38 @@
+"""GPU: random-forest inference (csrc/forest.hip, trees.py) against scikit-learn's own predict (the oracle for this
+third-party arithmetic)."""
+import numpy as np
+import pytest
+
+from bbbp_amd.trees import ForestGPU
+
+pytestmark = pytest.mark.gpu
+ens = pytest.importorskip("sklearn.ensemble")
+
+
+@pytest.mark.parametrize("cls,kw,n,f", [("RandomForestRegressor", dict(n_estimators=37, max_depth=30, random_state=42), 400, 60),
+                                         ("RandomForestRegressor", dict(n_estimators=300, max_depth=6, random_state=1), 300, 20),
+                                         ("ExtraTreesRegressor", dict(n_estimators=5, max_depth=None, random_state=3), 250, 33),
+                                         ("RandomForestRegressor", dict(n_estimators=1, max_depth=1, random_state=0), 50, 4)])
+def test_forest_predict_equals_sklearn(dev, cls, kw, n, f):
+    rs = np.random.RandomState(7)
+    X = rs.randn(n, f)
+    X[:, ::3] = (X[:, ::3] > 0)                 # fingerprint-like binary columns: many ties exactly on thresholds' sides
+    y = X @ rs.randn(f) + np.sin(3 * X[:, 1]) + 0.1 * rs.randn(n)
+    model = getattr(ens, cls)(**kw).fit(X, y)
+    Xt = np.vstack([X[:77], rs.randn(1001, f)])
+    got = ForestGPU.from_sklearn(model, device=dev).predict(Xt)
+    want = model.predict(Xt)
+    # same leaves, float64 sums; scikit-learn adds the trees from several threads, so only the summation order may differ
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+
+
+def test_forest_errors_and_empty(dev):
+    rs = np.random.RandomState(0)
+    X, y = rs.randn(40, 5), rs.randn(40)
+    model = ens.RandomForestRegressor(n_estimators=3, random_state=0).fit(X, y)
+    f = ForestGPU.from_sklearn(model, device=dev)
+    assert f.predict(np.zeros((0, 5))).shape == (0,)
+    with pytest.raises(ValueError):
+        f.predict(np.zeros((3, 6)))
+    with pytest.raises(RuntimeError):
+        ForestGPU.from_sklearn(model, device="cpu")
