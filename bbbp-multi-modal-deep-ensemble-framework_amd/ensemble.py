@@ -71,3 +71,31 @@ class StackedEnsemble:
         for c, w in zip(cols, self.coef_):
             out = out + float(w) * c
         return out
+
+
+def screen(model, forest, stack, fingerprints, images, extra_columns=(), batch_size: int = 4096):
+    """Stacked prediction over a library (BASELINE config 5; ``Descriptors/virtualscreening.py`` + ...20250113.py:394-403):
+    per batch, the multi-modal network in eval mode, the random forest on ``hstack([fingerprint, image])`` (``trees.ForestGPU``)
+    and any precomputed columns (XGBoost / CatBoost predictions) go through the linear meta-learner, all on the GPU.
+    Returns float64 predictions on the device.  Like the reference, the network attends ACROSS the batch, so its
+    column depends on ``batch_size`` and on the order of the library."""
+    import torch
+    n = fingerprints.shape[0]
+    if images.shape[0] != n or any(len(c) != n for c in extra_columns):
+        raise ValueError("fingerprints, images and extra columns must have the same number of rows")
+    was_training = model.training
+    model.eval()
+    out = []
+    try:
+        with torch.no_grad():
+            for i in range(0, n, batch_size):
+                fp, im = fingerprints[i:i + batch_size], images[i:i + batch_size]
+                nn_col = model(fp, im).reshape(-1)
+                cols = []
+                if forest is not None:
+                    cols.append(forest.predict_device(torch.cat([fp, im], dim=1)))
+                cols += [torch.as_tensor(c[i:i + batch_size], device=nn_col.device) for c in extra_columns]
+                out.append(stack.predict_device(nn_col, *cols))
+    finally:
+        model.train(was_training)
+    return torch.cat(out) if out else torch.empty(0, dtype=torch.float64, device=fingerprints.device)

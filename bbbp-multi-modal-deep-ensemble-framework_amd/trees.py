@@ -43,8 +43,8 @@ class ForestGPU:
         return cls(np.concatenate(left), np.concatenate(right), np.concatenate(feature), np.concatenate(threshold),
                    np.concatenate(value), np.asarray(root), forest.n_features_in_, device=device)
 
-    def predict(self, X) -> np.ndarray:
-        """``X``: [n, n_features] (numpy or a CUDA float32 tensor).  Returns float64 predictions on the host."""
+    def predict_device(self, X) -> torch.Tensor:
+        """``X``: [n, n_features] (numpy or a CUDA float32 tensor).  Returns float64 predictions as a tensor on the GPU."""
         if isinstance(X, torch.Tensor):
             Xd = X.to(self.device, torch.float32).contiguous()
         else:
@@ -59,4 +59,8 @@ class ForestGPU:
         _lib.check(L.bbbp_forest_predict(ops._stream(), Xd.data_ptr(), n, self.n_features, self.left.data_ptr(), self.right.data_ptr(),
                                          self.feature.data_ptr(), self.threshold.data_ptr(), self.value.data_ptr(), self.root.data_ptr(),
                                          self.n_trees, partial.data_ptr(), out.data_ptr()), "bbbp_forest_predict")
-        return out.cpu().numpy()
+        return out
+
+    def predict(self, X) -> np.ndarray:
+        """As ``predict_device``, predictions copied to the host (what ``rf.predict`` returns)."""
+        return self.predict_device(X).cpu().numpy()

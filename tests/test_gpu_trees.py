@@ -36,3 +36,28 @@ def test_forest_errors_and_empty(dev):
         f.predict(np.zeros((3, 6)))
     with pytest.raises(RuntimeError):
         ForestGPU.from_sklearn(model, device="cpu")
+
+
+def test_screening_pipeline_matches_columnwise_reference(dev):
+    """ensemble.screen = network (eval) + random forest + precomputed column through the linear meta-learner."""
+    import torch
+    import bbbp_amd
+    from bbbp_amd.ensemble import StackedEnsemble, screen
+    rs = np.random.RandomState(5)
+    n, F = 40, 167
+    fp = torch.from_numpy((rs.rand(n, F) > 0.7).astype(np.float32))
+    img = torch.from_numpy(rs.rand(n, 49152).astype(np.float32))
+    y = rs.randn(n)
+    feats = np.hstack([fp.numpy(), img.numpy()])
+    rf = ens.RandomForestRegressor(n_estimators=8, max_depth=5, random_state=42).fit(feats, y)
+    torch.manual_seed(0)
+    model = bbbp_amd.MixedInputModel(F, 128).to(dev)
+    xgb_col = rs.randn(n)
+    stack = StackedEnsemble.from_coefficients([0.19813994153864287, 0.8730076113813537, 0.16470120078934247], 0.019492486407121146)
+    got = screen(model, ForestGPU.from_sklearn(rf, device=dev), stack, fp.to(dev), img.to(dev), extra_columns=(xgb_col,), batch_size=16)
+    model.eval()
+    with torch.no_grad():
+        nn_col = torch.cat([model(fp[i:i + 16].to(dev), img[i:i + 16].to(dev)).reshape(-1) for i in range(0, n, 16)]).double().cpu().numpy()
+    want = stack.predict(np.stack([nn_col, rf.predict(feats), xgb_col], axis=1))
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-10, atol=1e-10)
+
