@@ -20,7 +20,7 @@ namespace {
 constexpr int ROWS = 16;         // rows per work-group = MFMA M
 constexpr int NTH = 512;         // 8 waves: the tiles of a layer are spread over them, 2 waves per SIMD hide each other's latencies
 constexpr int NW = NTH / 64;
-constexpr int COMB = 256, FHID = 128, NHEADS = 4, H1 = 256, H2 = 256 / 2, H3 = 64;
+constexpr int COMB = 256, FHID = 128, NHEADS = 4, H1 = 256, H2 = 128, H3 = 64;
 constexpr int LD = COMB + 4;     // LDS row stride (16-byte aligned rows)
 typedef float f32x4g __attribute__((ext_vector_type(4), aligned(4)));      // parameters are only 4-byte aligned
 static_assert(NTH >= H1, "one thread per BatchNorm column");
