@@ -25,9 +25,10 @@ class ForestGPU:
         self.threshold, self.value, self.root = to(threshold, np.float64), to(value, np.float64), to(root, np.int32)
         self.n_trees, self.n_features = len(root) - 1, int(n_features)
 
-    @classmethod
-    def from_sklearn(cls, forest, device="cuda") -> "ForestGPU":
-        """From a fitted ``RandomForestRegressor`` / ``ExtraTreesRegressor`` (single output)."""
+    @staticmethod
+    def flatten_sklearn(forest):
+        """Concatenate the trees of a fitted single-output forest: (left, right, feature, threshold, value, root, n_features).
+        Child indices are rebased to the concatenated arrays, -1 marks a leaf, root[t] is the first node of tree t."""
         if getattr(forest, "n_outputs_", 1) != 1:
             raise ValueError("single-output regressors only")
         left, right, feature, threshold, value, root = [], [], [], [], [], [0]
@@ -40,8 +41,13 @@ class ForestGPU:
             root.append(off + t.node_count)
         if root[-1] >= 2 ** 31:
             raise ValueError("forest too large for 32-bit node indices")
-        return cls(np.concatenate(left), np.concatenate(right), np.concatenate(feature), np.concatenate(threshold),
-                   np.concatenate(value), np.asarray(root), forest.n_features_in_, device=device)
+        return (np.concatenate(left), np.concatenate(right), np.concatenate(feature), np.concatenate(threshold),
+                np.concatenate(value), np.asarray(root), int(forest.n_features_in_))
+
+    @classmethod
+    def from_sklearn(cls, forest, device="cuda") -> "ForestGPU":
+        """From a fitted ``RandomForestRegressor`` / ``ExtraTreesRegressor`` (single output)."""
+        return cls(*cls.flatten_sklearn(forest), device=device)
 
     def predict_device(self, X) -> torch.Tensor:
         """``X``: [n, n_features] (numpy or a CUDA float32 tensor).  Returns float64 predictions as a tensor on the GPU."""

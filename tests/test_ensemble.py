@@ -43,3 +43,25 @@ def test_weighted_and_errors():
         StackedEnsemble.from_coefficients([1, 2, 3], 0.0).predict([[1, 2]])
     with pytest.raises(ValueError):
         StackedEnsemble().fit(np.zeros((3, 2)), np.zeros(4))
+
+
+def test_forest_flattening_walks_to_sklearn_predictions():
+    """Host side of trees.ForestGPU (no GPU): the concatenated node arrays, walked in numpy with scikit-learn's rule
+    (float32 feature <= float64 threshold goes left), give rf.predict."""
+    ens = pytest.importorskip("sklearn.ensemble")
+    from bbbp_amd.trees import ForestGPU
+    rs = np.random.RandomState(3)
+    X = rs.randn(120, 9); X[:, ::2] = X[:, ::2] > 0
+    y = X @ rs.randn(9) + 0.1 * rs.randn(120)
+    rf = ens.RandomForestRegressor(n_estimators=7, max_depth=6, random_state=42).fit(X, y)
+    left, right, feature, threshold, value, root, nf = ForestGPU.flatten_sklearn(rf)
+    assert nf == 9 and len(root) == 8 and root[0] == 0 and root[-1] == len(left) == len(value)
+    Xt = rs.randn(50, 9).astype(np.float32)
+    got = np.zeros(50)
+    for i in range(50):
+        for t in range(7):
+            node = root[t]
+            while left[node] >= 0:
+                node = left[node] if np.float64(Xt[i, feature[node]]) <= threshold[node] else right[node]
+            got[i] += value[node]
+    np.testing.assert_allclose(got / 7, rf.predict(Xt), rtol=1e-12, atol=1e-12)
