@@ -6,6 +6,7 @@
 // (R below) and its autograd under loss.backward() (R:190).  The encoder is called with a [B,1,F]
 // tensor and batch_first=False (R:110-111), so self-attention runs ACROSS the mini-batch: S = B, N = 1.
 #include "common.h"
+#include <optional>
 #include "bbbp_hip.h"
 #include <stdlib.h>
 
@@ -400,8 +401,8 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         ce.st = ss->s;
         ce.side = 1;
     }
-    Partition* part = new Partition(ss != nullptr);
-    struct PGuard { Partition*& p; ~PGuard() { delete p; p = nullptr; } } part_guard{part};
+    std::optional<Partition> part;           // scoped sections / partitions end early with reset(), or at any return
+    part.emplace(ss != nullptr);
     float* comb = c.f(plan.combined);
 
     // ---- image branch (R:84-94, 114-115): enqueued first so the GPU is busy while the host feeds the encoder's launches -------------------------------------------------------
@@ -424,8 +425,8 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
 
     // ---- fingerprint branch body (side stream)
     const float* x = fingerprint;
-    Section* sec_enc = new Section(ce.st, SEC_ENCODER_FWD);
-    struct Guard { Section*& p; ~Guard() { delete p; p = nullptr; } } enc_guard{sec_enc};
+    std::optional<Section> sec_enc;
+    sec_enc.emplace(ce.st, SEC_ENCODER_FWD);
     for (int l = 0; l < plan.L; ++l) {
         const LayerOff& o = plan.layer[l];
         float* qkv = c.f(o.qkv); float* prob = c.f(o.prob); float* ctx = c.f(o.ctx);
@@ -452,10 +453,10 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
     }
     // fingerprint_fc (R:79-82, 112) -> combined[:, 0:128]
     TRY(linear_fwd(ce, x, F, P[ix.fpfc_w()], P[ix.fpfc_b()], comb, COMB, B, FC, F, BBBP_ACT_RELU));
-    delete sec_enc; sec_enc = nullptr;
+    sec_enc.reset();
 
     if (ss) TRY(join_side(c.st, ss));        // fusion needs both halves of `combined`
-    delete part; part = nullptr;
+    part.reset();
     Section sec_head(c.st, SEC_HEAD_FWD);
 
     static const int fused_head = [] { const char* e = getenv("BBBP_FUSED_HEAD"); return e ? atoi(e) : 1; }();
@@ -529,9 +530,9 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
     float* dfused = c.f(plan.dfused); float* dcomb = c.f(plan.dcomb);
 
     // ---- head (chain on the caller's stream, leaves on the leaf stream) ---------------------------
-    Section* sec = new Section(c.st, SEC_HEAD_BWD);
-    struct Guard { Section*& p; ~Guard() { delete p; p = nullptr; } } sec_guard{sec};
-    auto next_section = [&](int id) { delete sec; sec = nullptr; sec = new Section(c.st, id); };
+    std::optional<Section> sec;
+    sec.emplace(c.st, SEC_HEAD_BWD);
+    auto next_section = [&](int id) { sec.reset(); sec.emplace(c.st, id); };
     // fc.7: out = h3 W7^T + b7
     TRY(linear_bwd_weight(cl, dout, 1, h3, H3, G[ix.fc7_w()], B, 1, H3));
     TRY(bbbp_bias_act_bwd(cl.st, const_cast<float*>(dout), 1, nullptr, 0, G[ix.fc7_b()], B, 1, 0, 1.f));   // act 0: dy untouched
@@ -619,7 +620,7 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
     next_section(SEC_CONV1_WGRAD);
     TRY(bbbp_conv3x3_relu_pool_bwd_weight(c.st, image, dpool1, c.u8(plan.mask1), G[ix.c1_w()], G[ix.c1_b()], B, 3, C1, IMG, IMG,
                                           c.scratch(), c.scratch_bytes()));
-    delete sec; sec = nullptr;
+    sec.reset();
 
     // ---- fingerprint branch: chain on `ce`, leaves on `cl` --------------------------------------------
     Section sec_encb(ce.st, SEC_ENCODER_BWD);
