@@ -7,6 +7,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define BBBP_OK 0
 #define BBBP_ERR_ARG 1
@@ -46,6 +47,7 @@ int bbbp_num_cus();   // cached multiProcessorCount of the current device
 // grids left free.  Measured without it: a 5 us kernel sharing CUs with a conv kernel takes 35-85 us.
 extern int g_bbbp_reserved_cus;
 extern size_t g_bbbp_small_lds_pad;
+extern int g_bbbp_wino_side_cus;      // CUs the Winograd conv grids leave free while the engine overlaps its branches
 // head.hip: fused fusion-block + regression-head forward (two launches); `partial`: ceil(B/16) * 2 * 256 floats
 int bbbp_head_forward_fused(hipStream_t st, const float* comb, const float* const* fw1, const float* const* fb1,
                             const float* const* fw2, const float* const* fb2, const float* w0, const float* b0, const float* gamma,
@@ -54,6 +56,11 @@ int bbbp_head_forward_fused(hipStream_t st, const float* comb, const float* cons
                             float* h, float* hb, float* bn_mean, float* bn_rstd, float* h2, float* h3, float* out, float* partial,
                             int B, int training);
 constexpr size_t BBBP_CONV_MIN_LDS = 120 * 1024;
+// conv_wino.hip: Winograd F(2x2,3x3) form of the 32 -> 64 @ 64x64 stage; workspace = 16*32*64 floats of transformed filters
+int bbbp_wino_conv2_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* y, uint8_t* mask, int B,
+                        float* workspace);
+int bbbp_wino_conv2_dgrad(hipStream_t st, const float* gy, const uint8_t* gmask, const float* w, float* dx, int B, float* workspace);
+int bbbp_wino_last_clock(unsigned long long* shader_cycles, unsigned long long* ticks_100mhz);
 
 // exact f32 MFMA: D[32x32] += A[32x2] * B[2x32]; lane l holds A[l&31][l>>5], B[l>>5][l&31];
 // D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5) for register r of 16.

@@ -798,11 +798,28 @@ inline bool supported(int cin, int cout, int h, int w) {
            (cin == 64 && cout == 128 && w == 64) || (cin == 128 && cout == 256 && w == 32);
 }
 
+// Winograd form of the 32 -> 64 @ 64x64 stage (conv_wino.hip): bit 0 = forward, bit 1 = data gradient
+int g_winograd = -1;
+int g_last_clock_wino = 0;
+inline int winograd_mask() {
+    if (g_winograd < 0) { const char* e = getenv("BBBP_CONV_WINOGRAD"); g_winograd = e ? atoi(e) & 3 : 3; }
+    return g_winograd;
+}
+
 }  // namespace
+
+extern "C" int bbbp_set_conv_winograd(int mask) {
+    BBBP_CHECK_ARG(mask >= 0 && mask <= 3, "set_conv_winograd: mask %d (bit 0 forward, bit 1 data gradient)", mask);
+    g_winograd = mask;
+    return BBBP_OK;
+}
+
+extern "C" int bbbp_get_conv_winograd(void) { return winograd_mask(); }
 
 // workspace: prepped weights (fwd / dgrad) or partial slabs (wgrad)
 extern "C" int bbbp_conv_last_clock(unsigned long long* shader_cycles, unsigned long long* ticks_100mhz) {
     BBBP_CHECK_ARG(shader_cycles && ticks_100mhz, "conv_last_clock: null pointer");
+    if (g_last_clock_wino) return bbbp_wino_last_clock(shader_cycles, ticks_100mhz);
     unsigned long long h[2] = {0, 0};
     BBBP_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_conv_clock), sizeof(h)));
     *shader_cycles = h[0]; *ticks_100mhz = h[1];
@@ -830,6 +847,12 @@ extern "C" int bbbp_conv3x3_relu_pool_fwd(void* stream, const float* x, const fl
     size_t need = (size_t)9 * cinp * cout * sizeof(float);
     BBBP_CHECK_ARG(workspace_bytes >= need, "conv fwd: workspace %zu < %zu", workspace_bytes, need);
     float* wt = static_cast<float*>(workspace);
+    g_last_clock_wino = 0;
+    if (cin == 32 && cout == 64 && (winograd_mask() & 1)) {
+        BBBP_CHECK_ARG(workspace_bytes >= (size_t)16 * 32 * 64 * sizeof(float), "conv fwd: workspace too small");
+        g_last_clock_wino = 1;
+        return bbbp_wino_conv2_fwd(st, x, w, bias, y, mask, B, wt);
+    }
     int total = 9 * cinp * cout;
     hipLaunchKernelGGL(conv_prep_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, wt, cin, cout, cinp, MODE_FWD);
     BBBP_CHECK_LAUNCH();
@@ -853,6 +876,12 @@ extern "C" int bbbp_conv3x3_relu_pool_bwd_data(void* stream, const float* gy, co
     size_t need = (size_t)9 * cout * cin * sizeof(float);
     BBBP_CHECK_ARG(workspace_bytes >= need, "conv bwd_data: workspace %zu < %zu", workspace_bytes, need);
     float* wt = static_cast<float*>(workspace);
+    g_last_clock_wino = 0;
+    if (cin == 32 && cout == 64 && (winograd_mask() & 2)) {
+        BBBP_CHECK_ARG(workspace_bytes >= (size_t)16 * 32 * 64 * sizeof(float), "conv bwd_data: workspace too small");
+        g_last_clock_wino = 1;
+        return bbbp_wino_conv2_dgrad(st, gy, mask, w, dx, B, wt);
+    }
     int total = 9 * cout * cin;
     hipLaunchKernelGGL(conv_prep_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, wt, cin, cout, 0, MODE_DGRAD);
     BBBP_CHECK_LAUNCH();

@@ -170,12 +170,24 @@ int reserved_cus() {
     return v;
 }
 // scoped CU partition (common.h): conv grids leave `reserved_cus()` CUs to the side stream's small kernels
+// The Winograd conv2 kernels take a whole CU each (496 registers per lane, 110-154 KB LDS): nothing of the side stream
+// can start beside them, so while the branches overlap their grids leave `wino_side_cus()` CUs entirely to the side
+// stream.  Measured (tools/exp_wino.sh, ms/step): 256 CUs 3.65, 224 3.51, 192 3.42, 160 3.51, 128 3.76.
+int wino_side_cus() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("BBBP_WINO_SIDE_CUS"); v = e ? atoi(e) : 64; if (v < 0 || v > 192) v = 64; }
+    return v;
+}
 struct Partition {
-    bool on;
-    explicit Partition(bool enable) : on(enable && reserved_cus() > 0) {
+    bool on, side;
+    explicit Partition(bool enable) : on(enable && reserved_cus() > 0), side(enable) {
         if (on) { g_bbbp_reserved_cus = reserved_cus(); g_bbbp_small_lds_pad = 48 * 1024; }
+        if (side) g_bbbp_wino_side_cus = wino_side_cus();
     }
-    ~Partition() { if (on) { g_bbbp_reserved_cus = 0; g_bbbp_small_lds_pad = 0; } }
+    ~Partition() {
+        if (on) { g_bbbp_reserved_cus = 0; g_bbbp_small_lds_pad = 0; }
+        if (side) g_bbbp_wino_side_cus = 0;
+    }
 };
 int get_side(SideStream** out) {
     int dev = 0;

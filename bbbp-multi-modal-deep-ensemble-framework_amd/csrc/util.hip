@@ -6,6 +6,7 @@
 static thread_local char g_err[512] = "";
 int g_bbbp_reserved_cus = 0;
 size_t g_bbbp_small_lds_pad = 0;
+int g_bbbp_wino_side_cus = 0;
 const unsigned long long* g_bbbp_seed_base = nullptr;
 
 void bbbp_set_error(const char* fmt, ...) {

@@ -218,6 +218,11 @@ def main():
         fl = fwd_flops(BATCH, F_DIM)
         conv2 = fl["conv2"]
         cand = {k: sections[k] for k in ("conv2_fwd", "conv2_dgrad", "conv2_wgrad") if k in sections}
+        # conv2's forward / data gradient may run as Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36.  The
+        # roofline line is the slowest conv2 kernel priced at the algorithmic (direct) flop count of SURVEY.md 8(d); for the
+        # Winograd kernels `winograd` below also gives the MFMA flops they actually execute.
+        wmask = L.bbbp_get_conv_winograd()
+        wino = {k: bool(wmask & bit) for k, bit in (("conv2_fwd", 1), ("conv2_dgrad", 2))}
         roofline = None
         if cand:
             dom = max(cand, key=cand.get)
@@ -234,12 +239,21 @@ def main():
                             ms_per_launch_isolated=round(isolated.get(dom, 0.0), 4),
                             frac_isolated=round(conv2 / (isolated[dom] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if isolated.get(dom) else None,
                             sections_ms={k: round(v, 4) for k, v in sections.items()})
+            roofline["algorithm"] = "winograd F(2x2,3x3) f32" if wino.get(dom) else "direct implicit GEMM f32"
+            if any(wino.values()):
+                roofline["winograd"] = {
+                    k: dict(ms_per_launch=round(sections[k], 4), ms_per_launch_isolated=round(isolated.get(k, 0.0), 4),
+                            executed_flops_per_launch=conv2 * 16 // 36,
+                            direct_equivalent_tflops=round(conv2 / (sections[k] * 1e-3) / 1e12, 2),
+                            executed_frac_of_peak=round(conv2 * 16 / 36 / (sections[k] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+                    for k in wino if wino[k] and k in sections}
             if clock.get("ghz"):
                 # one v_mfma_f32_32x32x2_f32 = 4096 flop and occupies its SIMD's matrix pipe for 64 cycles
                 n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+                executed = conv2 * 16 / 36 if wino["conv2_dgrad"] else conv2
                 roofline["conv2_dgrad_isolated_clock"] = dict(
                     sustained_ghz=round(clock["ghz"], 3), kernel_cycles=clock["cycles"],
-                    mfma_pipe_busy=round(conv2 / 4096 * 64 / n_simd / clock["cycles"], 4),
+                    mfma_pipe_busy=round(executed / 4096 * 64 / n_simd / clock["cycles"], 4),
                     note="shader clock while the kernel runs alone; the 157.3 TFLOP/s peak assumes 2.4 GHz")
         total_flops = sum(fl.values()) * 3 - fl["conv1"]          # bwd = 2 * fwd - conv1 dgrad
         result = {

@@ -79,6 +79,11 @@ size_t bbbp_conv3x3_workspace_bytes(int B, int cin, int cout, int H, int W);
 /* Measurement aid (bench.py): shader-clock cycles and 100 MHz wall ticks that work-group 0 of the most recent
  * forward / data-gradient conv launch ran for (synchronises the device). */
 int bbbp_conv_last_clock(unsigned long long* shader_cycles, unsigned long long* ticks_100mhz);
+/* Selects the algorithm of the 32->64 @ 64x64 stage (R:88-90): bit 0 = forward, bit 1 = data gradient run as Winograd
+ * F(2x2,3x3) in float32 (2.25x fewer multiplies, same tensors and mask, results within 1e-6 of the direct form);
+ * 0 = direct implicit GEMM everywhere.  Initial value: environment BBBP_CONV_WINOGRAD, else 3. */
+int bbbp_set_conv_winograd(int mask);
+int bbbp_get_conv_winograd(void);
 int bbbp_conv3x3_relu_pool_fwd(void* stream, const float* x, const float* w, const float* bias,
                                float* y, uint8_t* mask, int B, int cin, int cout, int H, int W,
                                void* workspace, size_t workspace_bytes);

@@ -4,7 +4,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from bbbp_amd import ops
+from bbbp_amd import _lib, ops
 from oracle import reference_cpu as oracle
 from helpers import assert_close, golden
 
@@ -136,12 +136,12 @@ def test_conv_wide_deep_shapes(dev, cin, cout, hw, B):
     _conv_case(dev, B, cin, cout, hw, seed=100 + cin + B)
 
 
-def test_conv_pool_ties_follow_first_max(dev):
+def test_conv_pool_ties_follow_first_max(dev, conv2_algo):
     _conv_case(dev, 2, 3, 32, 128, seed=31, uniform_patches=True)
     _conv_case(dev, 2, 32, 64, 64, seed=32, uniform_patches=True)
 
 
-def test_conv_many_strips_persistent_loop(dev):
+def test_conv_many_strips_persistent_loop(dev, conv2_algo):
     """More strips than work-groups: exercises the grid-stride loop and the double buffer across strips."""
     _conv_case(dev, 40, 32, 64, 64, seed=41)
     _conv_case(dev, 24, 3, 32, 128, seed=42)

@@ -1,0 +1,63 @@
+"""Direct vs Winograd form of the 32 -> 64 @ 64x64 conv stage: agreement and isolated kernel time (one GPU).
+
+    python tools/bench_conv2.py [B]         # default B = 512
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bbbp_amd import _lib, ops
+
+
+def timed(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    dev = torch.device("cuda")
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    for b in (1, 3, 40):
+        x = torch.relu(torch.randn(b, 32, 64, 64, generator=g)).to(dev)
+        w = (0.2 * torch.randn(64, 32, 3, 3, generator=g)).to(dev)
+        bias = (0.1 * torch.randn(64, generator=g)).to(dev)
+        gy = torch.randn(b, 64, 32, 32, generator=g).to(dev)
+        L.bbbp_set_conv_winograd(0)
+        y0, m0 = ops.conv3x3_relu_pool_fwd(x, w, bias)
+        dx0 = ops.conv3x3_relu_pool_bwd_data(gy, m0, w)
+        L.bbbp_set_conv_winograd(3)
+        y1, m1 = ops.conv3x3_relu_pool_fwd(x, w, bias)
+        dx1 = ops.conv3x3_relu_pool_bwd_data(gy, m0, w)
+        torch.cuda.synchronize()
+        print(f"B={b}: fwd max|diff| {float((y0 - y1).abs().max()):.3e} (max|y| {float(y0.abs().max()):.3f}), "
+              f"mask mismatch {float((m0 != m1).float().mean()):.2e}, dgrad max|diff| {float((dx0 - dx1).abs().max()):.3e} "
+              f"(max|dx| {float(dx0.abs().max()):.3f})", flush=True)
+    x = torch.relu(torch.randn(B, 32, 64, 64, generator=g)).to(dev)
+    w = (0.2 * torch.randn(64, 32, 3, 3, generator=g)).to(dev)
+    bias = (0.1 * torch.randn(64, generator=g)).to(dev)
+    gy = torch.randn(B, 64, 32, 32, generator=g).to(dev)
+    flops = 2.0 * B * 64 * 64 * 64 * 288
+    for mask, name in ((0, "direct"), (3, "winograd")):
+        L.bbbp_set_conv_winograd(mask)
+        y, m = ops.conv3x3_relu_pool_fwd(x, w, bias)
+        tf = timed(lambda: ops.conv3x3_relu_pool_fwd(x, w, bias))
+        td = timed(lambda: ops.conv3x3_relu_pool_bwd_data(gy, m, w))
+        print(f"{name:9s} B={B}: fwd {tf:.3f} ms ({flops / tf / 1e9:.1f} TFLOP/s direct-equivalent), dgrad {td:.3f} ms "
+              f"({flops / td / 1e9:.1f})", flush=True)
+    L.bbbp_set_conv_winograd(0)
+
+
+if __name__ == "__main__":
+    main()

@@ -9,9 +9,9 @@ import csv
 import json
 import sys
 
-KERNELS = {
-    "conv2_fwd": "conv3x3_kernel<32, 64, 64, 0>",
-    "conv2_dgrad": "conv3x3_kernel<64, 32, 64, 1>",
+KERNELS = {            # a section maps to whichever of its kernels ran (direct or Winograd form of conv2)
+    "conv2_fwd": ("conv3x3_kernel<32, 64, 64, 0>", "wino_conv_kernel<0>"),
+    "conv2_dgrad": ("conv3x3_kernel<64, 32, 64, 1>", "wino_conv_kernel<1>"),
     "conv2_wgrad": "conv_wgrad32_kernel<64, 64, 32, 64>",
     "conv1_fwd": "conv3x3_kernel<3, 32, 128, 0>",
     "conv1_wgrad": "conv_wgrad3_kernel<128>",
@@ -24,7 +24,7 @@ def mean_counter(path, counter):
         if r["Counter_Name"] != counter:
             continue
         for key, pat in KERNELS.items():
-            if pat in r["Kernel_Name"]:
+            if any(p_ in r["Kernel_Name"] for p_ in ((pat,) if isinstance(pat, str) else pat)):
                 acc[key].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items() if v}
 
