@@ -124,9 +124,44 @@ def test_conv1_3to32(dev, B):
     _conv_case(dev, B, 3, 32, 128, seed=10 + B)
 
 
+@pytest.fixture(params=[0, 3], ids=["direct", "winograd"])
+def conv2_algo(request):
+    """Both forms of the 32 -> 64 @ 64x64 stage (bbbp_set_conv_winograd): direct implicit GEMM and Winograd F(2x2,3x3)."""
+    L = _lib.lib()
+    old = L.bbbp_get_conv_winograd()
+    _lib.check(L.bbbp_set_conv_winograd(request.param), "bbbp_set_conv_winograd")
+    yield request.param
+    L.bbbp_set_conv_winograd(old)
+
+
 @pytest.mark.parametrize("B", [1, 2, 5])
-def test_conv2_32to64(dev, B):
+def test_conv2_32to64(dev, B, conv2_algo):
     _conv_case(dev, B, 32, 64, 64, seed=20 + B)
+
+
+def test_conv2_winograd_keeps_ties_and_matches_direct(dev):
+    """Flat regions (the white background of the depictions) give bit-equal outputs inside a pooling window in both forms,
+    so the arg-max mask -- which routes the gradient -- is the same; values agree to float32 rounding."""
+    L = _lib.lib()
+    old = L.bbbp_get_conv_winograd()
+    x = torch.relu(rnd(4, 32, 64, 64, seed=77))
+    x[:, :, 8:40, :] = 1.0                                   # flat band
+    w, b = rnd(64, 32, 3, 3, seed=78, scale=0.2), rnd(64, seed=79, scale=0.1)
+    gy = rnd(4, 64, 32, 32, seed=80)
+    try:
+        L.bbbp_set_conv_winograd(0)
+        y0, m0 = ops.conv3x3_relu_pool_fwd(x.to(dev), w.to(dev), b.to(dev))
+        dx0 = ops.conv3x3_relu_pool_bwd_data(gy.to(dev), m0, w.to(dev))
+        L.bbbp_set_conv_winograd(3)
+        y1, m1 = ops.conv3x3_relu_pool_fwd(x.to(dev), w.to(dev), b.to(dev))
+        dx1 = ops.conv3x3_relu_pool_bwd_data(gy.to(dev), m0, w.to(dev))
+    finally:
+        L.bbbp_set_conv_winograd(old)
+    flat = slice(5, 19)                                      # pooled rows whose 4x4 patches lie inside the flat band
+    assert torch.equal(m0[:, :, flat, 1:-1], m1[:, :, flat, 1:-1])
+    assert float((m0 != m1).float().mean()) < 1e-4
+    assert_close(y1.cpu().numpy(), y0.cpu().numpy(), rtol=1e-5, atol_frac=2e-6, what="winograd vs direct fwd")
+    assert_close(dx1.cpu().numpy(), dx0.cpu().numpy(), rtol=1e-5, atol_frac=2e-6, what="winograd vs direct dgrad")
 
 
 @pytest.mark.parametrize("cin,cout,hw,B", [(3, 64, 128, 2), (64, 128, 64, 2), (128, 256, 32, 3), (128, 256, 32, 20)])
