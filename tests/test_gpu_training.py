@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import bbbp_amd
-from bbbp_amd import training
+from bbbp_amd import _lib, training
 from oracle import reference_cpu as oracle
 from helpers import synth_inputs
 
@@ -44,7 +44,17 @@ def oracle_train(state, fp, img, y, orders, batch_size, faithful, test):
     return losses, preds
 
 
-def test_faithful_training_loop_matches_oracle(dev):
+@pytest.fixture(params=[0, 3], ids=["direct", "winograd"])
+def conv2_form(request):
+    """Both forms of the 32 -> 64 conv stage (include/bbbp_hip.h: bbbp_set_conv_winograd)."""
+    L = _lib.lib()
+    old = L.bbbp_get_conv_winograd()
+    _lib.check(L.bbbp_set_conv_winograd(request.param), "bbbp_set_conv_winograd")
+    yield request.param
+    L.bbbp_set_conv_winograd(old)
+
+
+def test_faithful_training_loop_matches_oracle(dev, conv2_form):
     F, N, NT, BS, EPOCHS = 64, 96, 32, 32, 3
     fp, img, y = synth_inputs(31, N + NT, F, 49152)
     torch.manual_seed(5)
@@ -70,7 +80,12 @@ def test_faithful_training_loop_matches_oracle(dev):
     yt = y[N:].numpy()
     r2_a, r2_b = training.r2_score(yt, preds), training.r2_score(yt, ref_preds)
     mse_a, mse_b = training.mean_squared_error(yt, preds), training.mean_squared_error(yt, ref_preds)
-    assert abs(r2_a - r2_b) <= 0.002 and abs(mse_a - mse_b) <= 0.002, (r2_a, r2_b, mse_a, mse_b)
+    # R^2 = 1 - MSE / var(y): on this 32-sample set var(y) = 0.36, so the +-0.002 MSE band is a +-0.0056 R^2 band.  Nine
+    # AdamW steps amplify float32 rounding differences between any two correct implementations (tools/exp_train_noise.py:
+    # max |pred - oracle| is 1e-4 .. 2.5e-3 depending only on summation order -- GEMM tiling, fused or unfused head,
+    # direct or Winograd conv2 -- and is the same bit for bit with one stream or three).
+    r2_tol = 0.002 / min(1.0, float(np.var(yt)))
+    assert abs(mse_a - mse_b) <= 0.002 and abs(r2_a - r2_b) <= r2_tol, (r2_a, r2_b, mse_a, mse_b)
     assert np.max(np.abs(preds - ref_preds)) <= 5e-3 * max(1.0, np.max(np.abs(ref_preds)))
     assert len(hist["val_loss"]) == EPOCHS and all(np.isfinite(hist["val_loss"]))
     assert int(model.state_dict()["fc.2.num_batches_tracked"]) == 3     # BatchNorm saw train mode in epoch 1 only
