@@ -53,7 +53,11 @@ struct GemmParams {
 template <bool VEC>
 __device__ __forceinline__ float4 ld4(const float* p, const float* safe, int valid) {
     const float* q = valid > 0 ? p : safe;
-    if (VEC) return *reinterpret_cast<const float4*>(q);
+    if (VEC) {          // gfx950 global loads need only 4-byte alignment: one dwordx4 also for odd parameter offsets / strides
+        typedef float f32x4_any __attribute__((ext_vector_type(4), aligned(4)));
+        const f32x4_any v = *reinterpret_cast<const f32x4_any*>(q);
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
     const int m = max(valid, 1) - 1;
     return make_float4(q[0], q[min(1, m)], q[min(2, m)], q[min(3, m)]);
 }
@@ -699,10 +703,11 @@ int gemm_run(hipStream_t st, const bbbp_gemm_desc& g, void* workspace, size_t wo
     p.sA = g.strideA; p.sB = g.strideB; p.sC = g.strideC; p.sR = g.strideR;
     p.alpha = g.alpha; p.act = g.act;
     p.gate = g.gate; p.ldg = g.ldg; p.sG = g.strideG; p.gate_scale = g.gate_scale; p.gate_after = g.gate_after_residual;
-    // 16-byte loads need aligned bases/strides AND a contiguous extent that is a multiple of 4 (so that a quad is
-    // either fully inside or fully outside the matrix): K for an [M][K] / [N][K] operand, M or N for a [K][.] one
-    p.vecA = aligned16(g.A) && (g.lda % 4 == 0) && (g.strideA % 4 == 0) && ((g.transA ? M : K) % 4 == 0);
-    p.vecB = aligned16(g.B) && (g.ldb % 4 == 0) && (g.strideB % 4 == 0) && ((g.transB ? K : N) % 4 == 0);
+    // 4-wide loads need a contiguous extent that is a multiple of 4 (so that a quad is either fully inside or fully
+    // outside the matrix): K for an [M][K] / [N][K] operand, M or N for a [K][.] one.  Bases and strides may be odd
+    // (the image-FC weight sits at an odd offset of the flat parameter buffer when F = 167): the loads are unaligned dwordx4.
+    p.vecA = ((g.transA ? M : K) % 4 == 0);
+    p.vecB = ((g.transB ? K : N) % 4 == 0);
     int tile;
     gemm_plan(M, N, K, batch, &tile, &p.splits, &p.kchunk);
     p.slab = nullptr;
