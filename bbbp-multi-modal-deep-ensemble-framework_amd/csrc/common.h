@@ -61,6 +61,7 @@ int bbbp_wino_conv2_fwd(hipStream_t st, const float* x, const float* w, const fl
                         float* workspace);
 int bbbp_wino_conv2_dgrad(hipStream_t st, const float* gy, const uint8_t* gmask, const float* w, float* dx, int B, float* workspace);
 int bbbp_wino_last_clock(unsigned long long* shader_cycles, unsigned long long* ticks_100mhz);
+int bbbp_wino_last_phases(unsigned long long* phases4);     // BBBP_WINO_PROBE=1 builds of the kernel only
 
 // exact f32 MFMA: D[32x32] += A[32x2] * B[2x32]; lane l holds A[l&31][l>>5], B[l>>5][l&31];
 // D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5) for register r of 16.

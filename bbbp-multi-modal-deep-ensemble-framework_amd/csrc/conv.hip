@@ -815,6 +815,10 @@ extern "C" int bbbp_set_conv_winograd(int mask) {
 }
 
 extern "C" int bbbp_get_conv_winograd(void) { return winograd_mask(); }
+extern "C" int bbbp_conv_winograd_phases(unsigned long long* phases4) {
+    BBBP_CHECK_ARG(phases4, "conv_winograd_phases: null pointer");
+    return bbbp_wino_last_phases(phases4);
+}
 
 // workspace: prepped weights (fwd / dgrad) or partial slabs (wgrad)
 extern "C" int bbbp_conv_last_clock(unsigned long long* shader_cycles, unsigned long long* ticks_100mhz) {

@@ -52,8 +52,11 @@ struct WinoCfg {
 };
 
 __device__ unsigned long long g_wino_clock[2];
+// phase breakdown of work-group 0 / wave 0 (PROBE builds only; tools/bench_conv2.py --probe): shader cycles spent in
+// [0] accumulator init, [1] k-steps (LDS reads, transforms, MFMAs), [2] stage hand-over (LDS writes + barrier), [3] output transform + stores
+__device__ unsigned long long g_wino_phase[4];
 
-template <int MODE>
+template <int MODE, bool PROBE>
 __device__ __forceinline__ void wino_conv_body(const WinoParams& p) {
     using C = WinoCfg<MODE>;
     constexpr int KIN = C::KIN, MOUT = C::MOUT, NCB = C::NCB, CC = C::CC, NCH = C::NCH, XST = C::XST, UF = C::UF;
@@ -131,6 +134,10 @@ __device__ __forceinline__ void wino_conv_body(const WinoParams& p) {
     };
 
     f32x16 acc[16];
+    unsigned long long ph[4] = {0, 0, 0, 0}, tprev = PROBE ? __builtin_readcyclecounter() : 0;
+    auto mark = [&](int k) __attribute__((always_inline)) {
+        if (PROBE) { const unsigned long long now = __builtin_readcyclecounter(); ph[k] += now - tprev; tprev = now; }
+    };
     int strip = first;
     if (strip < nstrips) {
         load_stage(strip, 0);
@@ -138,6 +145,7 @@ __device__ __forceinline__ void wino_conv_body(const WinoParams& p) {
     }
     __syncthreads();
     int buf = 0;
+    mark(2);
     for (; strip < nstrips; strip += stride) {
         const int b = strip >> 3, h0 = (strip & 7) * 8;
 #pragma unroll
@@ -149,6 +157,7 @@ __device__ __forceinline__ void wino_conv_body(const WinoParams& p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[5][r] = p.bias[cb * 32 + mfma_row(r, lane)];
         }
+        mark(0);
         for (int chunk = 0; chunk < NCH; ++chunk) {
             int nstrip = strip, nchunk = chunk + 1;
             if (nchunk == NCH) { nchunk = 0; nstrip = strip + stride; }
@@ -202,9 +211,11 @@ __device__ __forceinline__ void wino_conv_body(const WinoParams& p) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            mark(1);
             if (have_next) store_stage(nstrip, buf ^ 1);
             __syncthreads();
             buf ^= 1;
+            mark(2);
         }
         // ---- output transform A^T m A per accumulator register (one output channel x one tile) ----
 #pragma unroll
@@ -233,15 +244,20 @@ __device__ __forceinline__ void wino_conv_body(const WinoParams& p) {
                 *reinterpret_cast<float2*>(o + IMG) = make_float2(v10, v11);
             }
         }
+        mark(3);
     }
     if (blockIdx.x == 0 && t == 0) {
         g_wino_clock[0] = __builtin_readcyclecounter() - clk0;
         g_wino_clock[1] = wall_clock64() - wall0;
+        if (PROBE)
+            for (int k = 0; k < 4; ++k) g_wino_phase[k] = ph[k];
     }
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void wino_conv_kernel(WinoParams p) { wino_conv_body<MODE>(p); }
+__global__ __launch_bounds__(256) void wino_conv_kernel(WinoParams p) { wino_conv_body<MODE, false>(p); }
+template <int MODE>
+__global__ __launch_bounds__(256) void wino_conv_probe_kernel(WinoParams p) { wino_conv_body<MODE, true>(p); }
 
 // U[block][pos][k][32] = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], from the reference layout w[64][32][3][3].
 //  FWD:   k = input channel, produced channel = block * 32 + m, g = w[co][ci]
@@ -274,7 +290,8 @@ int launch_wino(const WinoParams& p, hipStream_t st) {
         if (!e) e = getenv("BBBP_WINO_CUS");
         return e ? atoi(e) : 0;
     }();
-    auto kernel = wino_conv_kernel<MODE>;
+    static const int probe = [] { const char* e = getenv("BBBP_WINO_PROBE"); return e ? atoi(e) : 0; }();
+    auto kernel = probe ? wino_conv_probe_kernel<MODE> : wino_conv_kernel<MODE>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -314,6 +331,11 @@ int bbbp_wino_conv2_dgrad(hipStream_t st, const float* gy, const uint8_t* gmask,
     BBBP_CHECK_LAUNCH();
     WinoParams p{gy, gmask, workspace, nullptr, dx, nullptr, B};
     return launch_wino<W_DGRAD>(p, st);
+}
+
+int bbbp_wino_last_phases(unsigned long long* phases4) {
+    BBBP_CHECK_HIP(hipMemcpyFromSymbol(phases4, HIP_SYMBOL(g_wino_phase), 4 * sizeof(unsigned long long)));
+    return BBBP_OK;
 }
 
 int bbbp_wino_last_clock(unsigned long long* shader_cycles, unsigned long long* ticks_100mhz) {

@@ -84,6 +84,9 @@ int bbbp_conv_last_clock(unsigned long long* shader_cycles, unsigned long long* 
  * 0 = direct implicit GEMM everywhere.  Initial value: environment BBBP_CONV_WINOGRAD, else 3. */
 int bbbp_set_conv_winograd(int mask);
 int bbbp_get_conv_winograd(void);
+/* Measurement aid: with BBBP_WINO_PROBE=1 in the environment the Winograd kernels stamp the shader clock at phase boundaries;
+ * phases4 = cycles work-group 0 spent in {accumulator init, k-steps, stage hand-over, output transform} of the last launch. */
+int bbbp_conv_winograd_phases(unsigned long long* phases4);
 int bbbp_conv3x3_relu_pool_fwd(void* stream, const float* x, const float* w, const float* bias,
                                float* y, uint8_t* mask, int B, int cin, int cout, int H, int W,
                                void* workspace, size_t workspace_bytes);

@@ -56,6 +56,17 @@ def main():
         td = timed(lambda: ops.conv3x3_relu_pool_bwd_data(gy, m, w))
         print(f"{name:9s} B={B}: fwd {tf:.3f} ms ({flops / tf / 1e9:.1f} TFLOP/s direct-equivalent), dgrad {td:.3f} ms "
               f"({flops / td / 1e9:.1f})", flush=True)
+        if mask and os.environ.get("BBBP_WINO_PROBE") == "1":
+            import ctypes
+            for what, fn in (("fwd", lambda: ops.conv3x3_relu_pool_fwd(x, w, bias)), ("dgrad", lambda: ops.conv3x3_relu_pool_bwd_data(gy, m, w))):
+                fn(); torch.cuda.synchronize()
+                ph = (ctypes.c_uint64 * 4)()
+                _lib.check(L.bbbp_conv_winograd_phases(ph), "phases")
+                cyc, ticks = ctypes.c_uint64(0), ctypes.c_uint64(0)
+                _lib.check(L.bbbp_conv_last_clock(ctypes.byref(cyc), ctypes.byref(ticks)), "clock")
+                tot = sum(ph)
+                print(f"   {what}: work-group 0 cycles {cyc.value}: init {ph[0]} ({100 * ph[0] / tot:.1f} %), k-steps {ph[1]} ({100 * ph[1] / tot:.1f} %), "
+                      f"stage hand-over {ph[2]} ({100 * ph[2] / tot:.1f} %), output transform {ph[3]} ({100 * ph[3] / tot:.1f} %)", flush=True)
     L.bbbp_set_conv_winograd(0)
 
 
