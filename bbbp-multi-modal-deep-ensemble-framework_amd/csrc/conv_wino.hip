@@ -169,14 +169,15 @@ __device__ __forceinline__ void wino_conv_body(const WinoParams& p) {
             constexpr int KS = CC / 2;
             float a[2][16], v[2][16];
             auto ld = [&](int ks, float* av, float* vv) __attribute__((always_inline)) {
-#pragma unroll
-                for (int pos = 0; pos < 16; ++pos) av[pos] = ub[(pos * KIN + 2 * ks) * 32];
+                // the patch first: its transform is the first consumer, the A operands are not needed before the next k-step
                 f32x2 d[4][2];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int cp = 0; cp < 2; ++cp)
                         d[r][cp] = *reinterpret_cast<const f32x2*>(xb + 2 * ks * PLANE + r * LDW + 2 * cp);
+#pragma unroll
+                for (int pos = 0; pos < 16; ++pos) av[pos] = ub[(pos * KIN + 2 * ks) * 32];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     // row r of B^T d as two column pairs (packed f32 adds), then (B^T d) B: columns 0 and 3 are one packed op
@@ -200,12 +201,13 @@ __device__ __forceinline__ void wino_conv_body(const WinoParams& p) {
 #pragma unroll
                 for (int pos = 0; pos < 16; ++pos) acc[pos] = mfma32(a[ks & 1][pos], v[ks & 1][pos], acc[pos]);
                 if (ks + 1 < KS) {
-                    // next step's LDS reads first, two MFMAs to cover their latency, then its adds under the rest
+                    // next step's LDS reads first, four MFMAs to cover their latency (the four waves of the group read at the
+                    // same time: 32 KB through the CU's LDS port), then its adds under the rest
                     __builtin_amdgcn_sched_group_barrier(0x100, 24, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
 #pragma unroll
-                    for (int g = 0; g < 14; ++g) {
-                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    for (int g = 0; g < 12; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     }
                 }
