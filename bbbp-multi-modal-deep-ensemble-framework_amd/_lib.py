@@ -58,6 +58,7 @@ _SIGNATURES = {
     "bbbp_mixed_backward_wait_bucket": (c_int, [c_void_p, c_int]),
     "bbbp_mixed_bucket_param": (c_int, [POINTER(MixedDesc), c_int]),
     "bbbp_set_graphs": (c_int, [c_int]),
+    "bbbp_set_fused_head_bwd": (c_int, [c_int]),
     "bbbp_forest_groups": (c_int, [c_int]),
     "bbbp_forest_predict": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_void_p]),

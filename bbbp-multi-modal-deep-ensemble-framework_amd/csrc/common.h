@@ -55,6 +55,12 @@ int bbbp_head_forward_fused(hipStream_t st, const float* comb, const float* cons
                             const float* w5, const float* b5, const float* w7, const float* b7, float* hid, float* attn, float* fused,
                             float* h, float* hb, float* bn_mean, float* bn_rstd, float* h2, float* h3, float* out, float* partial,
                             int B, int training);
+// head.hip: the input-gradient chain of the head and fusion block backward (two launches); `partial` as above
+int bbbp_head_backward_fused(hipStream_t st, const float* dout, const float* comb, const float* hid, const float* attn, const float* h,
+                             const float* h2, const float* h3, const float* bn_mean, const float* bn_rstd, const float* gamma,
+                             const float* const* fw1, const float* const* fw2, const float* w0, const float* w3, const float* w5,
+                             const float* w7, float* dh3, float* dh2, float* dhb, float* dh, float* dlogit, float* dpre, float* dcomb,
+                             float* dgamma, float* dbeta, float* partial, int B, int training);
 constexpr size_t BBBP_CONV_MIN_LDS = 120 * 1024;
 // conv_wino.hip: Winograd F(2x2,3x3) form of the 32 -> 64 @ 64x64 stage; workspace = 16*32*64 floats of transformed filters
 int bbbp_wino_conv2_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* y, uint8_t* mask, int B,

@@ -159,6 +159,7 @@ bool g_bucket_recorded[64];
 hipEvent_t g_bucket1_event[64];
 bool g_bucket1_recorded[64];
 int g_overlap = -1;
+int g_fused_head_bwd = -1;
 bool overlap_enabled() {
     if (g_overlap < 0) { const char* e = getenv("BBBP_SINGLE_STREAM"); g_overlap = (e && e[0] == '1') ? 0 : 1; }
     return g_overlap == 1;
@@ -357,6 +358,12 @@ int graph_lookup(const GraphKey& k, GraphEntry** slot) {
 }  // namespace
 
 // Branch overlap on/off at run time (default on; env BBBP_SINGLE_STREAM=1 starts with it off).  Returns the old value.
+extern "C" int bbbp_set_fused_head_bwd(int on) {
+    const int prev = g_fused_head_bwd > 0 ? 1 : 0;
+    g_fused_head_bwd = on ? 1 : 0;
+    return prev;
+}
+
 extern "C" int bbbp_set_overlap(int on) { int old = overlap_enabled() ? 1 : 0; g_overlap = on ? 1 : 0; return old; }
 
 // Profiling: enable, run steps, synchronise the stream, then collect {sum of ms, launches} per section.
@@ -545,6 +552,45 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
     std::optional<Section> sec;
     sec.emplace(c.st, SEC_HEAD_BWD);
     auto next_section = [&](int id) { sec.reset(); sec.emplace(c.st, id); };
+    // opt-in (bbbp_set_fused_head_bwd / BBBP_FUSED_HEAD_BWD=1): measured neutral at B = 512 (the head section shrinks 0.126 ->
+    // 0.070 ms but the step does not: the leaves it feeds finish no earlier) and slower at B = 256
+    if (g_fused_head_bwd < 0) { const char* e = getenv("BBBP_FUSED_HEAD_BWD"); g_fused_head_bwd = e ? atoi(e) != 0 : 0; }
+    const int fused_head_bwd = g_fused_head_bwd;
+    float* dlogit = c.f(plan.dlogit); float* dpre = c.f(plan.dpre);
+    bool head_leaves_pending = false;
+    auto head_leaves = [&]() -> int {
+        TRY(linear_bwd_weight(cl, dout, 1, h3, H3, G[ix.fc7_w()], B, 1, H3));
+        TRY(bbbp_bias_act_bwd(cl.st, const_cast<float*>(dout), 1, nullptr, 0, G[ix.fc7_b()], B, 1, 0, 1.f));
+        TRY(bbbp_bias_act_bwd(cl.st, dh3, H3, nullptr, 0, G[ix.fc5_b()], B, H3, 0, 1.f));
+        TRY(linear_bwd_weight(cl, dh3, H3, h2, H2, G[ix.fc5_w()], B, H3, H2));
+        TRY(bbbp_bias_act_bwd(cl.st, dh2, H2, nullptr, 0, G[ix.fc3_b()], B, H2, 0, 1.f));
+        TRY(linear_bwd_weight(cl, dh2, H2, hb, H1, G[ix.fc3_w()], B, H2, H1));
+        TRY(bbbp_bias_act_bwd(cl.st, dh, H1, nullptr, 0, G[ix.fc0_b()], B, H1, 0, 1.f));
+        TRY(linear_bwd_weight(cl, dh, H1, fused, COMB, G[ix.fc0_w()], B, H1, COMB));
+        for (int hh = 0; hh < NHEADS_FUSION; ++hh) {
+            float* dl = dlogit + (size_t)hh * B;
+            float* dp = dpre + (size_t)hh * B * FUS_HID;
+            const float* hd = hid + (size_t)hh * B * FUS_HID;
+            TRY(linear_bwd_weight(cl, dl, 1, hd, FUS_HID, G[ix.fus(hh, 2)], B, 1, FUS_HID));
+            TRY(bbbp_bias_act_bwd(cl.st, dl, 1, nullptr, 0, G[ix.fus(hh, 3)], B, 1, 0, 1.f));
+            TRY(linear_bwd_weight(cl, dp, FUS_HID, comb, COMB, G[ix.fus(hh, 0)], B, FUS_HID, COMB));
+            TRY(bbbp_bias_act_bwd(cl.st, dp, FUS_HID, nullptr, 0, G[ix.fus(hh, 1)], B, FUS_HID, 0, 1.f));
+        }
+        TRY(bbbp_bias_act_bwd(cl.st, dcomb, COMB, nullptr, 0, G[ix.fpfc_b()], B, FC, 0, 1.f));
+        TRY(bbbp_bias_act_bwd(cl.st, dcomb + FC, COMB, nullptr, 0, G[ix.ifc_b()], B, FC, 0, 1.f));
+        return BBBP_OK;
+    };
+    if (fused_head_bwd) {
+        // the whole input-gradient chain of the head and the fusion block in two launches (head.hip); every weight / bias
+        // gradient below is a leaf that reads what those wrote
+        const float* fw1[NHEADS_FUSION]; const float* fw2[NHEADS_FUSION];
+        for (int hh = 0; hh < NHEADS_FUSION; ++hh) { fw1[hh] = P[ix.fus(hh, 0)]; fw2[hh] = P[ix.fus(hh, 2)]; }
+        TRY(bbbp_head_backward_fused(c.st, dout, comb, hid, c.f(plan.attn), h, h2, h3, c.f(plan.bn_mean), c.f(plan.bn_rstd),
+                                     P[ix.bn_w()], fw1, fw2, P[ix.fc0_w()], P[ix.fc3_w()], P[ix.fc5_w()], P[ix.fc7_w()], dh3, dh2, dhb,
+                                     dh, dlogit, dpre, dcomb, G[ix.bn_w()], G[ix.bn_b()], c.f(plan.head_partial), B, d->training));
+        TRY(leaf_after(c));
+        head_leaves_pending = true;          // enqueued after the image branch's kernels: the host reaches those sooner
+    } else {
     // fc.7: out = h3 W7^T + b7
     TRY(linear_bwd_weight(cl, dout, 1, h3, H3, G[ix.fc7_w()], B, 1, H3));
     TRY(bbbp_bias_act_bwd(cl.st, const_cast<float*>(dout), 1, nullptr, 0, G[ix.fc7_b()], B, 1, 0, 1.f));   // act 0: dy untouched
@@ -574,7 +620,6 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
     TRY(linear_bwd_input(c, dh, H1, P[ix.fc0_w()], dfused, COMB, B, H1, COMB));
 
     // ---- attention fusion ------------------------------------------------------------------------
-    float* dlogit = c.f(plan.dlogit); float* dpre = c.f(plan.dpre);
     const float* w2[NHEADS_FUSION];
     for (int hh = 0; hh < NHEADS_FUSION; ++hh) w2[hh] = P[ix.fus(hh, 2)];
     TRY(bbbp_fusion_combine_bwd(c.st, dfused, comb, hid, c.f(plan.attn), w2, dcomb, dlogit, dpre, B, COMB, FUS_HID, NHEADS_FUSION));
@@ -597,6 +642,8 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
     TRY(leaf_after(c));
     TRY(bbbp_bias_act_bwd(cl.st, dcomb, COMB, nullptr, 0, G[ix.fpfc_b()], B, FC, 0, 1.f));
     TRY(bbbp_bias_act_bwd(cl.st, dcomb + FC, COMB, nullptr, 0, G[ix.ifc_b()], B, FC, 0, 1.f));
+
+    }
 
     // both branches only READ dcomb from here on
     if (ss) { TRY(after(ss, c.st, ce.st)); TRY(after(ss, c.st, cl.st)); }
@@ -633,6 +680,7 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
     TRY(bbbp_conv3x3_relu_pool_bwd_weight(c.st, image, dpool1, c.u8(plan.mask1), G[ix.c1_w()], G[ix.c1_b()], B, 3, C1, IMG, IMG,
                                           c.scratch(), c.scratch_bytes()));
     sec.reset();
+    if (head_leaves_pending) TRY(head_leaves());
 
     // ---- fingerprint branch: chain on `ce`, leaves on `cl` --------------------------------------------
     Section sec_encb(ce.st, SEC_ENCODER_BWD);

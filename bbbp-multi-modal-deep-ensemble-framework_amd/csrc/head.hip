@@ -272,6 +272,212 @@ __global__ __launch_bounds__(NTH) void head_b_kernel(HeadParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Backward of the same stretch (autograd of R:60-65, 98-107 under loss.backward(), R:190), input gradients only -- the
+// weight and bias gradients stay GEMM / column-sum leaves on the leaf stream and read the intermediates written here.
+// Two launches, split again where BatchNorm needs sums over the whole batch:
+//   head_bwd_a: dh3 = dout W7 (.) [h3 > 0];  dh2 = dh3 W5 (.) [h2 > 0];  dhb = dh2 W3;  per-block column sums of dhb and
+//               dhb * xhat for the BatchNorm backward
+//   head_bwd_c: merges those sums in block order (= dbeta, dgamma), dh = BatchNorm backward (.) [h > 0], dfused = dh W0,
+//               the fusion block's backward (dlogit, dpre through the Tanh), dcomb = dfused sum_h a_h + sum_h dpre_h W1_h,
+//               masked by the two branches' output ReLUs.
+// Input-gradient products contract over the weight's ROW index (Linear weight [out][in]), so the weight is the k-major
+// operand: a lane reads T consecutive columns of row k with one load and feeds T MFMAs (a wave owns T * 16 consecutive
+// output columns, column = base + T * (lane & 15) + u), the A operand (the block's rows) comes from LDS as in the forward.
+struct HeadBwdParams {
+    const float* dout;                                   // [B] (the loss gradient of out[B,1])
+    const float* comb; const float* hid; const float* attn; const float* h; const float* h2; const float* h3;
+    const float* bn_mean; const float* bn_rstd; const float* gamma;
+    const float* fw1[NHEADS]; const float* fw2[NHEADS];
+    const float* w0; const float* w3; const float* w5; const float* w7;
+    float* dh3; float* dh2; float* dhb; float* dh; float* dlogit; float* dpre; float* dcomb;
+    float* dgamma; float* dbeta;
+    float* partial;                                      // [blocks][2][256]: per-block sums of dhb * xhat and dhb
+    int B, training;
+};
+
+typedef float f32x2g __attribute__((ext_vector_type(2), aligned(4)));
+
+// acc[u] (16 rows x 16 columns base + T q + u) += A[16 x K] (LDS, row stride lda) * W[K][ldw] columns
+template <int K, int T>
+__device__ __forceinline__ void mma_kmajor(f32x4 (&acc)[T], const float* sA, int lda, const float* W, int ldw, int colbase, int lane) {
+    const int q = lane & 15, kq = lane >> 4;
+    const float* wcol = W + colbase + T * q;
+#pragma unroll 4
+    for (int c = 0; c < K / 16; ++c) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(sA + q * lda + 16 * c + 4 * kq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* wr = wcol + (long)(16 * c + 4 * kq + j) * ldw;
+            if constexpr (T == 2) {
+                const f32x2g b = *reinterpret_cast<const f32x2g*>(wr);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[1], acc[1], 0, 0, 0);
+            } else {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], wr[0], acc[0], 0, 0, 0);
+            }
+        }
+    }
+}
+
+constexpr int LD2 = H2 + 4, LD3 = H3 + 4, LDP = FHID + 4;
+
+__global__ __launch_bounds__(NTH) void head_bwd_a_kernel(HeadBwdParams p) {
+    __shared__ __attribute__((aligned(16))) float sD3[ROWS * LD3];        // dh3
+    __shared__ __attribute__((aligned(16))) float sD2[ROWS * LD2];        // dh2
+    __shared__ float sPa[4][H1], sPb[4][H1];                              // per row-quad column sums of dhb * xhat, dhb
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int q = lane & 15, kq = lane >> 4;
+    const int r0 = blockIdx.x * ROWS, nrows = min(ROWS, p.B - r0);
+    // ---- dh3 = dout W7, masked by fc.5's ReLU output ----
+    for (int idx = t; idx < ROWS * H3; idx += NTH) {
+        const int r = idx / H3, c = idx % H3;
+        float v = 0.f;
+        if (r < nrows) {
+            v = p.h3[(long)(r0 + r) * H3 + c] > 0.f ? p.dout[r0 + r] * p.w7[c] : 0.f;
+            p.dh3[(long)(r0 + r) * H3 + c] = v;
+        }
+        sD3[r * LD3 + c] = v;
+    }
+    __syncthreads();
+    // ---- dh2 = dh3 W5 (.) [h2 > 0]: 8 column tiles, one per wave ----
+    {
+        f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+        mma_kmajor<H3, 1>(acc, sD3, LD3, p.w5, H2, wave * 16, lane);
+        const int n = wave * 16 + q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * kq + r;
+            float v = 0.f;
+            if (row < nrows) {
+                v = p.h2[(long)(r0 + row) * H2 + n] > 0.f ? acc[0][r] : 0.f;
+                p.dh2[(long)(r0 + row) * H2 + n] = v;
+            }
+            sD2[row * LD2 + n] = v;
+        }
+    }
+    __syncthreads();
+    // ---- dhb = dh2 W3: 32 columns per wave; the block's column sums for the BatchNorm backward ----
+    {
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        mma_kmajor<H2, 2>(acc, sD2, LD2, p.w3, H1, wave * 32, lane);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int n = wave * 32 + 2 * q + u;
+            const float mu = p.bn_mean[n], rs = p.bn_rstd[n];
+            float pa = 0.f, pb = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * kq + r;
+                if (row < nrows) {
+                    const float g = acc[u][r];
+                    p.dhb[(long)(r0 + row) * H1 + n] = g;
+                    pa += g * (p.h[(long)(r0 + row) * H1 + n] - mu) * rs;
+                    pb += g;
+                }
+            }
+            sPa[kq][n] = pa; sPb[kq][n] = pb;
+        }
+    }
+    __syncthreads();
+    if (t < H1) {
+        p.partial[((long)blockIdx.x * 2 + 0) * H1 + t] = ((sPa[0][t] + sPa[1][t]) + sPa[2][t]) + sPa[3][t];       // fixed order
+        p.partial[((long)blockIdx.x * 2 + 1) * H1 + t] = ((sPb[0][t] + sPb[1][t]) + sPb[2][t]) + sPb[3][t];
+    }
+}
+
+__global__ __launch_bounds__(NTH) void head_bwd_c_kernel(HeadBwdParams p) {
+    __shared__ __attribute__((aligned(16))) float sX[ROWS * LD];                      // dh, later dfused, finally the unmasked dcomb
+    __shared__ __attribute__((aligned(16))) float sP[NHEADS * ROWS * LDP];            // dpre of the four heads
+    __shared__ float sSa[H1], sSb[H1];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int q = lane & 15, kq = lane >> 4;
+    const int r0 = blockIdx.x * ROWS, nrows = min(ROWS, p.B - r0);
+    const int nblocks = (p.B + ROWS - 1) / ROWS;
+    // ---- BatchNorm: sums over the batch, blocks merged in block order ----
+    if (t < H1) {
+        float sa = 0.f, sb = 0.f;
+        for (int b = 0; b < nblocks; ++b) { sa += p.partial[((long)b * 2 + 0) * H1 + t]; sb += p.partial[((long)b * 2 + 1) * H1 + t]; }
+        sSa[t] = sa; sSb[t] = sb;
+        if (blockIdx.x == 0) { p.dgamma[t] = sa; p.dbeta[t] = sb; }
+    }
+    __syncthreads();
+    // ---- dh = BatchNorm backward of dhb, masked by fc.0's ReLU output h ----
+    for (int idx = t; idx < ROWS * H1; idx += NTH) {
+        const int r = idx / H1, c = idx % H1;
+        float v = 0.f;
+        if (r < nrows) {
+            const float d = p.dhb[(long)(r0 + r) * H1 + c], xv = p.h[(long)(r0 + r) * H1 + c];
+            const float g = p.gamma[c], mu = p.bn_mean[c], rs = p.bn_rstd[c];
+            v = p.training ? g * rs * (d - sSb[c] / p.B - (xv - mu) * rs * (sSa[c] / p.B)) : d * g * rs;
+            v = xv > 0.f ? v : 0.f;
+            p.dh[(long)(r0 + r) * H1 + c] = v;
+        }
+        sX[r * LD + c] = v;
+    }
+    __syncthreads();
+    // ---- dfused = dh W0: 32 columns per wave (kept in registers until every wave has read dh) ----
+    f32x4 df[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    mma_kmajor<H1, 2>(df, sX, LD, p.w0, COMB, wave * 32, lane);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sX[(4 * kq + r) * LD + wave * 32 + 2 * q + u] = df[u][r];
+    __syncthreads();
+    // ---- fusion block backward, two rows per wave: dcomb0 = dfused sum_h a_h; dlogit_h = a_h (t - t sum_k a_k), t = dfused . comb;
+    //      dpre_h = dlogit_h w2_h (1 - hid_h^2) ----
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int r = wave * 2 + rr;
+        const bool live = r < nrows;
+        float a[NHEADS], asum = 0.f;
+#pragma unroll
+        for (int hh = 0; hh < NHEADS; ++hh) { a[hh] = live ? p.attn[(long)(r0 + r) * NHEADS + hh] : 0.f; asum += a[hh]; }
+        float tt = 0.f;
+#pragma unroll
+        for (int c = lane; c < COMB; c += 64) {
+            const float g = sX[r * LD + c];
+            tt += live ? g * p.comb[(long)(r0 + r) * COMB + c] : 0.f;
+            sX[r * LD + c] = g * asum;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tt += __shfl_xor(tt, o);
+#pragma unroll
+        for (int hh = 0; hh < NHEADS; ++hh) {
+            const float dl = a[hh] * (tt - tt * asum);
+            if (lane == 0 && live) p.dlogit[(long)hh * p.B + r0 + r] = dl;
+#pragma unroll
+            for (int c = lane; c < FHID; c += 64) {
+                float v = 0.f;
+                if (live) {
+                    const float y = p.hid[((long)hh * p.B + r0 + r) * FHID + c];
+                    v = dl * p.fw2[hh][c] * (1.f - y * y);
+                    p.dpre[((long)hh * p.B + r0 + r) * FHID + c] = v;
+                }
+                sP[(hh * ROWS + r) * LDP + c] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- dcomb = dcomb0 + sum_h dpre_h W1_h, masked by the ReLUs that produced combined = [fp_out | img_out] ----
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int hh = 0; hh < NHEADS; ++hh) mma_kmajor<FHID, 2>(acc, sP + hh * ROWS * LDP, LDP, p.fw1[hh], COMB, wave * 32, lane);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int n = wave * 32 + 2 * q + u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * kq + r;
+            if (row < nrows) {
+                const float v = acc[u][r] + sX[row * LD + n];
+                p.dcomb[(long)(r0 + row) * COMB + n] = p.comb[(long)(r0 + row) * COMB + n] > 0.f ? v : 0.f;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // Internal entry point (engine.hip): enqueue the fused fusion-block + head forward.  `partial` needs
@@ -295,6 +501,30 @@ int bbbp_head_forward_fused(hipStream_t st, const float* comb, const float* cons
     hipLaunchKernelGGL(head_a_kernel, dim3(blocks), dim3(NTH), 0, st, p);
     BBBP_CHECK_LAUNCH();
     hipLaunchKernelGGL(head_b_kernel, dim3(blocks), dim3(NTH), 0, st, p);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+// Internal entry point (engine.hip): the input-gradient chain of the head and fusion block in two launches.  Writes dh3, dh2,
+// dhb, dh, dlogit [4][B], dpre [4][B][128], dcomb [B][256] (masked by combined > 0) and the BatchNorm's dgamma / dbeta;
+// `partial` needs ceil(B / 16) * 2 * 256 floats.
+int bbbp_head_backward_fused(hipStream_t st, const float* dout, const float* comb, const float* hid, const float* attn, const float* h,
+                             const float* h2, const float* h3, const float* bn_mean, const float* bn_rstd, const float* gamma,
+                             const float* const* fw1, const float* const* fw2, const float* w0, const float* w3, const float* w5,
+                             const float* w7, float* dh3, float* dh2, float* dhb, float* dh, float* dlogit, float* dpre, float* dcomb,
+                             float* dgamma, float* dbeta, float* partial, int B, int training) {
+    BBBP_CHECK_ARG(B >= 1, "head backward: empty batch");
+    HeadBwdParams p;
+    p.dout = dout; p.comb = comb; p.hid = hid; p.attn = attn; p.h = h; p.h2 = h2; p.h3 = h3;
+    p.bn_mean = bn_mean; p.bn_rstd = bn_rstd; p.gamma = gamma;
+    for (int i = 0; i < NHEADS; ++i) { p.fw1[i] = fw1[i]; p.fw2[i] = fw2[i]; }
+    p.w0 = w0; p.w3 = w3; p.w5 = w5; p.w7 = w7;
+    p.dh3 = dh3; p.dh2 = dh2; p.dhb = dhb; p.dh = dh; p.dlogit = dlogit; p.dpre = dpre; p.dcomb = dcomb;
+    p.dgamma = dgamma; p.dbeta = dbeta; p.partial = partial; p.B = B; p.training = training;
+    const int blocks = cdiv(B, ROWS);
+    hipLaunchKernelGGL(head_bwd_a_kernel, dim3(blocks), dim3(NTH), 0, st, p);
+    BBBP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(head_bwd_c_kernel, dim3(blocks), dim3(NTH), 0, st, p);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }

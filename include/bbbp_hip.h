@@ -235,6 +235,9 @@ int bbbp_forest_predict(void* stream, const float* X, long n, int n_features, co
 /* ---- optional per-section timing (HIP events on the launch stream; used by bench.py's roofline leg) ----
  * enable(1), run steps, synchronise the stream, collect(ms_sum[n], count[n]) with n = num_sections(). */
 int bbbp_set_partition(int reserved_cus, size_t small_lds_pad);   /* CU partition knob, see csrc/common.h */
+/* The head / fusion-block input-gradient chain of bbbp_mixed_backward as two fused launches instead of ten (default off:
+ * measured neutral at B = 512, slower at B = 256).  Returns the previous setting.  Initial value: BBBP_FUSED_HEAD_BWD. */
+int bbbp_set_fused_head_bwd(int on);
 int bbbp_set_overlap(int on);   /* two/three-stream branch overlap inside bbbp_mixed_forward/backward (default on) */
 /* Data-parallel overlap: the gradient of the image-FC weight (62 % of all gradient bytes at F = 167) is final after the
  * first GEMM of the image branch's backward.  wait_bucket(stream, 0) makes `stream` wait for exactly that point of the

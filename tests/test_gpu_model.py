@@ -293,3 +293,32 @@ def test_stream_overlap_is_bit_identical_to_one_stream(dev, B, steps):
     a, b = run(True), run(False)
     assert torch.isfinite(a).all()
     assert torch.equal(a, b), f"max diff {float((a - b).abs().max()):.3e}"
+
+
+@pytest.mark.parametrize("B,training", [(37, True), (64, False), (512, True)])
+def test_fused_head_backward_matches_the_launch_per_op_chain(dev, B, training):
+    """csrc/head.hip's two-launch input-gradient chain of the head and fusion block (opt-in, bbbp_set_fused_head_bwd) gives the
+    gradients of the ten-launch chain: same math, different summation order (ragged last block, eval-mode BatchNorm included)."""
+    from bbbp_amd import _lib
+    L = _lib.lib()
+    F = 167
+    fp, img, y = synth_inputs(41, B, F, 49152)
+    m = build(F, 11, dev).train(training)
+    zero_dropout(m)                     # a fresh dropout seed per forward call would otherwise differ between the two passes
+    grads = []
+    for fused in (0, 1):
+        old = L.bbbp_set_fused_head_bwd(fused)
+        try:
+            m.zero_grad(set_to_none=True)
+            if training:
+                m.fc[2].running_mean.zero_(); m.fc[2].running_var.fill_(1.0)
+            bbbp_amd.MSELoss()(m(fp.to(dev), img.to(dev)).squeeze(), y.to(dev)).backward()
+            grads.append({k: p.grad.detach().cpu().double() for k, p in m.named_parameters()})
+        finally:
+            L.bbbp_set_fused_head_bwd(old)
+    for k in grads[0]:
+        if k.startswith("attention_fusion."):
+            continue                    # exact gradient 0: both return rounding noise (DESIGN.md section 4)
+        a, b = grads[1][k], grads[0][k]
+        tol = 2e-5 * float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), float(b.abs().max()))

@@ -40,5 +40,29 @@ def main():
             print(f"    {t / 1e3:9.1f} us  {n:4d} x {t / n / 1e3:8.2f} us  {name}")
 
 
+
+
+def sequence(path, which=None, lo_name="head_a_kernel", count=40):
+    """Kernel sequence of the queue that runs `lo_name`, from its first launch in the step: start offset, duration, gap."""
+    rows = list(csv.DictReader(open(path)))
+    for r in rows:
+        r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    rows.sort(key=lambda r: r["s"])
+    adam = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"]]
+    which = len(adam) - 2 if which is None else which
+    step = rows[adam[which] + 1:adam[which + 1] + 1]
+    t0 = step[0]["s"]
+    first = next(r for r in step if lo_name in r["Kernel_Name"])
+    ks = [r for r in step if r["Queue_Id"] == first["Queue_Id"] and r["s"] >= first["s"]][:count]
+    prev = None
+    for r in ks:
+        gap = (r["s"] - prev["e"]) / 1e3 if prev else 0.0
+        print(f"  +{(r['s'] - t0) / 1e3:8.1f} us  dur {(r['e'] - r['s']) / 1e3:8.1f}  gap {gap:7.1f}  {short(r['Kernel_Name'])}")
+        prev = r
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 3 and sys.argv[3] == "seq":
+        sequence(sys.argv[1], int(sys.argv[2]))
+    else:
+        main()
