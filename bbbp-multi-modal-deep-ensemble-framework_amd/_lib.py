@@ -103,6 +103,7 @@ _SIGNATURES = {
     "bbbp_profile_num_sections": (c_int, []),
     "bbbp_profile_section_name": (c_char_p, [c_int]),
     "bbbp_profile_collect": (c_int, [POINTER(c_float), POINTER(c_int)]),
+    "bbbp_profile_timeline": (c_int, [POINTER(c_int), POINTER(c_float), POINTER(c_float), c_int]),
     "bbbp_mixed_num_params": (c_int, [POINTER(MixedDesc)]),
     "bbbp_mixed_workspace_bytes": (c_size_t, [POINTER(MixedDesc)]),
     "bbbp_mixed_forward": (c_int, [c_void_p, POINTER(MixedDesc), _PP, _PP, _FP, _FP, _FP, c_void_p, c_size_t]),

@@ -383,6 +383,19 @@ extern "C" int bbbp_profile_collect(float* ms_sum, int* count) {
     return BBBP_OK;
 }
 
+// Absolute placement of the recorded section instances (does not clear them): start / end in ms after the first instance's
+// start.  Events of different streams share the device timeline, so the gaps between sections are visible.
+extern "C" int bbbp_profile_timeline(int* section, float* start_ms, float* end_ms, int max_entries) {
+    BBBP_CHECK_ARG(section && start_ms && end_ms && max_entries >= 0, "profile_timeline: bad arguments");
+    const int n = g_prof.n < max_entries ? g_prof.n : max_entries;
+    for (int i = 0; i < n; ++i) {
+        section[i] = g_prof.sec[i];
+        BBBP_CHECK_HIP(hipEventElapsedTime(&start_ms[i], g_prof.a[0], g_prof.a[i]));
+        BBBP_CHECK_HIP(hipEventElapsedTime(&end_ms[i], g_prof.a[0], g_prof.b[i]));
+    }
+    return n;
+}
+
 extern "C" int bbbp_mixed_num_params(const bbbp_mixed_desc* d) {
     if (!d) return -1;
     return PIdx(d->num_layers).count();

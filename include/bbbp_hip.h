@@ -257,6 +257,9 @@ int bbbp_profile_select(unsigned section_mask);   /* bit i = section i records e
 int bbbp_profile_num_sections(void);
 const char* bbbp_profile_section_name(int i);
 int bbbp_profile_collect(float* ms_sum, int* count);
+/* Before collect(): section id, start and end (ms after the first recorded section's start) of up to max_entries recorded
+ * section instances, in recording order; returns how many were written (or a negative error). */
+int bbbp_profile_timeline(int* section, float* start_ms, float* end_ms, int max_entries);
 
 #ifdef __cplusplus
 }
