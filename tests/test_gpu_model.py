@@ -322,3 +322,44 @@ def test_fused_head_backward_matches_the_launch_per_op_chain(dev, B, training):
         a, b = grads[1][k], grads[0][k]
         tol = 2e-5 * float(b.abs().max()) + 1e-12
         assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), float(b.abs().max()))
+
+
+@pytest.mark.parametrize("conv2_form", [0, 3], ids=["direct", "winograd"])
+def test_real_molecule_images_against_oracle(dev, conv2_form):
+    """The eight depictions shipped with the reference (tests/golden/img, white background: large flat regions, i.e. exact
+    ties inside pooling windows in BOTH conv stages) through the full model: output, loss and every gradient element against
+    the float64 oracle, for the direct and the Winograd form of conv2.  A mis-routed tie would show up in the conv gradients."""
+    import glob, os
+    from bbbp_amd import _lib
+    from oracle import preprocess_cpu
+    from helpers import GOLDEN
+    pngs = sorted(glob.glob(os.path.join(GOLDEN, "img", "*.png")))
+    assert len(pngs) == 8
+    img = torch.from_numpy(np.stack([preprocess_cpu.load_image_features(q) for q in pngs])).float()       # [8, 49152] in [0, 1]
+    B, F = img.shape[0], 167
+    g = torch.Generator().manual_seed(5)
+    fp = (torch.rand(B, F, generator=g) < 0.25).float()
+    y = torch.randn(B, generator=g) * 0.8 - 0.1
+    m = build(F, 13, dev)
+    zero_dropout(m)
+    m.train()
+    p = {k: (v.detach().cpu().double() if v.dtype.is_floating_point else v.detach().cpu()).clone()
+         .requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in m.state_dict().items()}
+    ref_out = oracle.mixed_input_forward(p, fp.double(), img.double(), training=True, bn_state={})
+    lo = oracle.mse_loss(ref_out, y.double())
+    lo.backward()
+    L = _lib.lib()
+    old = L.bbbp_get_conv_winograd()
+    _lib.check(L.bbbp_set_conv_winograd(conv2_form), "bbbp_set_conv_winograd")
+    try:
+        out = m(fp.to(dev), img.to(dev))
+        loss = torch.nn.MSELoss()(out.squeeze(), y.to(dev))
+        loss.backward()
+    finally:
+        L.bbbp_set_conv_winograd(old)
+    assert_close(out.detach().cpu().numpy().reshape(-1), ref_out.detach().numpy().reshape(-1), rtol=1e-4, atol_frac=1e-5, what="output")
+    assert abs(float(loss.detach()) - float(lo.detach())) <= 1e-4 * abs(float(lo.detach()))
+    for k, q in m.named_parameters():
+        if k.startswith(FUSION):
+            continue
+        assert_close(q.grad.cpu().numpy(), p[k].grad.numpy(), rtol=1e-4, atol_frac=5e-5, what=k)
