@@ -42,6 +42,7 @@ struct GemmParams {
     int splits, kchunk;      // split-K: K range per split (multiple of BK)
     float* slab;             // [batch][split][M][N] when splits > 1
     int vecA, vecB;          // 16-byte global loads allowed
+    int short_k;             // 128 x 128 tiles with 16-deep stages
     const float* gate; int ldg; long sG; float gate_scale;      // optional: result *= gate > 0 ? gate_scale : 0
     int gate_after;          // gate applied after the residual add
 };
@@ -74,10 +75,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 // LAYOUT 0: NT, 1: NN, 2: TN;  VEC: 16-byte global loads on both operands
-template <int BM, int BN, int LAYOUT, bool VEC>
+// BKT: k-depth of a stage (0 = bk_of(BM)).  16 instead of 32 halves the LDS of the 128 x 128 tile to 33 KB, so four
+// work-groups share a CU instead of two: for a short K (the image FC's input gradient, K = 128 = 4 stages of 32) the tile's
+// prologue, epilogue and exposed load latency then overlap with three other groups' MFMAs instead of one.
+template <int BM, int BN, int LAYOUT, bool VEC, int BKT = 0>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     BBBP_HIGH_PRIO();
-    constexpr int BK = bk_of(BM);
+    constexpr int BK = BKT ? BKT : bk_of(BM);
     constexpr bool A_KMAJ = (LAYOUT == 2);
     constexpr bool B_KMAJ = (LAYOUT != 0);
     // k-major global tiles land with 16-B stores (row stride % 4 == 0); m-major tiles are transposed with
@@ -588,22 +592,28 @@ bool launch_pair(const DirectParams& a, int la, int ta, const DirectParams& b, i
     return false;
 }
 
-template <int BM, int BN, int LAYOUT, bool VEC>
+template <int BM, int BN, int LAYOUT, bool VEC, int BKT = 0>
 void launch_one(const GemmParams& p, dim3 grid, hipStream_t st) {
-    constexpr int BK = bk_of(BM);
+    constexpr int BK = BKT ? BKT : bk_of(BM);
     constexpr size_t lds = (size_t)2 * BK * ((BM + (LAYOUT == 2 ? 4 : 1)) + (BN + (LAYOUT != 0 ? 4 : 1))) * sizeof(float);
     static bool attr_set = false;        // > 64 KB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, LAYOUT, VEC>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, LAYOUT, VEC, BKT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, LAYOUT, VEC>), grid, dim3(256), lds > g_bbbp_small_lds_pad ? lds : g_bbbp_small_lds_pad, st, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, LAYOUT, VEC, BKT>), grid, dim3(256), lds > g_bbbp_small_lds_pad ? lds : g_bbbp_small_lds_pad, st, p);
 }
 
 template <int BM, int BN>
 void launch_tile(const GemmParams& p, int layout, dim3 grid, hipStream_t st) {
     const bool vec = p.vecA && p.vecB;
+    if (BM == 128 && p.short_k && vec) {           // short K over a large output: four work-groups per CU (see the kernel)
+        if (layout == 0) launch_one<128, 128, 0, true, 16>(p, grid, st);
+        else if (layout == 1) launch_one<128, 128, 1, true, 16>(p, grid, st);
+        else launch_one<128, 128, 2, true, 16>(p, grid, st);
+        return;
+    }
     if (layout == 0) { if (vec) launch_one<BM, BN, 0, true>(p, grid, st); else launch_one<BM, BN, 0, false>(p, grid, st); }
     else if (layout == 1) { if (vec) launch_one<BM, BN, 1, true>(p, grid, st); else launch_one<BM, BN, 1, false>(p, grid, st); }
     else { if (vec) launch_one<BM, BN, 2, true>(p, grid, st); else launch_one<BM, BN, 2, false>(p, grid, st); }
@@ -721,6 +731,8 @@ int gemm_run(hipStream_t st, const bbbp_gemm_desc& g, void* workspace, size_t wo
         }
     }
     if (K == 0) { p.splits = 1; p.kchunk = bk_of(tile); }
+    static const int short_k_max = [] { const char* e = getenv("BBBP_GEMM_SHORT_K"); return e ? atoi(e) : 256; }();
+    p.short_k = (tile == 128 && p.splits == 1 && K <= short_k_max && (long)cdiv(M, 128) * cdiv(N, 128) * batch >= 4L * bbbp_num_cus()) ? 1 : 0;
     dim3 grid(cdiv(N, tile), cdiv(M, tile), batch * p.splits);
     BBBP_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
     if (tile == 128) launch_tile<128, 128>(p, layout, grid, st);

@@ -20,7 +20,9 @@ GEMM_SHAPES = [(512, 501, 167), (512, 167, 167), (512, 2048, 167), (512, 167, 20
                (33, 65, 17), (512, 128, 4096), (256, 256, 256), (130, 70, 9), (64, 64, 1),
                # the latency path: K slices inside a work-group, 2x2 sub-tiles, single / exact / ragged last chunk
                (512, 167, 512), (512, 167, 501), (2048, 167, 512), (40, 24, 16), (40, 24, 32), (40, 24, 33), (3, 5, 700),
-               (1024, 1024, 64)]
+               (1024, 1024, 64),
+               # short K over > 4 tiles per CU: the 128 x 128 tile with 16-deep stages (the image FC's input gradient)
+               (384, 49152, 128), (512, 33000, 100)]
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
