@@ -732,7 +732,9 @@ int gemm_run(hipStream_t st, const bbbp_gemm_desc& g, void* workspace, size_t wo
     }
     if (K == 0) { p.splits = 1; p.kchunk = bk_of(tile); }
     static const int short_k_max = [] { const char* e = getenv("BBBP_GEMM_SHORT_K"); return e ? atoi(e) : 256; }();
-    p.short_k = (tile == 128 && p.splits == 1 && K <= short_k_max && (long)cdiv(M, 128) * cdiv(N, 128) * batch >= 4L * bbbp_num_cus()) ? 1 : 0;
+    static const int short_k_tiles = [] { const char* e = getenv("BBBP_GEMM_SHORT_TILES"); return e ? atoi(e) : 4; }();
+    p.short_k = (tile == 128 && p.splits == 1 && K <= short_k_max &&
+                 (long)cdiv(M, 128) * cdiv(N, 128) * batch >= (long)short_k_tiles * bbbp_num_cus()) ? 1 : 0;
     dim3 grid(cdiv(N, tile), cdiv(M, tile), batch * p.splits);
     BBBP_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
     if (tile == 128) launch_tile<128, 128>(p, layout, grid, st);
