@@ -52,7 +52,7 @@ struct WinoCfg {
 };
 
 __device__ unsigned long long g_wino_clock[2];
-// phase breakdown of work-group 0 / wave 0 (PROBE builds only; tools/bench_conv2.py --probe): shader cycles spent in
+// phase breakdown of work-group 0 / wave 0 (PROBE instantiation, selected by BBBP_WINO_PROBE=1; printed by tools/bench_conv2.py): shader cycles spent in
 // [0] accumulator init, [1] k-steps (LDS reads, transforms, MFMAs), [2] stage hand-over (LDS writes + barrier), [3] output transform + stores
 __device__ unsigned long long g_wino_phase[4];
 
