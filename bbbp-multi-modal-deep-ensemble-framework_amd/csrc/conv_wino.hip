@@ -37,6 +37,7 @@ struct WinoParams {
     float* y;               // FWD: pooled [B][64][32][32];  DGRAD: [B][32][64][64]
     uint8_t* ymask;         // FWD
     int B;
+    int xcd_pairing;        // forward: pair the two channel blocks of a strip on one XCD
 };
 
 template <int MODE>
@@ -65,9 +66,14 @@ __device__ __forceinline__ void wino_conv_body(const WinoParams& p) {
     float* Us = smem;
     float* Xs = smem + UF;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, j = lane & 31, kh = lane >> 5;
-    const int cb = blockIdx.x % NCB;
+    // Work-groups are dealt to the 8 XCDs round-robin by id, and each XCD has its own L2.  The two channel blocks of a strip
+    // (forward) therefore go to ids w and w + 8: same XCD, resident together, so the second read of the strip is an L2 hit
+    // (ids w and w + 1 would fetch it from HBM into two L2s).  Needs a grid that is a multiple of 16; else plain pairing.
+    const bool xcd_pairs = NCB == 2 && (gridDim.x & 15) == 0 && p.xcd_pairing;
+    const int cb = NCB == 1 ? 0 : xcd_pairs ? (blockIdx.x >> 3) & 1 : blockIdx.x % NCB;
     const int nstrips = p.B * (IMG / 8);
-    const int first = blockIdx.x / NCB, stride = gridDim.x / NCB;
+    const int first = NCB == 1 ? blockIdx.x : xcd_pairs ? (blockIdx.x & 7) + 8 * (blockIdx.x >> 4) : blockIdx.x / NCB;
+    const int stride = gridDim.x / NCB;
 
     for (int i = t * 4; i < UF; i += 1024)
         *reinterpret_cast<float4*>(Us + i) = *reinterpret_cast<const float4*>(p.u + (size_t)cb * UF + i);
@@ -324,14 +330,15 @@ int bbbp_wino_conv2_fwd(hipStream_t st, const float* x, const float* w, const fl
                         float* workspace) {
     hipLaunchKernelGGL(wino_prep_kernel, dim3(128), dim3(256), 0, st, w, workspace, W_FWD);
     BBBP_CHECK_LAUNCH();
-    WinoParams p{x, nullptr, workspace, bias, y, mask, B};
+    static const int pairing = [] { const char* e = getenv("BBBP_WINO_XCD_PAIRS"); return e ? atoi(e) : 1; }();
+    WinoParams p{x, nullptr, workspace, bias, y, mask, B, pairing};
     return launch_wino<W_FWD>(p, st);
 }
 
 int bbbp_wino_conv2_dgrad(hipStream_t st, const float* gy, const uint8_t* gmask, const float* w, float* dx, int B, float* workspace) {
     hipLaunchKernelGGL(wino_prep_kernel, dim3(128), dim3(256), 0, st, w, workspace, W_DGRAD);
     BBBP_CHECK_LAUNCH();
-    WinoParams p{gy, gmask, workspace, nullptr, dx, nullptr, B};
+    WinoParams p{gy, gmask, workspace, nullptr, dx, nullptr, B, 0};
     return launch_wino<W_DGRAD>(p, st);
 }
 
