@@ -69,6 +69,11 @@ int bbbp_wino_conv2_dgrad(hipStream_t st, const float* gy, const uint8_t* gmask,
 int bbbp_wino_last_clock(unsigned long long* shader_cycles, unsigned long long* ticks_100mhz);
 int bbbp_wino_last_phases(unsigned long long* phases4);     // BBBP_WINO_PROBE=1 builds of the kernel only
 
+// Work-groups are dealt to the 8 XCDs round-robin by id and every XCD has its own L2.  Persistent kernels whose consecutive
+// work items share input rows (conv strips and their halos) map group w of n to logical index (w % 8) * (n / 8) + w / 8: the
+// groups of one XCD then hold consecutive items at the same time and the shared rows are L2 hits instead of second HBM reads.
+__device__ __forceinline__ int xcd_adjacent(int w, int n) { return (n & 7) ? w : (w & 7) * (n >> 3) + (w >> 3); }
+
 // exact f32 MFMA: D[32x32] += A[32x2] * B[2x32]; lane l holds A[l&31][l>>5], B[l>>5][l&31];
 // D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5) for register r of 16.
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {

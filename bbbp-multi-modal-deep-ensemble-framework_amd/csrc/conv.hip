@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
 
     f32x16 acc[MT][2];
 
-    int strip = blockIdx.x;
+    int strip = xcd_adjacent(blockIdx.x, gridDim.x);
     if (strip < nstrips) {
         load_stage(strip, 0);
         store_stage(strip, 0);
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(512) void conv_wgrad32_kernel(WgradParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    int strip = grp;
+    int strip = xcd_adjacent(grp, p.groups);       // groups % 8 == 0 keeps id % 8 == grp % 8 for every (channel block) pair; else identity
     if (strip < nstrips) { load_stage(strip); store_stage(0); }
     __syncthreads();
     int buf = 0;
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    int strip = grp;
+    int strip = xcd_adjacent(grp, p.groups);       // groups % 8 == 0 keeps id % 8 == grp % 8 for every (channel block) pair; else identity
     if (strip < nstrips) { load_stage(strip); store_stage(0); }
     __syncthreads();
     int buf = 0;

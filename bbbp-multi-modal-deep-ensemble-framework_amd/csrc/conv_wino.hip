@@ -72,8 +72,11 @@ __device__ __forceinline__ void wino_conv_body(const WinoParams& p) {
     const bool xcd_pairs = NCB == 2 && (gridDim.x & 15) == 0 && p.xcd_pairing;
     const int cb = NCB == 1 ? 0 : xcd_pairs ? (blockIdx.x >> 3) & 1 : blockIdx.x % NCB;
     const int nstrips = p.B * (IMG / 8);
-    const int first = NCB == 1 ? blockIdx.x : xcd_pairs ? (blockIdx.x & 7) + 8 * (blockIdx.x >> 4) : blockIdx.x / NCB;
     const int stride = gridDim.x / NCB;
+    // ... and consecutive strips (shared halo rows) to the groups of one XCD
+    const int first = NCB == 1 ? xcd_adjacent(blockIdx.x, gridDim.x)
+                    : xcd_pairs ? ((stride & 7) ? (blockIdx.x & 7) + 8 * (blockIdx.x >> 4) : (blockIdx.x & 7) * (stride >> 3) + (blockIdx.x >> 4))
+                    : blockIdx.x / NCB;
 
     for (int i = t * 4; i < UF; i += 1024)
         *reinterpret_cast<float4*>(Us + i) = *reinterpret_cast<const float4*>(p.u + (size_t)cb * UF + i);
