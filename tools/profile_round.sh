@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the per-round evidence on the GPU box: tools/profile_round.sh rNN   (writes gpurun_out/<rNN>_*; copy into profiles/)
-# rocprofv3 serialises kernels, so the kernel table shows every kernel ALONE; bench.py's own numbers are the in-situ ones.
+# The kernel table is collected with the branch overlap ON: its durations are in-step (in-situ) ones, like bench.py's sections.
 set -o pipefail
 R=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
