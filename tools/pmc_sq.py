@@ -1,0 +1,32 @@
+"""Matrix-pipe utilisation of the conv kernels from one rocprofv3 --pmc pass over SQ counters.
+
+    pmc_sq.py counter_collection.csv out.txt
+
+SQ_VALU_MFMA_BUSY_CYCLES is 64 cycles per v_mfma_f32_32x32x2_f32 summed over all SIMDs; GRBM_GUI_ACTIVE is summed over the
+8 XCDs; utilisation = MFMA_BUSY / (GUI_ACTIVE / 8 * 4 * CUs).  Counter collection serialises the dispatches."""
+import collections
+import csv
+import sys
+
+KERNELS = {"conv2_fwd (winograd)": "wino_conv_kernel<0>", "conv2_dgrad (winograd)": "wino_conv_kernel<1>", "conv2_wgrad": "conv_wgrad32_kernel",
+           "conv1_fwd": "conv3x3_kernel<3, 32", "conv1_wgrad": "conv_wgrad3_kernel", "conv2_fwd (direct)": "conv3x3_kernel<32, 64",
+           "conv2_dgrad (direct)": "conv3x3_kernel<64, 32"}
+CUS, XCDS = 256, 8
+
+
+def main():
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(sys.argv[1])):
+        for key, pat in KERNELS.items():
+            if pat in r["Kernel_Name"]:
+                acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    with open(sys.argv[2], "w") as out:
+        out.write("# " + __doc__.strip().replace("\n", "\n# ") + "\n")
+        for key, v in acc.items():
+            m = {c: sum(x) / len(x) for c, x in v.items()}
+            util = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (m["GRBM_GUI_ACTIVE"] / XCDS * 4 * CUS) if m.get("GRBM_GUI_ACTIVE") else float("nan")
+            out.write(f"{key}: mfma_pipe_utilisation={util:.3f} " + " ".join(f"{c}={x:.4g}" for c, x in sorted(m.items())) + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -13,5 +13,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${R}_write -- python3 bench
 cp $(find $O/${R}_fetch -name '*counter_collection.csv' | head -1) $O/${R}_pmc_fetch_size.csv
 cp $(find $O/${R}_write -name '*counter_collection.csv' | head -1) $O/${R}_pmc_write_size.csv
 python3 tools/pmc_traffic.py $O/${R}_pmc_fetch_size.csv $O/${R}_pmc_write_size.csv $O/${R}_pmc_traffic.json
-rm -rf $O/${R}_stats $O/${R}_fetch $O/${R}_write
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/${R}_sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/${R}_sq.log 2>&1 || exit 1
+python3 tools/pmc_sq.py $(find $O/${R}_sq -name '*counter_collection.csv' | head -1) $O/${R}_pmc_sq.txt
+rm -rf $O/${R}_stats $O/${R}_fetch $O/${R}_write $O/${R}_sq
 ls -la $O | grep ${R}_
