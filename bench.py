@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)      # 0.75 s of timed work: long enough for the clocks to settle
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-isolated", action="store_true",
+                    help="skip the untimed overlap-off leg (profiles: every launch of the rocprofv3 kernel table is then an in-step one)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -205,7 +207,8 @@ def main():
                 sections[names[i]] = ms_sum[i] / cnt[i]
     # ... and the same kernels with the branch overlap off, i.e. each conv kernel alone on the GPU
     isolated = {}
-    if rank == 0:
+    clock = {}
+    if rank == 0 and not args.no_isolated:
         old = L.bbbp_set_overlap(0)
         for i in range(2):
             step(i, collective=False)

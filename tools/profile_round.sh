@@ -6,7 +6,7 @@ R=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 python3 bench.py > $O/${R}_bench_n1.log 2>&1 && tail -1 $O/${R}_bench_n1.log > $O/${R}_bench_n1.json || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/${R}_stats.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-isolated > $O/${R}_stats.log 2>&1 || exit 1
 cp $(find $O/${R}_stats -name '*kernel_stats.csv' | head -1) $O/${R}_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${R}_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/${R}_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${R}_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/${R}_write.log 2>&1 || exit 1
