@@ -32,3 +32,20 @@ def test_bench_line_has_the_contract_fields():
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     # consistency: value = batch / step time
     assert abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) / d["value"] < 2e-3
+
+
+def test_rocprof_kernel_table_agrees_with_the_bench_line():
+    """The measurement contract: the rocprofv3 --kernel-trace --stats average of the roofline kernel agrees with the duration
+    bench.py measured with its own HIP events (profiles are collected by tools/profile_round.sh with --no-isolated, so every
+    launch in the table is an in-step one)."""
+    import csv
+    d = json.load(open(os.path.join(PROF, "r01_bench_n1.json")))
+    r = d["roofline"]
+    pattern = {"conv2_wgrad": "conv_wgrad32_kernel", "conv2_fwd": "wino_conv_kernel<0>", "conv2_dgrad": "wino_conv_kernel<1>"}[r["kernel"]]
+    rows = [x for x in csv.DictReader(open(os.path.join(PROF, "r01_kernel_stats.csv"))) if pattern in x["Name"]]
+    assert len(rows) == 1
+    avg_ms = float(rows[0]["AverageNs"]) * 1e-6
+    assert abs(avg_ms - r["ms_per_launch"]) <= 0.05 * r["ms_per_launch"], (avg_ms, r["ms_per_launch"])
+    # and the PMC traffic of that kernel is what the bench line reports
+    t = json.load(open(os.path.join(PROF, "r01_pmc_traffic.json")))
+    assert abs(t[r["kernel"]] - r["traffic"]) <= 0.05 * r["traffic"]
