@@ -5,7 +5,8 @@ Layout:  csrc/ (HIP kernels + the C ABI of include/bbbp_hip.h), _lib.py (ctypes 
 front end), models.py (the reference's nn.Module interface), optim.py (fused AdamW), ensemble.py (stacked
 predict surface), distributed.py (one process per GPU, RCCL gradient all-reduce).
 """
-from .models import MixedDataset, MixedInputModel, MSELoss, MultiHeadAttentionFusion, flatten_parameters, reference_nhead  # noqa: F401
+from .models import (ConcatMixedInputModel, MixedDataset, MixedInputModel, MSELoss, TwoBranchConcatModel,
+                     MultiHeadAttentionFusion, flatten_parameters, reference_nhead)  # noqa: F401
 from . import ops  # noqa: F401
 
-__all__ = ["MixedDataset", "MixedInputModel", "MSELoss", "MultiHeadAttentionFusion", "flatten_parameters", "reference_nhead", "ops"]
+__all__ = ["ConcatMixedInputModel", "TwoBranchConcatModel", "MixedDataset", "MixedInputModel", "MSELoss", "MultiHeadAttentionFusion", "flatten_parameters", "reference_nhead", "ops"]

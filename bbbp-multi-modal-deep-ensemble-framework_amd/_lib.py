@@ -21,7 +21,7 @@ class MixedDesc(Structure):
     """bbbp_mixed_desc (include/bbbp_hip.h)."""
     _fields_ = [("batch", c_int), ("fingerprint_size", c_int), ("nhead", c_int), ("num_layers", c_int),
                 ("dim_feedforward", c_int), ("training", c_int), ("dropout_p", c_float), ("seed", c_uint64),
-                ("need_input_grad", c_int)]
+                ("need_input_grad", c_int), ("fusion", c_int), ("inference", c_int)]
 
 
 class GemmDesc(Structure):

@@ -54,7 +54,7 @@ int bbbp_head_forward_fused(hipStream_t st, const float* comb, const float* cons
                             const float* beta, float* running_mean, float* running_var, const float* w3, const float* b3,
                             const float* w5, const float* b5, const float* w7, const float* b7, float* hid, float* attn, float* fused,
                             float* h, float* hb, float* bn_mean, float* bn_rstd, float* h2, float* h3, float* out, float* partial,
-                            int B, int training);
+                            int B, int training, int concat);
 // head.hip: the input-gradient chain of the head and fusion block backward (two launches); `partial` as above
 int bbbp_head_backward_fused(hipStream_t st, const float* dout, const float* comb, const float* hid, const float* attn, const float* h,
                              const float* h2, const float* h3, const float* bn_mean, const float* bn_rstd, const float* gamma,

@@ -20,8 +20,9 @@ constexpr int IMG_FLAT = C2 * (IMG / 4) * (IMG / 4);   // 65536
 // parameter indices in named_parameters() order
 enum { L_INW = 0, L_INB, L_OUTW, L_OUTB, L_W1, L_B1, L_W2, L_B2, L_N1W, L_N1B, L_N2W, L_N2B, L_COUNT };
 struct PIdx {
-    int L;
-    explicit PIdx(int layers) : L(layers) {}
+    int L, NF;             // NF: parameter tensors of the fusion block (16 for MultiHeadAttentionFusion, 0 for torch.cat)
+    PIdx(int layers, int fusion) : L(layers), NF(fusion == 0 ? 4 * NHEADS_FUSION : 0) {}
+    explicit PIdx(const bbbp_mixed_desc* d) : PIdx(d->num_layers, d->fusion) {}
     int layer(int l, int k) const { return l * L_COUNT + k; }
     int base() const { return L * L_COUNT; }
     int fpfc_w() const { return base() + 0; }
@@ -33,17 +34,17 @@ struct PIdx {
     int ifc_w() const { return base() + 6; }
     int ifc_b() const { return base() + 7; }
     int fus(int h, int k) const { return base() + 8 + h * 4 + k; }     // k: 0 W1, 1 b1, 2 w2, 3 b2
-    int fc0_w() const { return base() + 24; }
-    int fc0_b() const { return base() + 25; }
-    int bn_w() const { return base() + 26; }
-    int bn_b() const { return base() + 27; }
-    int fc3_w() const { return base() + 28; }
-    int fc3_b() const { return base() + 29; }
-    int fc5_w() const { return base() + 30; }
-    int fc5_b() const { return base() + 31; }
-    int fc7_w() const { return base() + 32; }
-    int fc7_b() const { return base() + 33; }
-    int count() const { return base() + 34; }
+    int fc0_w() const { return base() + 8 + NF; }
+    int fc0_b() const { return base() + 9 + NF; }
+    int bn_w() const { return base() + 10 + NF; }
+    int bn_b() const { return base() + 11 + NF; }
+    int fc3_w() const { return base() + 12 + NF; }
+    int fc3_b() const { return base() + 13 + NF; }
+    int fc5_w() const { return base() + 14 + NF; }
+    int fc5_b() const { return base() + 15 + NF; }
+    int fc7_w() const { return base() + 16 + NF; }
+    int fc7_b() const { return base() + 17 + NF; }
+    int count() const { return base() + 18 + NF; }
 };
 
 struct Bump {
@@ -59,7 +60,7 @@ struct LayerGrad { size_t dyout, dz2, dz2d, dhff, dy1, dz1, dz1d, dqkv; };
 
 struct Plan {
     int B, F, NH, D, L, DFF;
-    bool drop;
+    bool drop, concat, inference;
     LayerOff layer[32];
     LayerGrad lgrad[32];
     size_t scratch3, scratch3_bytes;
@@ -80,6 +81,9 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     BBBP_CHECK_ARG(d->num_layers >= 0 && d->num_layers <= 32, "num_layers %d not in [0, 32]", d->num_layers);
     BBBP_CHECK_ARG(d->dim_feedforward >= 1, "dim_feedforward");
     BBBP_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f, "dropout_p %f", d->dropout_p);
+    BBBP_CHECK_ARG(d->fusion == 0 || d->fusion == 1, "fusion %d (0 attention fusion, 1 concat)", d->fusion);
+    BBBP_CHECK_ARG(!(d->inference && d->training), "an inference workspace cannot serve a training-mode call");
+    p->concat = d->fusion == 1; p->inference = d->inference != 0;
     p->B = d->batch; p->F = d->fingerprint_size; p->NH = d->nhead; p->D = p->F / p->NH; p->L = d->num_layers;
     p->DFF = d->dim_feedforward;
     p->drop = d->training && d->dropout_p > 0.f;
@@ -88,6 +92,9 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     p->seed_slot = b.take(256);
     for (int l = 0; l < p->L; ++l) {
         LayerOff& o = p->layer[l];
+        // forward only: nothing is kept for a backward pass, every layer runs in layer 0's buffers (layer l reads its input
+        // y2 before it writes y2 again: qkv <- y2, y1 <- LN(z1 + y2), y2 <- LN(z2 + y1))
+        if (p->inference && l > 0) { o = p->layer[0]; continue; }
         o.qkv = b.f(B * 3 * F); o.prob = b.f(NH * B * B); o.ctx = b.f(B * F);
         // dropped attention weights are KEPT per layer (1 MB at B = 512, one head) rather than recomputed in backward:
         // every launch on the encoder's chain costs more than the bytes
@@ -98,7 +105,7 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     p->pool1 = b.f(B * C1 * (IMG / 2) * (IMG / 2)); p->mask1 = b.take(B * C1 * (IMG / 2) * (IMG / 2));
     p->pool2 = b.f(B * IMG_FLAT); p->mask2 = b.take(B * IMG_FLAT);
     p->combined = b.f(B * COMB); p->hid = b.f(NHEADS_FUSION * B * FUS_HID); p->attn = b.f(B * NHEADS_FUSION);
-    p->fused = b.f(B * COMB); p->h = b.f(B * H1); p->hb = b.f(B * H1); p->bn_mean = b.f(H1); p->bn_rstd = b.f(H1);
+    p->fused = p->concat ? p->combined : b.f(B * COMB); p->h = b.f(B * H1); p->hb = b.f(B * H1); p->bn_mean = b.f(H1); p->bn_rstd = b.f(H1);
     p->h2 = b.f(B * H2); p->h3 = b.f(B * H3);
     p->head_partial = b.f(((B + 15) / 16) * 2 * H1);
     size_t cw = bbbp_conv3x3_workspace_bytes(p->B, 32, 64, 64, 64);
@@ -112,6 +119,7 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     // the fingerprint branch runs on its own stream beside the image branch: it needs its own split-K scratch
     p->scratch2_bytes = (size_t)32 << 20;
     p->scratch2 = b.take(p->scratch2_bytes);
+    if (p->inference) { p->total = b.off; return BBBP_OK; }
     // backward temporaries
     for (int l = 0; l < p->L; ++l) {
         LayerGrad& g = p->lgrad[l];
@@ -398,7 +406,8 @@ extern "C" int bbbp_profile_timeline(int* section, float* start_ms, float* end_m
 
 extern "C" int bbbp_mixed_num_params(const bbbp_mixed_desc* d) {
     if (!d) return -1;
-    return PIdx(d->num_layers).count();
+    if (d->num_layers < 0 || d->num_layers > 32 || (d->fusion != 0 && d->fusion != 1)) return -1;
+    return PIdx(d).count();
 }
 
 extern "C" size_t bbbp_mixed_workspace_bytes(const bbbp_mixed_desc* d) {
@@ -419,7 +428,7 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         return BBBP_ERR_WORKSPACE;
     }
     Ctx c{static_cast<hipStream_t>(stream), static_cast<char*>(workspace), &plan};
-    const PIdx ix(plan.L);
+    const PIdx ix(d);
     const int B = plan.B, F = plan.F, NH = plan.NH, D = plan.D, DFF = plan.DFF;
     const float p_drop = plan.drop ? d->dropout_p : 0.f;
     const float scale = 1.0f / sqrtf((float)D);
@@ -493,25 +502,28 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
 
     static const int fused_head = [] { const char* e = getenv("BBBP_FUSED_HEAD"); return e ? atoi(e) : 1; }();
     if (fused_head && NHEADS_FUSION == 4) {
-        // fusion block + head in two launches (head.hip)
-        const float *fw1[4], *fb1[4], *fw2[4], *fb2[4];
-        for (int h = 0; h < 4; ++h) { fw1[h] = P[ix.fus(h, 0)]; fb1[h] = P[ix.fus(h, 1)]; fw2[h] = P[ix.fus(h, 2)]; fb2[h] = P[ix.fus(h, 3)]; }
+        // fusion block + head in two launches (head.hip); with torch.cat fusion the first launch starts at fc.0
+        const float *fw1[4] = {}, *fb1[4] = {}, *fw2[4] = {}, *fb2[4] = {};
+        if (!plan.concat)
+            for (int h = 0; h < 4; ++h) { fw1[h] = P[ix.fus(h, 0)]; fb1[h] = P[ix.fus(h, 1)]; fw2[h] = P[ix.fus(h, 2)]; fb2[h] = P[ix.fus(h, 3)]; }
         return bbbp_head_forward_fused(c.st, comb, fw1, fb1, fw2, fb2, P[ix.fc0_w()], P[ix.fc0_b()], P[ix.bn_w()], P[ix.bn_b()],
                                        bn_running[0], bn_running[1], P[ix.fc3_w()], P[ix.fc3_b()], P[ix.fc5_w()], P[ix.fc5_b()],
                                        P[ix.fc7_w()], P[ix.fc7_b()], c.f(plan.hid), c.f(plan.attn), c.f(plan.fused), c.f(plan.h),
                                        c.f(plan.hb), c.f(plan.bn_mean), c.f(plan.bn_rstd), c.f(plan.h2), c.f(plan.h3), out,
-                                       c.f(plan.head_partial), B, d->training);
+                                       c.f(plan.head_partial), B, d->training, plan.concat ? 1 : 0);
     }
     // ---- attention fusion (R:60-65, 117) -------------------------------------------------------
     float* hid = c.f(plan.hid);
-    const float* w2[NHEADS_FUSION]; const float* b2[NHEADS_FUSION];
-    for (int h = 0; h < NHEADS_FUSION; ++h) {
-        TRY(linear_fwd(c, comb, COMB, P[ix.fus(h, 0)], P[ix.fus(h, 1)], hid + (size_t)h * B * FUS_HID, FUS_HID, B, FUS_HID, COMB,
-                       BBBP_ACT_TANH));
-        w2[h] = P[ix.fus(h, 2)]; b2[h] = P[ix.fus(h, 3)];
+    float* fused = c.f(plan.fused);              // == combined under torch.cat fusion
+    if (!plan.concat) {
+        const float* w2[NHEADS_FUSION]; const float* b2[NHEADS_FUSION];
+        for (int h = 0; h < NHEADS_FUSION; ++h) {
+            TRY(linear_fwd(c, comb, COMB, P[ix.fus(h, 0)], P[ix.fus(h, 1)], hid + (size_t)h * B * FUS_HID, FUS_HID, B, FUS_HID, COMB,
+                           BBBP_ACT_TANH));
+            w2[h] = P[ix.fus(h, 2)]; b2[h] = P[ix.fus(h, 3)];
+        }
+        TRY(bbbp_fusion_combine_fwd(c.st, comb, hid, w2, b2, fused, c.f(plan.attn), B, COMB, FUS_HID, NHEADS_FUSION));
     }
-    float* fused = c.f(plan.fused);
-    TRY(bbbp_fusion_combine_fwd(c.st, comb, hid, w2, b2, fused, c.f(plan.attn), B, COMB, FUS_HID, NHEADS_FUSION));
 
     // ---- regression head (R:98-107, 118) -------------------------------------------------------
     float* h = c.f(plan.h); float* hb = c.f(plan.hb); float* h2 = c.f(plan.h2); float* h3 = c.f(plan.h3);
@@ -531,6 +543,7 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
     TRY(make_plan(d, &plan));
     SeedScope seed_scope(reinterpret_cast<const unsigned long long*>(static_cast<char*>(workspace) + plan.seed_slot));
     BBBP_CHECK_ARG(P && G && fingerprint && image && dout && workspace, "mixed_backward: null pointer");
+    BBBP_CHECK_ARG(!plan.inference, "mixed_backward: the forward call used an inference workspace (desc.inference = 1)");
     if (workspace_bytes < plan.total) {
         bbbp_set_error("mixed_backward: workspace %zu < %zu bytes", workspace_bytes, plan.total);
         return BBBP_ERR_WORKSPACE;
@@ -550,7 +563,7 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         cl.st = ss->leaf; cl.side = 2;
     }
     auto leaf_after = [&](const Ctx& producer) -> int { return ss ? after(ss, producer.st, cl.st) : BBBP_OK; };
-    const PIdx ix(plan.L);
+    const PIdx ix(d);
     const int B = plan.B, F = plan.F, NH = plan.NH, D = plan.D, DFF = plan.DFF;
     const float p_drop = plan.drop ? d->dropout_p : 0.f;
     const float inv_keep = plan.drop ? 1.f / (1.f - p_drop) : 1.f;
@@ -568,7 +581,7 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
     // opt-in (bbbp_set_fused_head_bwd / BBBP_FUSED_HEAD_BWD=1): measured neutral at B = 512 (the head section shrinks 0.126 ->
     // 0.070 ms but the step does not: the leaves it feeds finish no earlier) and slower at B = 256
     if (g_fused_head_bwd < 0) { const char* e = getenv("BBBP_FUSED_HEAD_BWD"); g_fused_head_bwd = e ? atoi(e) != 0 : 0; }
-    const int fused_head_bwd = g_fused_head_bwd;
+    const int fused_head_bwd = g_fused_head_bwd && !plan.concat;
     float* dlogit = c.f(plan.dlogit); float* dpre = c.f(plan.dpre);
     bool head_leaves_pending = false;
     auto head_leaves = [&]() -> int {
@@ -580,7 +593,7 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         TRY(linear_bwd_weight(cl, dh2, H2, hb, H1, G[ix.fc3_w()], B, H2, H1));
         TRY(bbbp_bias_act_bwd(cl.st, dh, H1, nullptr, 0, G[ix.fc0_b()], B, H1, 0, 1.f));
         TRY(linear_bwd_weight(cl, dh, H1, fused, COMB, G[ix.fc0_w()], B, H1, COMB));
-        for (int hh = 0; hh < NHEADS_FUSION; ++hh) {
+        for (int hh = 0; hh < (plan.concat ? 0 : NHEADS_FUSION); ++hh) {
             float* dl = dlogit + (size_t)hh * B;
             float* dp = dpre + (size_t)hh * B * FUS_HID;
             const float* hd = hid + (size_t)hh * B * FUS_HID;
@@ -630,6 +643,12 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
     TRY(leaf_after(c));
     TRY(bbbp_bias_act_bwd(cl.st, dh, H1, nullptr, 0, G[ix.fc0_b()], B, H1, 0, 1.f));
     TRY(linear_bwd_weight(cl, dh, H1, fused, COMB, G[ix.fc0_w()], B, H1, COMB));
+    if (plan.concat) {
+        // torch.cat fusion: dcomb = dh W0, masked by the ReLUs that produced combined = [fp_out | img_out]
+        bbbp_gemm_desc g = gemm_desc(0, 0, B, COMB, H1, 1.f, dh, H1, P[ix.fc0_w()], COMB, dcomb, COMB);
+        g.gate = comb; g.ldg = COMB;
+        TRY(bbbp_gemm_f32_grouped(c.st, &g, 1, c.scratch(), c.scratch_bytes()));
+    } else {
     TRY(linear_bwd_input(c, dh, H1, P[ix.fc0_w()], dfused, COMB, B, H1, COMB));
 
     // ---- attention fusion ------------------------------------------------------------------------
@@ -650,6 +669,7 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         g.residual = dcomb; g.ldr = COMB;
         if (hh == NHEADS_FUSION - 1) { g.gate = comb; g.ldg = COMB; g.gate_after_residual = 1; }
         TRY(bbbp_gemm_f32_grouped(c.st, &g, 1, c.scratch(), c.scratch_bytes()));
+    }
     }
     // bias gradients of the two branch outputs: column sums of the masked dcomb, leaves
     TRY(leaf_after(c));
@@ -849,7 +869,7 @@ extern "C" int bbbp_mixed_backward_wait_bucket(void* stream, int bucket) {
 }
 extern "C" int bbbp_mixed_bucket_param(const bbbp_mixed_desc* d, int bucket) {
     if (!d || bucket != 0) return -1;
-    return PIdx(d->num_layers).ifc_w();
+    return PIdx(d).ifc_w();
 }
 
 extern "C" int bbbp_set_graphs(int on) { const int old = graphs_mode(); g_graphs_mode = on ? 1 : 0; return old; }
@@ -877,7 +897,7 @@ extern "C" int bbbp_mixed_forward(void* stream, const bbbp_mixed_desc* d, const 
                            reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + plan.seed_slot), (unsigned long long)d->seed);
         BBBP_CHECK_LAUNCH();
     }
-    const int np = PIdx(d->num_layers).count();
+    const int np = PIdx(d).count();
     uint64_t h = hash_ptrs(reinterpret_cast<const void* const*>(P), np);
     h = hash_ptrs(reinterpret_cast<const void* const*>(bn_running), 2, h);
     const GraphKey key = make_key(0, d, fingerprint, image, out, workspace, h);
@@ -897,7 +917,7 @@ extern "C" int bbbp_mixed_backward(void* stream, const bbbp_mixed_desc* d, const
         return BBBP_ERR_WORKSPACE;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int np = PIdx(d->num_layers).count();
+    const int np = PIdx(d).count();
     uint64_t h = hash_ptrs(reinterpret_cast<const void* const*>(P), np);
     h = hash_ptrs(reinterpret_cast<const void* const*>(G), np, h);
     const GraphKey key = make_key(1, d, fingerprint, image, dout, workspace, h);

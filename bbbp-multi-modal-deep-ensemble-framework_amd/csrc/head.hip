@@ -37,6 +37,7 @@ struct HeadParams {
     float* partial;                                      // [blocks][2][256]: per-block mean and M2 of h
     int B, training;
     float eps, momentum;
+    int concat;                                          // 1: fused = combined (torch.cat fusion), the fusion block is skipped
 };
 
 // B fragments of one 16-column tile: W rows n = 16 * tile + (lane & 15), k = 16c + 4 (lane >> 4) .. +3
@@ -94,6 +95,10 @@ __global__ __launch_bounds__(NTH) void head_a_kernel(HeadParams p) {
     float lg[NHEADS][4];
     f32x4 bf[2][COMB / 16];
     const int n = wave * 16 + q;
+    if (p.concat) {
+        // torch.cat fusion (Descriptors/..._round_2_transformer_cnn.py:99): `fused` IS `combined`; straight to fc.0
+        load_b<COMB / 16>(bf[0], p.w0 + (long)n * COMB + 4 * kq);
+    } else {
     load_b<COMB / 16>(bf[0], p.fw1[0] + (long)n * COMB + 4 * kq);
 #pragma unroll
     for (int h = 0; h < NHEADS; ++h) {
@@ -150,6 +155,7 @@ __global__ __launch_bounds__(NTH) void head_a_kernel(HeadParams p) {
     }
     __syncthreads();
     load_a<COMB / 16>(af, sC, LD, lane);
+    }
     // ---- fc.0 + ReLU, and the block's (mean, M2) per column for the BatchNorm: 16 tiles, 2 per wave ----
     // (bf[0] already holds this wave's first fc.0 tile: it was requested under the last fusion tile)
 #pragma unroll
@@ -487,7 +493,7 @@ int bbbp_head_forward_fused(hipStream_t st, const float* comb, const float* cons
                             const float* beta, float* running_mean, float* running_var, const float* w3, const float* b3,
                             const float* w5, const float* b5, const float* w7, const float* b7, float* hid, float* attn, float* fused,
                             float* h, float* hb, float* bn_mean, float* bn_rstd, float* h2, float* h3, float* out, float* partial,
-                            int B, int training) {
+                            int B, int training, int concat) {
     BBBP_CHECK_ARG(B >= 1, "head: empty batch");
     BBBP_CHECK_ARG(!(training && B <= 1), "Expected more than 1 value per channel when training, got input size [%d, %d]", B, H1);
     HeadParams p;
@@ -496,7 +502,7 @@ int bbbp_head_forward_fused(hipStream_t st, const float* comb, const float* cons
     p.w0 = w0; p.b0 = b0; p.gamma = gamma; p.beta = beta; p.running_mean = running_mean; p.running_var = running_var;
     p.w3 = w3; p.b3 = b3; p.w5 = w5; p.b5 = b5; p.w7 = w7; p.b7 = b7;
     p.hid = hid; p.attn = attn; p.fused = fused; p.h = h; p.hb = hb; p.bn_mean = bn_mean; p.bn_rstd = bn_rstd; p.h2 = h2; p.h3 = h3;
-    p.out = out; p.partial = partial; p.B = B; p.training = training; p.eps = 1e-5f; p.momentum = 0.1f;
+    p.out = out; p.partial = partial; p.B = B; p.training = training; p.eps = 1e-5f; p.momentum = 0.1f; p.concat = concat;
     const int blocks = cdiv(B, ROWS);
     hipLaunchKernelGGL(head_a_kernel, dim3(blocks), dim3(NTH), 0, st, p);
     BBBP_CHECK_LAUNCH();

@@ -105,10 +105,12 @@ class _HeadHidden(torch.autograd.Function):
         return (dcomb, *dw1, *db1)
 
 
-def attention_fusion(module, x1, x2):
-    """MultiHeadAttentionFusion.forward (Models/...20250113.py:60-65) on the HIP ops."""
+def attention_fusion(module, x1, x2, heads=None):
+    """MultiHeadAttentionFusion.forward (Models/...20250113.py:60-65) on the HIP ops.  ``heads`` overrides the list of
+    Linear/Tanh/Linear scorers (the single-head AttentionFusion of ..._rdkit.py:53-66 is the one-head case: its softmax runs
+    over a size-1 dimension, so the weight is exactly 1 and its scorer's gradients exactly 0)."""
     combined = torch.cat((x1, x2), dim=1).contiguous()
-    heads = module.attention_heads
+    heads = module.attention_heads if heads is None else heads
     w1 = [h[0].weight for h in heads]; b1 = [h[0].bias for h in heads]
     w2 = [h[2].weight for h in heads]; b2 = [h[2].bias for h in heads]
     hid = _HeadHidden.apply(combined, *w1, *b1)

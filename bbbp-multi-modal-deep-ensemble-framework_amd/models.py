@@ -115,17 +115,22 @@ class _MixedFn(torch.autograd.Function):
     """One autograd node for the whole model: forward and backward are single C-ABI calls."""
 
     @staticmethod
-    def forward(ctx, model, fingerprint, image, *params):
+    def forward(ctx, model, inference, fingerprint, image, *params):
         L = _lib.lib()
         B = fingerprint.shape[0]
-        desc = model._descriptor(B)
+        desc = model._descriptor(B, inference)
         ws_bytes = L.bbbp_mixed_workspace_bytes(ctypes.byref(desc))
         if ws_bytes == 0:
             _lib.check(1, "bbbp_mixed_workspace_bytes")
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=fingerprint.device)
         out = torch.empty((B, 1), dtype=torch.float32, device=fingerprint.device)
+        if not params or any(p.dtype != torch.float32 or p.device != fingerprint.device for p in params):
+            raise RuntimeError("the HIP kernels are float32-only: every parameter must be float32 on the inputs' device "
+                               f"({fingerprint.device}); undo .half()/.double() or move the model")
         pp = _cached_ptrs(model, "_pp", params)
         bn = model.fc[2]
+        if any(b.dtype != torch.float32 or b.device != fingerprint.device for b in (bn.running_mean, bn.running_var)):
+            raise RuntimeError("BatchNorm running statistics must be float32 on the inputs' device")
         bnp = _cached_ptrs(model, "_bnp", (bn.running_mean, bn.running_var))
         _lib.check(L.bbbp_mixed_forward(ops._stream(), ctypes.byref(desc), pp, bnp, fingerprint.data_ptr(), image.data_ptr(),
                                         out.data_ptr(), ws.data_ptr(), ws_bytes), "bbbp_mixed_forward")
@@ -151,13 +156,16 @@ class _MixedFn(torch.autograd.Function):
         _lib.check(L.bbbp_mixed_backward(ops._stream(), ctypes.byref(ctx.desc), ctx.pp, gp, fingerprint.data_ptr(),
                                          image.data_ptr(), dout.data_ptr(), ctx.ws.data_ptr(), ctx.ws_bytes),
                    "bbbp_mixed_backward")
-        return (None, None, None, *grads)
+        return (None, None, None, None, *grads)
 
 
 class MixedInputModel(nn.Module):
     """Drop-in for the reference ``MixedInputModel`` (…20250113.py:68-119): 6-layer post-norm
     Transformer encoder over the fingerprint (attending across the mini-batch), 2-stage conv/ReLU/pool
     CNN over the 3x128x128 image, attention fusion and a BatchNorm regression head."""
+
+    NUM_LAYERS = 6            # encoder depth; 0 = no encoder (fingerprint_fc reads the fingerprint itself)
+    FUSION = "attention"      # "attention": MultiHeadAttentionFusion(256, 4); "concat": torch.cat of the branch outputs
 
     def __init__(self, fingerprint_size, image_feature_size):
         super().__init__()
@@ -166,14 +174,16 @@ class MixedInputModel(nn.Module):
         self.nhead = reference_nhead(self.fingerprint_size)
         F, S = self.fingerprint_size, self.image_feature_size
         # same modules, same creation order as the reference => same state_dict keys and RNG stream
-        self.fingerprint_transformer = nn.TransformerEncoder(
-            nn.TransformerEncoderLayer(d_model=F, nhead=self.nhead), num_layers=6, enable_nested_tensor=False)
+        if self.NUM_LAYERS > 0:
+            self.fingerprint_transformer = nn.TransformerEncoder(
+                nn.TransformerEncoderLayer(d_model=F, nhead=self.nhead), num_layers=self.NUM_LAYERS, enable_nested_tensor=False)
         self.fingerprint_fc = nn.Sequential(nn.Linear(F, 128), nn.ReLU())
         self.image_cnn = nn.Sequential(
             nn.Conv2d(3, 32, kernel_size=3, stride=1, padding=1), nn.ReLU(), nn.MaxPool2d(kernel_size=2, stride=2),
             nn.Conv2d(32, 64, kernel_size=3, stride=1, padding=1), nn.ReLU(), nn.MaxPool2d(kernel_size=2, stride=2),
             nn.Flatten(), nn.Linear(64 * (S // 4) * (S // 4), 128), nn.ReLU())
-        self.attention_fusion = MultiHeadAttentionFusion(256, num_heads=4)
+        if self.FUSION == "attention":
+            self.attention_fusion = MultiHeadAttentionFusion(256, num_heads=4)
         self.fc = nn.Sequential(nn.Linear(256, 256), nn.ReLU(), nn.BatchNorm1d(256), nn.Linear(256, 128), nn.ReLU(),
                                 nn.Linear(128, 64), nn.ReLU(), nn.Linear(64, 1))
         if S != 128:
@@ -192,20 +202,22 @@ class MixedInputModel(nn.Module):
         flat = flat_view_of(params)
         return flat if flat is not None else flatten_parameters(self)
 
-    def _descriptor(self, batch: int) -> _lib.MixedDesc:
-        layer0 = self.fingerprint_transformer.layers[0]
-        p = float(layer0.dropout.p)
-        for m in (layer0.dropout1, layer0.dropout2):
-            if float(m.p) != p:
-                raise RuntimeError("encoder dropout probabilities must agree")
-        if float(layer0.self_attn.dropout) != p:
-            raise RuntimeError("attention dropout must equal the layer dropout")
+    def _descriptor(self, batch: int, inference: bool = False) -> _lib.MixedDesc:
+        p, dff, layers = 0.0, 2048, 0
+        if self.NUM_LAYERS > 0:
+            layers = len(self.fingerprint_transformer.layers)
+            layer0 = self.fingerprint_transformer.layers[0]
+            p, dff = float(layer0.dropout.p), layer0.linear1.out_features
+            for m in (layer0.dropout1, layer0.dropout2):
+                if float(m.p) != p:
+                    raise RuntimeError("encoder dropout probabilities must agree")
+            if float(layer0.self_attn.dropout) != p:
+                raise RuntimeError("attention dropout must equal the layer dropout")
         training = bool(self.training)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (training and p > 0) else 0
-        return _lib.MixedDesc(batch=batch, fingerprint_size=self.fingerprint_size, nhead=self.nhead,
-                              num_layers=len(self.fingerprint_transformer.layers),
-                              dim_feedforward=layer0.linear1.out_features, training=int(training), dropout_p=p,
-                              seed=seed, need_input_grad=0)
+        return _lib.MixedDesc(batch=batch, fingerprint_size=self.fingerprint_size, nhead=self.nhead, num_layers=layers,
+                              dim_feedforward=dff, training=int(training), dropout_p=p, seed=seed, need_input_grad=0,
+                              fusion=0 if self.FUSION == "attention" else 1, inference=int(inference and not training))
 
     def forward(self, fingerprint, image):
         if not fingerprint.is_cuda:
@@ -219,10 +231,31 @@ class MixedInputModel(nn.Module):
         fingerprint = fingerprint.to(torch.float32).contiguous()
         image = image.to(torch.float32).contiguous()
         params = list(self.parameters())
-        out = _MixedFn.apply(self, fingerprint, image, *params)
+        # forward-only calls (torch.no_grad(), eval loops, screening) take the small inference workspace
+        inference = not (torch.is_grad_enabled() and any(p.requires_grad for p in params))
+        out = _MixedFn.apply(self, inference, fingerprint, image, *params)
         if self.training:
             self.fc[2].num_batches_tracked += 1
         return out
+
+
+class ConcatMixedInputModel(MixedInputModel):
+    """Drop-in for the earliest Transformer+CNN ``MixedInputModel``
+    (Descriptors/multi_input_data_regression_opt_round_2_transformer_cnn.py:45-102): same encoder, ``fingerprint_fc`` and CNN as
+    the flagship, but the branch outputs are fused by a plain ``torch.cat`` (:99) -- there is no ``attention_fusion`` block and
+    no such ``state_dict`` keys.  Runs on the same fused engine (``bbbp_mixed_desc.fusion = 1``)."""
+    FUSION = "concat"
+
+
+class TwoBranchConcatModel(MixedInputModel):
+    """BASELINE config 2: MACCS ``Linear(F,128)+ReLU`` + the 2-stage image CNN + ``torch.cat`` + BatchNorm regression head.
+    NO exact reference script exists for it: it is the class above
+    (Descriptors/multi_input_data_regression_opt_round_2_transformer_cnn.py:45-102) with the encoder omitted, i.e. its
+    ``forward`` lines :95-101 without :91-92; ``state_dict`` keys are that class's minus ``fingerprint_transformer.*``, so
+    ``two.load_state_dict({k: v for k, v in full.state_dict().items() if not k.startswith("fingerprint_transformer.")})``
+    carries weights over.  Engine: ``num_layers = 0``, ``fusion = 1``."""
+    NUM_LAYERS = 0
+    FUSION = "concat"
 
 
 class _MSEFn(torch.autograd.Function):

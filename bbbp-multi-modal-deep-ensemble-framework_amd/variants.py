@@ -5,6 +5,8 @@ the HIP GEMM / BatchNorm / dropout / fusion ops through per-op autograd nodes.
 * ``PCAFusionModel``  -- Models/multi_input_data_regression_opt_transformer_cnn_opt.py:72-105 (also _morgan.py):
   PCA-reduced fingerprint and image each through Linear+ReLU, attention fusion, 256->128->64->1.  This is the
   architecture of the shipped ``best_nn_model*.pth``.
+* ``RdkitPCAFusionModel`` -- Models/multi_input_data_regression_opt_transformer_cnn_rdkit.py:53-105: the same with the
+  single-head ``AttentionFusion``.
 * ``DenseMLPModel``   -- Models/multi_input_data_regression_opt.py:41-85: raw fingerprint F->512->256->128 and raw image
   49152->1024->256->128 with ReLU -> BatchNorm1d -> Dropout(0.2), concat, BatchNorm head.
 """
@@ -28,6 +30,45 @@ class PCAFusionModel(nn.Module):
         self.fingerprint_fc = nn.Sequential(nn.Linear(fingerprint_size, 128), nn.ReLU())
         self.image_fc = nn.Sequential(nn.Linear(image_feature_size, 128), nn.ReLU())
         self.attention_fusion = MultiHeadAttentionFusion(256)
+        self.fc = nn.Sequential(nn.Linear(256, 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU(), nn.Linear(64, 1))
+        flatten_parameters(self)
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        flatten_parameters(self)
+        return out
+
+    def forward(self, fingerprint, image):
+        _need_cuda(fingerprint)
+        a = run_sequential(self.fingerprint_fc, fingerprint.float().contiguous())
+        b = run_sequential(self.image_fc, image.float().contiguous())
+        return run_sequential(self.fc, self.attention_fusion(a, b))
+
+
+class AttentionFusion(nn.Module):
+    """Single-head fusion block of Models/multi_input_data_regression_opt_transformer_cnn_rdkit.py:53-66:
+    ``Linear(input_dim,128) -> Tanh -> Linear(128,1) -> Softmax(dim=1)`` then ``weights * combined``.  The softmax normalises
+    a size-1 dimension, so ``weights == 1`` whatever the scorer says: output = ``cat(x1, x2)`` exactly, scorer gradients are
+    exact zeros.  Same parameter container (``attention.{0,2}.*`` keys) as the reference."""
+
+    def __init__(self, input_dim):
+        super().__init__()
+        self.attention = nn.Sequential(nn.Linear(input_dim, 128), nn.Tanh(), nn.Linear(128, 1), nn.Softmax(dim=1))
+
+    def forward(self, x1, x2):
+        from .functional import attention_fusion
+        return attention_fusion(self, x1, x2, heads=[self.attention])
+
+
+class RdkitPCAFusionModel(nn.Module):
+    """``MixedInputModel`` of Models/multi_input_data_regression_opt_transformer_cnn_rdkit.py:69-105: the PCA-MLP fusion
+    model above with the single-head ``AttentionFusion``."""
+
+    def __init__(self, fingerprint_size, image_feature_size):
+        super().__init__()
+        self.fingerprint_fc = nn.Sequential(nn.Linear(fingerprint_size, 128), nn.ReLU())
+        self.image_fc = nn.Sequential(nn.Linear(image_feature_size, 128), nn.ReLU())
+        self.attention_fusion = AttentionFusion(256)
         self.fc = nn.Sequential(nn.Linear(256, 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU(), nn.Linear(64, 1))
         flatten_parameters(self)
 

@@ -173,6 +173,8 @@ int bbbp_standardize_chunk(void* stream, const uint8_t* fingerprint_u8, const fl
  *   fingerprint_fc.0.{weight,bias}; image_cnn.{0,3,7}.{weight,bias};
  *   attention_fusion.attention_heads.h.{0.weight,0.bias,2.weight,2.bias} for h in 0..3;
  *   fc.0.{w,b}, fc.2.{w,b} (BatchNorm affine), fc.3.{w,b}, fc.5.{w,b}, fc.7.{w,b}
+ * num_layers = 0 drops the encoder (fingerprint_fc reads the fingerprint itself): with fusion = 1 that is BASELINE
+ * config 2, the two-branch MACCS-Linear + image-CNN + concat + BatchNorm-head model.
  * grads[]: same order, written (not accumulated).  bn_running: {running_mean, running_var} of fc.2.
  * The workspace carries the saved activations from forward to backward. */
 typedef struct {
@@ -185,6 +187,11 @@ typedef struct {
     float dropout_p;      /* 0.1 in the encoder when training */
     uint64_t seed;        /* dropout stream of this step */
     int need_input_grad;  /* unused by the reference (inputs do not require grad) */
+    int fusion;           /* 0: MultiHeadAttentionFusion(256, 4 heads) (R:48-65); 1: plain torch.cat of the two branch outputs
+                             (Descriptors/multi_input_data_regression_opt_round_2_transformer_cnn.py:99) -- the 16
+                             attention_fusion.* entries are then absent from params[] / grads[] */
+    int inference;        /* 1: forward only (torch.no_grad()): the workspace omits every backward temporary and the encoder
+                             layers share one set of activation buffers; bbbp_mixed_backward refuses such a workspace */
 } bbbp_mixed_desc;
 
 int bbbp_mixed_num_params(const bbbp_mixed_desc* d);

@@ -108,6 +108,15 @@ def attention_fusion(x1: torch.Tensor, x2: torch.Tensor, p: Params, prefix: str,
     return torch.sum(w * combined.unsqueeze(1), dim=1)
 
 
+def attention_fusion_single(x1: torch.Tensor, x2: torch.Tensor, p: Params, prefix: str) -> torch.Tensor:
+    """Single-head AttentionFusion, Models/multi_input_data_regression_opt_transformer_cnn_rdkit.py:53-66:
+    Linear(256,128) -> Tanh -> Linear(128,1) -> Softmax(dim=1) over a size-1 dimension (weights == 1), ``weights * combined``."""
+    combined = torch.cat((x1, x2), dim=1)
+    hid = torch.tanh(F.linear(combined, p[prefix + "attention.0.weight"], p[prefix + "attention.0.bias"]))
+    w = torch.softmax(F.linear(hid, p[prefix + "attention.2.weight"], p[prefix + "attention.2.bias"]), dim=1)   # [B, 1]
+    return w * combined
+
+
 def batchnorm1d(x: torch.Tensor, p: Params, prefix: str, training: bool,
                 bn_state: Optional[Dict[str, torch.Tensor]] = None,
                 momentum: float = 0.1, eps: float = 1e-5) -> torch.Tensor:
@@ -138,8 +147,11 @@ def batchnorm1d(x: torch.Tensor, p: Params, prefix: str, training: bool,
 def mixed_input_forward(p: Params, fingerprint: torch.Tensor, image: torch.Tensor, *,
                         training: bool = False, num_layers: int = 6,
                         bn_state: Optional[Dict[str, torch.Tensor]] = None,
-                        parts: Optional[dict] = None) -> torch.Tensor:
+                        parts: Optional[dict] = None, fusion: str = "attention") -> torch.Tensor:
     """MixedInputModel.forward(fingerprint[B,F], image[B,49152]) -> [B,1].
+    ``fusion="concat"`` is the earliest variant, Descriptors/multi_input_data_regression_opt_round_2_transformer_cnn.py:89-102
+    (plain torch.cat, no attention_fusion parameters); with ``num_layers=0`` on top, BASELINE config 2 (that class without
+    its encoder; no exact reference script).
     ``training`` only selects the BatchNorm1d statistics (dropout is the identity in the oracle).
     ``parts`` (optional dict) receives the intermediate activations for per-op parity tests."""
     Fdim = fingerprint.shape[1]
@@ -150,7 +162,12 @@ def mixed_input_forward(p: Params, fingerprint: torch.Tensor, image: torch.Tenso
     p1 = conv3x3_relu_pool(img, p["image_cnn.0.weight"], p["image_cnn.0.bias"])
     p2 = conv3x3_relu_pool(p1, p["image_cnn.3.weight"], p["image_cnn.3.bias"])
     img_out = F.relu(F.linear(p2.flatten(1), p["image_cnn.7.weight"], p["image_cnn.7.bias"]))
-    fused = attention_fusion(fp_out, img_out, p, "attention_fusion.")
+    if fusion == "attention":
+        fused = attention_fusion(fp_out, img_out, p, "attention_fusion.")
+    elif fusion == "concat":
+        fused = torch.cat((fp_out, img_out), dim=1)
+    else:
+        raise ValueError(fusion)
     h = F.relu(F.linear(fused, p["fc.0.weight"], p["fc.0.bias"]))
     hb = batchnorm1d(h, p, "fc.2.", training, bn_state)
     h2 = F.relu(F.linear(hb, p["fc.3.weight"], p["fc.3.bias"]))
@@ -171,10 +188,12 @@ def mse_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
 # a17: PCA-MLP fusion model (Models/multi_input_data_regression_opt_transformer_cnn_opt.py:72-105);
 # this is the architecture of the shipped best_nn_model*.pth
 # --------------------------------------------------------------------------------------------
-def pca_mlp_forward(p: Params, fingerprint: torch.Tensor, image: torch.Tensor) -> torch.Tensor:
+def pca_mlp_forward(p: Params, fingerprint: torch.Tensor, image: torch.Tensor, single_head: bool = False) -> torch.Tensor:
+    """``single_head=True``: the _rdkit.py variant (Models/multi_input_data_regression_opt_transformer_cnn_rdkit.py:69-105),
+    same layers around the single-head AttentionFusion."""
     a = F.relu(F.linear(fingerprint, p["fingerprint_fc.0.weight"], p["fingerprint_fc.0.bias"]))
     b = F.relu(F.linear(image, p["image_fc.0.weight"], p["image_fc.0.bias"]))
-    fused = attention_fusion(a, b, p, "attention_fusion.")
+    fused = attention_fusion_single(a, b, p, "attention_fusion.") if single_head else attention_fusion(a, b, p, "attention_fusion.")
     h = F.relu(F.linear(fused, p["fc.0.weight"], p["fc.0.bias"]))
     h = F.relu(F.linear(h, p["fc.2.weight"], p["fc.2.bias"]))
     return F.linear(h, p["fc.4.weight"], p["fc.4.bias"])

@@ -170,9 +170,9 @@ def test_train_mode_dropout_is_active_and_seeded(dev):
 
 
 def test_headline_batch_properties(dev):
-    """B = 512 (BASELINE config 3): the oracle is too slow to check every element cheaply, so use
-    size-independent properties: the image branch is per-sample (a permutation of the batch permutes its
-    features), the fingerprint branch is permutation-EQUIVARIANT (attention across the batch), and a B = 512 call
+    """B = 512 (BASELINE config 3), size-independent properties on top of the element-wise oracle comparison in
+    test_gpu_parity_sizes.py: the image branch is per-sample (a permutation of the batch permutes its
+    features), the fingerprint branch is permutation-EQUIVARIANT (attention across the batch), and the same model
     agrees with the oracle on a 16-sample sub-batch run at B = 16."""
     m = build(167, 20250113, dev).eval()
     B = 512

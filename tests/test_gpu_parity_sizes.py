@@ -1,0 +1,115 @@
+"""GPU: parity at the sizes that are BENCHMARKED (BASELINE configs 3 and 5) and of the optimizer against the reference's own
+AdamW trajectory -- the small-batch goldens and oracle checks in test_gpu_model.py cover every code path, these cover the
+grids, partitions and slab counts that only exist at full size."""
+import numpy as np
+import pytest
+import torch
+
+import bbbp_amd
+from bbbp_amd import _lib
+from oracle import reference_cpu as oracle
+from helpers import assert_close, check_summary_adam, golden, synth_inputs
+from test_gpu_model import FUSION, build, zero_dropout
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_params(m, double=True):
+    return {k: ((v.detach().cpu().double() if double else v.detach().cpu()) if v.dtype.is_floating_point else v.detach().cpu()).clone()
+            .requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in m.state_dict().items()}
+
+
+@pytest.mark.parametrize("conv2_form", [3, 0], ids=["winograd", "direct"])
+def test_headline_batch_fwd_bwd_against_oracle(dev, conv2_form):
+    """BASELINE config 3 exactly as bench.py runs it (B = 512, F = 167, train mode, branch overlap ON, the 192-CU Winograd
+    partition or the direct conv2 form) with dropout 0: output, loss, BatchNorm running statistics and EVERY element of
+    every non-degenerate gradient against the float64 oracle."""
+    L = _lib.lib()
+    B, F = 512, 167
+    m = build(F, 20250113, dev)
+    zero_dropout(m)
+    m.train()
+    fp, img, y = synth_inputs(512512, B, F, 49152)
+    p = oracle_params(m)
+    st = {}
+    ref_out = oracle.mixed_input_forward(p, fp.double(), img.double(), training=True, bn_state=st)
+    ref_loss = oracle.mse_loss(ref_out, y.double())
+    ref_loss.backward()
+    old_w, old_o = L.bbbp_get_conv_winograd(), L.bbbp_set_overlap(1)
+    _lib.check(L.bbbp_set_conv_winograd(conv2_form), "bbbp_set_conv_winograd")
+    try:
+        out = m(fp.to(dev), img.to(dev))
+        loss = bbbp_amd.MSELoss()(out.squeeze(), y.to(dev))
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        L.bbbp_set_conv_winograd(old_w)
+        L.bbbp_set_overlap(old_o)
+    assert_close(out.detach().cpu().numpy(), ref_out.detach().numpy(), rtol=1e-4, atol_frac=2e-5, what="B=512 train output")
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-4 * abs(float(ref_loss.detach()))
+    sd = m.state_dict()
+    for k in ("fc.2.running_mean", "fc.2.running_var"):
+        assert_close(sd[k].cpu().numpy(), st[k].numpy(), rtol=1e-4, what=k)
+    for k, q in m.named_parameters():
+        if not k.startswith(FUSION):
+            assert_close(q.grad.cpu().numpy(), p[k].grad.numpy(), rtol=1e-4, atol_frac=5e-5, what=k)
+
+
+def test_screening_batch_4096_eval_and_screen(dev):
+    """BASELINE config 5 at its stated size: eval-mode forward at B = 4096 (attention rows of 4096, the inference workspace)
+    against the oracle, and ensemble.screen with batch_size = 4096 over 4096 + 40 molecules (network + random forest +
+    precomputed column through the shipped linear meta-learner) against the column-wise reference."""
+    ens = pytest.importorskip("sklearn.ensemble")
+    from bbbp_amd.ensemble import StackedEnsemble, screen
+    from bbbp_amd.trees import ForestGPU
+    B, tail, F = 4096, 40, 167
+    n = B + tail
+    m = build(F, 20250113, dev).eval()
+    fp, img, _ = synth_inputs(4096, n, F, 49152)
+    p = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        got = m(fp[:B].to(dev), img[:B].to(dev)).cpu().numpy()
+        want = np.concatenate([oracle.mixed_input_forward(p, fp[:B], img[:B], training=False).numpy(),
+                               oracle.mixed_input_forward(p, fp[B:], img[B:], training=False).numpy()])
+    assert_close(got, want[:B], rtol=1e-4, atol_frac=2e-5, what="B=4096 eval")
+    rs = np.random.RandomState(5)
+    feats = np.hstack([fp.numpy(), img.numpy()])
+    rf = ens.RandomForestRegressor(n_estimators=6, max_depth=5, max_features=64, random_state=42).fit(feats[:96], rs.randn(96))
+    xgb_col = rs.randn(n)
+    stack = StackedEnsemble.from_coefficients([0.19813994153864287, 0.8730076113813537, 0.16470120078934247], 0.019492486407121146)
+    out = screen(m, ForestGPU.from_sklearn(rf, device=dev), stack, fp.to(dev), img.to(dev), extra_columns=(xgb_col,), batch_size=B)
+    ref = stack.predict(np.stack([want.reshape(-1).astype(np.float64), rf.predict(feats), xgb_col], axis=1))
+    # the network column carries the 1e-4 tolerance; the forest and the stack arithmetic are exact to float64 rounding
+    scale = float(np.abs(ref).max())
+    assert np.abs(out.cpu().numpy() - ref).max() <= 0.2 * (1e-4 * scale + 2e-5 * float(np.abs(want).max())) + 1e-9
+
+
+def test_hip_adamw_follows_the_reference_trajectory(dev):
+    """The reference's own three AdamW steps (torch.optim.AdamW(lr 1e-4, wd 1e-5) on the reference class, B = 7, goldens
+    adamw/B7/step{1,3} of tests/golden/flagship_f167.npz) with the HIP forward/backward and the fused bbbp_adamw_step:
+    losses, parameters after steps 1 and 3, BatchNorm running statistics -- same bands as the CPU oracle is held to."""
+    from bbbp_amd.optim import AdamW
+    from test_oracle_golden import adam_noise_amplified
+    g = golden("flagship_f167")
+    B, F = 7, 167
+    m = build(F, 20250113, dev)
+    zero_dropout(m)
+    m.train()
+    opt = AdamW(m.parameters(), lr=1e-4, weight_decay=1e-5)
+    fp, img, y = (t.to(dev) for t in synth_inputs(1000 + B, B, F, 49152))
+    for step in range(1, 4):
+        opt.zero_grad(set_to_none=True)
+        loss = bbbp_amd.MSELoss()(m(fp, img).squeeze(), y)
+        loss.backward()
+        opt.step()
+        want = float(g[f"adamw/B{B}/step{step}/loss"])
+        assert abs(float(loss.detach()) - want) <= (1e-4 if step == 1 else 3e-3) * abs(want), (step, float(loss.detach()), want)
+        if step in (1, 3):
+            for k, q in m.named_parameters():
+                if not adam_noise_amplified(k):
+                    check_summary_adam(g, f"adamw/B{B}/step{step}/{k}", q, lr=1e-4, steps=step,
+                                       tight_lr_frac=0.02 if step == 1 else 0.6, min_frac=0.9 if step == 1 else 0.75)
+            sd = m.state_dict()
+            for k in ("fc.2.running_mean", "fc.2.running_var"):
+                assert_close(sd[k].cpu().numpy(), g[f"adamw/B{B}/step{step}/bn/{k}"], rtol=2e-4 if step == 1 else 5e-3, what=k)
+    assert opt.state[next(iter(m.parameters()))]["step"] == 3

@@ -235,3 +235,108 @@ def test_wide_deep_variant_golden():
     for k in ("fc.0.weight", "image_cnn.6.weight", "image_cnn.10.weight", "fingerprint_transformer.layers.11.linear1.weight",
               "attention_fusion.cross_modal_attention.2.weight", "fc.12.weight"):
         check_summary(g, f"train/B5/{k}", p[k].grad, rtol=2e-4, atol_frac=1e-4)
+
+
+def _filtered(sd, drop_prefix="fingerprint_transformer."):
+    return {k: v for k, v in sd.items() if not k.startswith(drop_prefix)}
+
+
+def test_concat_variant_golden():
+    """Earliest Transformer+CNN class (Descriptors/multi_input_data_regression_opt_round_2_transformer_cnn.py:45-102: torch.cat
+    fusion, no attention_fusion block): seeded init of the product's module tree and the oracle's fusion="concat" path."""
+    g = golden("concat_f167")
+    torch.manual_seed(20250102)
+    m = bbbp_amd.ConcatMixedInputModel(167, 128)
+    check_param_checksums(g, m.state_dict())
+    assert not any(k.startswith("attention_fusion") for k in m.state_dict())
+    p = named(m)
+    fp, img, _ = synth_inputs(1002, 2, 167, 49152)
+    with torch.no_grad():
+        assert_close(oracle.mixed_input_forward(p, fp, img, training=False, fusion="concat").numpy(), g["eval/B2/out"], rtol=1e-5, what="concat eval")
+    fp, img, y = synth_inputs(1007, 7, 167, 49152)
+    st = {}
+    out = oracle.mixed_input_forward(p, fp, img, training=True, bn_state=st, fusion="concat")
+    oracle.mse_loss(out, y).backward()
+    assert_close(out.detach().numpy(), g["train/B7/out"], rtol=1e-5, what="concat train")
+    for k, _ in m.named_parameters():
+        check_summary(g, f"train/B7/{k}", p[k].grad, rtol=2e-4)
+
+
+def test_two_branch_config2_golden():
+    """BASELINE config 2 (the class above without its encoder; tools/make_golden.py:drop_encoder): key set, weights carried
+    over from the seeded full class, oracle (num_layers=0, fusion="concat") vs the golden up to the config's batch 256,
+    and three AdamW steps."""
+    g = golden("two_branch_f167")
+    torch.manual_seed(20250102)
+    full = bbbp_amd.ConcatMixedInputModel(167, 128)
+    m = bbbp_amd.TwoBranchConcatModel(167, 128)
+    m.load_state_dict(_filtered(full.state_dict()), strict=True)
+    check_param_checksums(g, m.state_dict())
+    assert sum(q.numel() for q in m.parameters()) == 8_537_153       # 21504 + 896 + 18496 + 8388736 + head 107521
+    p = named(m)
+    for B in (2, 7):
+        fp, img, _ = synth_inputs(1000 + B, B, 167, 49152)
+        with torch.no_grad():
+            out = oracle.mixed_input_forward(p, fp, img, training=False, num_layers=0, fusion="concat")
+        assert_close(out.numpy(), g[f"eval/B{B}/out"], rtol=1e-5, what=f"two-branch eval B{B}")
+    for B in (7, 256):
+        for k in p:
+            p[k].grad = None
+        fp, img, y = synth_inputs(1000 + B, B, 167, 49152)
+        st = {}
+        out = oracle.mixed_input_forward(p, fp, img, training=True, bn_state=st, num_layers=0, fusion="concat")
+        loss = oracle.mse_loss(out, y)
+        loss.backward()
+        assert_close(out.detach().numpy(), g[f"train/B{B}/out"], rtol=1e-5, what=f"two-branch train B{B}")
+        assert abs(float(loss.detach()) - float(g[f"train/B{B}/loss"])) <= 1e-5 * abs(float(g[f"train/B{B}/loss"]))
+        for k in ("fc.2.running_mean", "fc.2.running_var"):
+            assert_close(st[k].numpy(), g[f"train/B{B}/bn/{k}"], rtol=1e-5, what=k)
+        for k, _ in m.named_parameters():
+            check_summary(g, f"train/B{B}/{k}", p[k].grad, rtol=2e-4, atol_frac=1e-4 if k.startswith("image_cnn.") else 2e-5)
+    # AdamW
+    keys = [k for k, _ in m.named_parameters()]
+    for k in keys:
+        p[k].grad = None
+    state = {k: (torch.zeros_like(p[k]), torch.zeros_like(p[k])) for k in keys}
+    fp, img, y = synth_inputs(1007, 7, 167, 49152)
+    for step in range(1, 4):
+        for k in keys:
+            p[k].grad = None
+        st = {}
+        oracle.mse_loss(oracle.mixed_input_forward(p, fp, img, training=True, bn_state=st, num_layers=0, fusion="concat"), y).backward()
+        with torch.no_grad():
+            for k in keys:
+                oracle.adamw_step(p[k], p[k].grad, state[k][0], state[k][1], step)
+            for k, v in st.items():
+                p[k] = v
+        if step in (1, 3):
+            for k in keys:
+                if k != "fc.0.bias":
+                    check_summary_adam(g, f"adamw/B7/step{step}/{k}", p[k], lr=1e-4, steps=step,
+                                       tight_lr_frac=0.02 if step == 1 else 0.6, min_frac=0.9 if step == 1 else 0.75)
+
+
+def test_rdkit_single_head_fusion_golden():
+    """_rdkit.py variant: PCA-MLP with the single-head AttentionFusion (softmax over a size-1 dim): seeded init of the
+    product's module tree, oracle vs the golden, and the scorer's gradients are exact zeros in the reference too."""
+    from bbbp_amd.variants import RdkitPCAFusionModel
+    g = golden("rdkit_pca")
+    torch.manual_seed(3)
+    m = RdkitPCAFusionModel(128, 256)
+    check_param_checksums(g, m.state_dict())
+    assert "attention_fusion.attention.0.weight" in m.state_dict() and "attention_fusion.attention.2.bias" in m.state_dict()
+    p = named(m)
+    for B in (1, 9):
+        fp, img, _ = synth_inputs(1000 + B, B, 128, 256)
+        with torch.no_grad():
+            assert_close(oracle.pca_mlp_forward(p, fp, img, single_head=True).numpy(), g[f"eval/B{B}/out"], rtol=1e-5, what=f"rdkit B{B}")
+    fp, img, y = synth_inputs(1006, 6, 128, 256)
+    out = oracle.pca_mlp_forward(p, fp, img, single_head=True)
+    oracle.mse_loss(out, y).backward()
+    assert_close(out.detach().numpy(), g["train/B6/out"], rtol=1e-5, what="rdkit train")
+    for k, _ in m.named_parameters():
+        if k.startswith(FUSION):
+            assert float(g[f"train/B6/{k}/stats"][1]) == 0.0, k          # reference: exact zero gradient
+            assert p[k].grad is None or float(p[k].grad.abs().sum()) == 0.0
+        else:
+            check_summary(g, f"train/B6/{k}", p[k].grad, rtol=2e-4)

@@ -69,8 +69,22 @@ def synth_inputs(seed: int, B: int, F: int, I: int):
     return fp, img, y
 
 
+def drop_encoder(model: nn.Module):
+    """BASELINE config 2 (no exact reference script): the reference's round-2 Transformer+CNN class with its
+    encoder removed -- the module tree is the reference's own (seeded init included), the encoder is deleted and the two
+    statements of its forward that call it are skipped."""
+    import types
+    del model.fingerprint_transformer
+
+    def forward(self, fingerprint, image):
+        fingerprint_out = self.fingerprint_fc(fingerprint)
+        image_out = self.image_cnn(image.view(-1, 3, 128, 128))
+        return self.fc(torch.cat((fingerprint_out, image_out), dim=1))
+    model.forward = types.MethodType(forward, model)
+
+
 def case_model(tag, relpath, F, I_ctor, I_flat, Bs, init_seed, train_Bs=(), adam_B=None,
-               state_dict_path=None, extra_classes=()):
+               state_dict_path=None, extra_classes=(), mutate=None):
     ns = load_classes(relpath, {"MixedDataset", "MultiHeadAttentionFusion", "MixedInputModel",
                                 "AttentionFusion", "MultiModalAttentionFusion", *extra_classes})
     torch.manual_seed(init_seed)
@@ -78,6 +92,8 @@ def case_model(tag, relpath, F, I_ctor, I_flat, Bs, init_seed, train_Bs=(), adam
     if state_dict_path is not None:
         sd = torch.load(os.path.join(REF, state_dict_path), map_location="cpu", weights_only=True)
         model.load_state_dict(sd, strict=True)
+    if mutate is not None:
+        mutate(model)
     zero_dropout(model)
     out = {"meta/init_seed": np.array(init_seed), "meta/F": np.array(F), "meta/I_ctor": np.array(I_ctor),
            "meta/I_flat": np.array(I_flat),
@@ -203,6 +219,12 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     M = "Models/"
+    only = set(sys.argv[1:])                      # optional: regenerate just the named fixtures
+    global case_model, case_ops
+    if only:
+        all_case_model, all_case_ops = case_model, case_ops
+        case_model = lambda tag, *a, **k: all_case_model(tag, *a, **k) if tag in only else None
+        case_ops = lambda: all_case_ops() if "ops" in only else None
     # flagship (published variant), MACCS width; nhead = 1, head_dim = 167
     case_model("flagship_f167", M + "multi_input_data_regression_opt_transformer_cnn_20250113.py",
                167, 128, 49152, Bs=(1, 2, 7, 32), init_seed=20250113, train_Bs=(7, 32), adam_B=7)
@@ -225,6 +247,14 @@ def main():
     # wide/deep variant: 12-layer encoder, 3-conv CNN, MultiModalAttentionFusion (batch-mean broadcast), 6-layer head
     case_model("wide_deep_f167", M + "multi_input_data_regression_opt_transformer_cnn_opt_20250107_network.py",
                167, 128, 49152, Bs=(3,), init_seed=20250107, train_Bs=(5,))
+    # earliest Transformer+CNN class: torch.cat fusion, no attention_fusion block
+    R2 = "Descriptors/multi_input_data_regression_opt_round_2_transformer_cnn.py"
+    case_model("concat_f167", R2, 167, 128, 49152, Bs=(2,), init_seed=20250102, train_Bs=(7,))
+    # BASELINE config 2: that class with the encoder removed (see drop_encoder), up to the config's batch 256
+    case_model("two_branch_f167", R2, 167, 128, 49152, Bs=(2, 7), init_seed=20250102, train_Bs=(7, 256), adam_B=7, mutate=drop_encoder)
+    # PCA-MLP fusion with the single-head AttentionFusion (softmax over a size-1 dim => weights == 1)
+    case_model("rdkit_pca", M + "multi_input_data_regression_opt_transformer_cnn_rdkit.py",
+               128, 256, 256, Bs=(1, 9), init_seed=3, train_Bs=(6,))
     case_ops()
 
 
