@@ -867,6 +867,22 @@ extern "C" int bbbp_mixed_backward_wait_bucket(void* stream, int bucket) {
     BBBP_CHECK_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), ev, 0));
     return BBBP_OK;
 }
+__global__ void positive_gate_kernel(const float* x, uint8_t* gate, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) gate[i] = x[i] > 0.f ? 1 : 0;
+}
+extern "C" int bbbp_mixed_debug_ffn_gate(void* stream, const bbbp_mixed_desc* d, const void* workspace, int layer, uint8_t* gate) {
+    Plan plan;
+    TRY(make_plan(d, &plan));
+    BBBP_CHECK_ARG(workspace && gate, "debug_ffn_gate: null pointer");
+    BBBP_CHECK_ARG(layer >= 0 && layer < plan.L, "debug_ffn_gate: layer %d of %d", layer, plan.L);
+    BBBP_CHECK_ARG(!plan.inference, "debug_ffn_gate: an inference workspace keeps no per-layer activations");
+    const long n = (long)plan.B * plan.DFF;
+    const float* hff = reinterpret_cast<const float*>(static_cast<const char*>(workspace) + plan.layer[layer].hff);
+    hipLaunchKernelGGL(positive_gate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), hff, gate, n);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
 extern "C" int bbbp_mixed_bucket_param(const bbbp_mixed_desc* d, int bucket) {
     if (!d || bucket != 0) return -1;
     return PIdx(d).ifc_w();

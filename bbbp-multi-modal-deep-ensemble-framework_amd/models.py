@@ -109,6 +109,7 @@ def _cached_ptrs(model, attr, tensors):
 
 
 _PTR_CACHE = weakref.WeakKeyDictionary()
+_LAST_WS = weakref.WeakKeyDictionary()
 
 
 class _MixedFn(torch.autograd.Function):
@@ -135,6 +136,8 @@ class _MixedFn(torch.autograd.Function):
         _lib.check(L.bbbp_mixed_forward(ops._stream(), ctypes.byref(desc), pp, bnp, fingerprint.data_ptr(), image.data_ptr(),
                                         out.data_ptr(), ws.data_ptr(), ws_bytes), "bbbp_mixed_forward")
         ctx.desc, ctx.ws, ctx.ws_bytes, ctx.pp = desc, ws, ws_bytes, pp
+        if getattr(model, "keep_workspace", False):
+            _LAST_WS[model] = (desc, ws)
         ctx.save_for_backward(fingerprint, image, *params)
         return out
 
@@ -218,6 +221,20 @@ class MixedInputModel(nn.Module):
         return _lib.MixedDesc(batch=batch, fingerprint_size=self.fingerprint_size, nhead=self.nhead, num_layers=layers,
                               dim_feedforward=dff, training=int(training), dropout_p=p, seed=seed, need_input_grad=0,
                               fusion=0 if self.FUSION == "attention" else 1, inference=int(inference and not training))
+
+    def debug_ffn_gates(self):
+        """Test hook: per encoder layer, the [B, dim_feedforward] uint8 ReLU decisions of ``linear1`` in the most recent
+        forward call made with ``self.keep_workspace = True`` (``bbbp_mixed_debug_ffn_gate``)."""
+        if self not in _LAST_WS:
+            raise RuntimeError("set model.keep_workspace = True before the forward call")
+        desc, ws = _LAST_WS[self]
+        L, gates = _lib.lib(), []
+        for l in range(desc.num_layers):
+            g = torch.empty((desc.batch, desc.dim_feedforward), dtype=torch.uint8, device=ws.device)
+            _lib.check(L.bbbp_mixed_debug_ffn_gate(ops._stream(), ctypes.byref(desc), ws.data_ptr(), l, g.data_ptr()),
+                       "bbbp_mixed_debug_ffn_gate")
+            gates.append(g)
+        return gates
 
     def forward(self, fingerprint, image):
         if not fingerprint.is_cuda:

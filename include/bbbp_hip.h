@@ -253,6 +253,11 @@ int bbbp_set_overlap(int on);   /* two/three-stream branch overlap inside bbbp_m
  * gradient except the four conv tensors: final when the fingerprint branch and all weight-gradient leaves are (the image
  * branch's last kernel is then still running); the conv tensors are final only at the end of the pass. */
 int bbbp_mixed_backward_wait_bucket(void* stream, int bucket);
+/* Test hook: the ReLU decisions of encoder layer `layer`'s linear1 (R:75-78; nn.TransformerEncoderLayer.linear1 + ReLU) as
+ * the forward pass that filled `workspace` took them -- gate[b * dim_feedforward + j] = 1 where the (post-dropout) hidden
+ * activation is > 0.  Parity tests at B = 512 hand these to the float64 oracle: a pre-activation within float32 rounding of
+ * zero may legitimately fall on either side, and ONE such element changes that unit's weight-gradient row by percents. */
+int bbbp_mixed_debug_ffn_gate(void* stream, const bbbp_mixed_desc* d, const void* workspace, int layer, uint8_t* gate);
 int bbbp_mixed_bucket_param(const bbbp_mixed_desc* d, int bucket);
 /* HIP-graph replay of bbbp_mixed_forward / bbbp_mixed_backward: the second call with identical arguments is captured,
  * later ones are replayed with one hipGraphLaunch.  Opt-in (env BBBP_GRAPHS=1 or bbbp_set_graphs(1), which returns the

@@ -71,3 +71,19 @@ def check_summary_adam(g, prefix, tensor, lr, steps, rtol=1e-5, min_frac=0.9, ti
     assert (err <= 2.5 * lr * steps + rtol * np.abs(exp)).all(), f"{prefix}: max err {err.max():.3e}"
     tight = err <= rtol * np.abs(exp) + tight_lr_frac * lr
     assert tight.mean() >= min_frac, f"{prefix}: only {tight.mean():.2%} of sampled elements agree tightly"
+
+
+def assert_close_or_as_accurate_as_fp32(actual, ref64, ref32, rtol=RTOL, atol_frac=5e-5, slack=2.0, what=""):
+    """For sums that are ill-conditioned in float32 (the conv weight/bias gradients: 10^6..10^7 cancelling products per element
+    behind max-pools): pass when ``actual`` meets the float64 oracle element-wise, OR when its worst error against float64 is
+    no larger than ``slack`` x the worst error of the SAME arithmetic done by torch on the CPU in float32 (``ref32``: the
+    reference's own path) -- i.e. the GPU is held to the accuracy the reference itself has, not to one float32 cannot give."""
+    a = np.asarray(actual, dtype=np.float64); e = np.asarray(ref64, dtype=np.float64); r = np.asarray(ref32, dtype=np.float64)
+    assert a.shape == e.shape == r.shape, f"{what}: shapes {a.shape} {e.shape} {r.shape}"
+    scale = float(np.max(np.abs(e))) if e.size else 0.0
+    err = np.abs(a - e)
+    if (err <= rtol * np.abs(e) + atol_frac * scale + 1e-30).all():
+        return
+    ref_err = float(np.abs(r - e).max())
+    assert err.max() <= slack * ref_err + atol_frac * scale, (
+        f"{what}: max err {err.max():.3e} vs float64 at scale {scale:.3e}; torch-CPU float32 is off by {ref_err:.3e}")

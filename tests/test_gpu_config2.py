@@ -6,7 +6,7 @@ import torch
 
 import bbbp_amd
 from oracle import reference_cpu as oracle
-from helpers import assert_close, check_param_checksums, check_summary, check_summary_adam, golden, synth_inputs
+from helpers import assert_close, assert_close_or_as_accurate_as_fp32, check_param_checksums, check_summary, check_summary_adam, golden, synth_inputs
 from test_gpu_model import grad_atol, zero_dropout
 
 pytestmark = pytest.mark.gpu
@@ -50,12 +50,18 @@ def test_two_branch_train_step(dev, B):
     assert int(sd["fc.2.num_batches_tracked"]) == 1
     for k, q in m.named_parameters():
         check_summary(g, f"train/B{B}/{k}", q.grad, rtol=5e-4, atol_frac=grad_atol(k))
-    p = {k: (v.detach().cpu().double() if v.dtype.is_floating_point else v.detach().cpu()).clone()
-         .requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in two_branch(dev).state_dict().items()}
-    oracle.mse_loss(oracle.mixed_input_forward(p, fp.double(), img.double(), training=True, bn_state={}, num_layers=0, fusion="concat"),
-                    y.double()).backward()
+    refs = []
+    for cast in (torch.Tensor.double, torch.Tensor.float):
+        p = {k: (cast(v.detach().cpu()) if v.dtype.is_floating_point else v.detach().cpu()).clone()
+             .requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in two_branch(dev).state_dict().items()}
+        oracle.mse_loss(oracle.mixed_input_forward(p, cast(fp), cast(img), training=True, bn_state={}, num_layers=0, fusion="concat"),
+                        cast(y)).backward()
+        refs.append(p)
     for k, q in m.named_parameters():
-        assert_close(q.grad.cpu().numpy(), p[k].grad.numpy(), rtol=1e-4, atol_frac=5e-5, what=k)
+        if k.startswith(("image_cnn.0.", "image_cnn.3.")):      # ill-conditioned float32 sums: see the helper
+            assert_close_or_as_accurate_as_fp32(q.grad.cpu().numpy(), refs[0][k].grad.numpy(), refs[1][k].grad.numpy(), what=k)
+        else:
+            assert_close(q.grad.cpu().numpy(), refs[0][k].grad.numpy(), rtol=1e-4, atol_frac=5e-5, what=k)
 
 
 def test_two_branch_adamw_steps(dev):

@@ -8,7 +8,7 @@ import torch
 import bbbp_amd
 from bbbp_amd import _lib
 from oracle import reference_cpu as oracle
-from helpers import assert_close, check_summary_adam, golden, synth_inputs
+from helpers import assert_close, assert_close_or_as_accurate_as_fp32, check_summary_adam, golden, synth_inputs
 from test_gpu_model import FUSION, build, zero_dropout
 
 pytestmark = pytest.mark.gpu
@@ -23,35 +23,63 @@ def oracle_params(m, double=True):
 def test_headline_batch_fwd_bwd_against_oracle(dev, conv2_form):
     """BASELINE config 3 exactly as bench.py runs it (B = 512, F = 167, train mode, branch overlap ON, the 192-CU Winograd
     partition or the direct conv2 form) with dropout 0: output, loss, BatchNorm running statistics and EVERY element of
-    every non-degenerate gradient against the float64 oracle."""
+    every non-degenerate gradient against the float64 oracle.
+
+    ReLU kinks: a step has 6.3 M hidden FFN activations, and a float32 pre-activation carries ~1e-7 of rounding, so in about
+    every second step ONE of them lands on the other side of zero than in float64 (measured: tools/exp_b512_accuracy.py).  That
+    single decision moves its unit's linear1 weight-gradient row by percents (the batch has only 512 rows) and everything
+    upstream by 2-5e-4 -- in ANY float32 implementation, torch's CPU path included.  So the oracle is evaluated with the
+    GPU's own FFN ReLU decisions (bbbp_mixed_debug_ffn_gate), after checking that they differ from float64's only where the
+    float64 pre-activation is within 2e-6 of zero, and at no more than a handful of elements."""
     L = _lib.lib()
     B, F = 512, 167
     m = build(F, 20250113, dev)
     zero_dropout(m)
     m.train()
+    m.keep_workspace = True
     fp, img, y = synth_inputs(512512, B, F, 49152)
-    p = oracle_params(m)
-    st = {}
-    ref_out = oracle.mixed_input_forward(p, fp.double(), img.double(), training=True, bn_state=st)
-    ref_loss = oracle.mse_loss(ref_out, y.double())
-    ref_loss.backward()
+    p = oracle_params(m)                                 # before the forward call updates the BatchNorm running statistics
+    p32 = oracle_params(m, double=False)                 # the reference's own precision: yardstick for the ill-conditioned sums
     old_w, old_o = L.bbbp_get_conv_winograd(), L.bbbp_set_overlap(1)
     _lib.check(L.bbbp_set_conv_winograd(conv2_form), "bbbp_set_conv_winograd")
     try:
         out = m(fp.to(dev), img.to(dev))
+        gates = [g.cpu() for g in m.debug_ffn_gates()]
         loss = bbbp_amd.MSELoss()(out.squeeze(), y.to(dev))
         loss.backward()
         torch.cuda.synchronize()
     finally:
         L.bbbp_set_conv_winograd(old_w)
         L.bbbp_set_overlap(old_o)
-    assert_close(out.detach().cpu().numpy(), ref_out.detach().numpy(), rtol=1e-4, atol_frac=2e-5, what="B=512 train output")
+    # the oracle's own decisions first: where do the GPU's differ?
+    parts = {}
+    with torch.no_grad():
+        free_out = oracle.mixed_input_forward(p, fp.double(), img.double(), training=True, bn_state={}, parts=parts)
+    flips = 0
+    for l, (g, pre) in enumerate(zip(gates, parts["ffn_pre"])):
+        diff = g.bool() != (pre > 0)
+        flips += int(diff.sum())
+        if diff.any():
+            assert float(pre[diff].abs().max()) <= 2e-6 * float(pre.abs().mean()), f"layer {l}: ReLU decision differs away from zero"
+    assert flips <= 8, f"{flips} ReLU decisions differ from float64"
+    assert_close(out.detach().cpu().numpy(), free_out.numpy(), rtol=1e-4, atol_frac=2e-5, what="B=512 train output")
+    # gradients of the function with those decisions
+    st = {}
+    ref_out = oracle.mixed_input_forward(p, fp.double(), img.double(), training=True, bn_state=st, ffn_gates=gates)
+    ref_loss = oracle.mse_loss(ref_out, y.double())
+    ref_loss.backward()
+    oracle.mse_loss(oracle.mixed_input_forward(p32, fp, img, training=True, bn_state={}, ffn_gates=gates), y).backward()
     assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-4 * abs(float(ref_loss.detach()))
     sd = m.state_dict()
     for k in ("fc.2.running_mean", "fc.2.running_var"):
         assert_close(sd[k].cpu().numpy(), st[k].numpy(), rtol=1e-4, what=k)
     for k, q in m.named_parameters():
-        if not k.startswith(FUSION):
+        if k.startswith(FUSION):
+            continue
+        if k.startswith(("image_cnn.0.", "image_cnn.3.")):
+            # 10^7-term cancelling sums behind max-pools: held to the accuracy torch's own float32 CPU path has (helpers.py)
+            assert_close_or_as_accurate_as_fp32(q.grad.cpu().numpy(), p[k].grad.numpy(), p32[k].grad.numpy(), what=k)
+        else:
             assert_close(q.grad.cpu().numpy(), p[k].grad.numpy(), rtol=1e-4, atol_frac=5e-5, what=k)
 
 
