@@ -73,6 +73,61 @@ class StackedEnsemble:
         return out
 
 
+class StackingRegressor:
+    """``sklearn.ensemble.StackingRegressor(estimators, final_estimator=LinearRegression())`` as the published script builds
+    and uses it (Models/multi_input_data_regression_opt_transformer_cnn_20250113.py:394-403) -- NOT ``X c + b`` on the input
+    columns: ``fit(X, y)`` (X = the [N,4] out-of-fold matrix ``[nn, rf, xgb, cat]``) fits every base learner on ALL of X,
+    builds the meta-features from 5-fold ``cross_val_predict`` of clones (``KFold(5)`` without shuffling, scikit-learn's default
+    for regressors) and fits the final linear model on those [N, n_estimators] columns; ``predict(X)`` runs the full-data base
+    learners and the final model on their outputs.  Base learners are anything with scikit-learn's ``fit`` / ``predict``
+    (third-party CPU code, as in the reference); fitted random forests / extra-trees predict through ``trees.ForestGPU`` when
+    ``device`` is given.  The final estimator is this module's ``StackedEnsemble`` (OLS by default)."""
+
+    def __init__(self, estimators, final_estimator=None, cv: int = 5, device=None):
+        self.estimators = list(estimators)
+        self.final_estimator = final_estimator if final_estimator is not None else StackedEnsemble(0.0)
+        self.cv, self.device = int(cv), device
+        self.estimators_ = None
+        self.final_estimator_ = None
+
+    def _predict_one(self, est, X):
+        if self.device is not None and hasattr(est, "estimators_") and hasattr(est.estimators_[0], "tree_"):
+            from .trees import ForestGPU
+            return ForestGPU.from_sklearn(est, device=self.device).predict(X)
+        return np.asarray(est.predict(X), dtype=np.float64)
+
+    def fit(self, X, y):
+        from sklearn.base import clone
+        X = np.asarray(X, dtype=np.float64)
+        y = np.asarray(y, dtype=np.float64).reshape(-1)
+        n = X.shape[0]
+        if X.ndim != 2 or n != y.shape[0]:
+            raise ValueError(f"X {X.shape} and y {y.shape} do not match")
+        if n < self.cv:
+            raise ValueError(f"cv={self.cv} folds need at least as many rows, got {n}")
+        self.estimators_ = [(name, clone(est).fit(X, y)) for name, est in self.estimators]
+        # KFold(cv) without shuffling: the first n % cv folds have one row more
+        sizes = np.full(self.cv, n // self.cv); sizes[: n % self.cv] += 1
+        bounds = np.concatenate([[0], np.cumsum(sizes)])
+        meta = np.zeros((n, len(self.estimators)))
+        for f in range(self.cv):
+            test = np.arange(bounds[f], bounds[f + 1])
+            train = np.concatenate([np.arange(0, bounds[f]), np.arange(bounds[f + 1], n)])
+            for j, (_, est) in enumerate(self.estimators):
+                meta[test, j] = self._predict_one(clone(est).fit(X[train], y[train]), X[test])
+        self.final_estimator_ = StackedEnsemble(getattr(self.final_estimator, "alpha", 0.0)).fit(meta, y)
+        return self
+
+    def transform(self, X):
+        if self.estimators_ is None:
+            raise RuntimeError("StackingRegressor is not fitted")
+        X = np.asarray(X, dtype=np.float64)
+        return np.stack([self._predict_one(est, X) for _, est in self.estimators_], axis=1)
+
+    def predict(self, X):
+        return self.final_estimator_.predict(self.transform(X))
+
+
 def screen(model, forest, stack, fingerprints, images, extra_columns=(), batch_size: int = 4096):
     """Stacked prediction over a library (BASELINE config 5; ``Descriptors/virtualscreening.py`` + ...20250113.py:394-403):
     per batch, the multi-modal network in eval mode, the random forest on ``hstack([fingerprint, image])`` (``trees.ForestGPU``)

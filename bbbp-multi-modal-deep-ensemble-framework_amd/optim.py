@@ -24,6 +24,9 @@ class AdamW(torch.optim.Optimizer):
         self._flat_params = {}
 
     def _init_group_state(self, gi, params):
+        """Flat first/second-moment buffers for group ``gi``; ``state[p]`` holds views of them.  Moments and step counts a
+        parameter already has (restored by ``load_state_dict``, or from steps taken before the group's layout changed)
+        are carried over, never reset."""
         total = sum(p.numel() for p in params)
         dev = params[0].device
         m = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -31,9 +34,37 @@ class AdamW(torch.optim.Optimizer):
         off = 0
         for p in params:
             n = p.numel()
-            self.state[p] = {"step": 0, "exp_avg": m[off:off + n].view(p.shape), "exp_avg_sq": v[off:off + n].view(p.shape)}
+            mv, vv = m[off:off + n].view(p.shape), v[off:off + n].view(p.shape)
+            old = self.state.get(p)
+            step = 0
+            if old:
+                mv.copy_(old["exp_avg"]); vv.copy_(old["exp_avg_sq"])
+                step = int(old["step"])
+            self.state[p] = {"step": step, "exp_avg": mv, "exp_avg_sq": vv}
             off += n
         self._flat_state[gi] = (m, v)
+
+    def _state_is_flat(self, gi, params) -> bool:
+        """True while the parameters' moments are still views of this group's flat buffers (first and last are checked: the
+        views are only ever replaced wholesale, by ``load_state_dict`` or ``_init_group_state``)."""
+        flat = self._flat_state.get(gi)
+        if flat is None:
+            return False
+        first, last = self.state.get(params[0]), self.state.get(params[-1])
+        if not first or not last:
+            return False
+        end = flat[0].data_ptr() + 4 * (flat[0].numel() - params[-1].numel())
+        return first["exp_avg"].data_ptr() == flat[0].data_ptr() and last["exp_avg"].data_ptr() == end
+
+    def load_state_dict(self, state_dict):
+        """torch's loader deep-copies the saved moments into fresh per-parameter tensors; the next ``step()`` notices that
+        they are no longer views of the flat buffers (``_state_is_flat``) and re-homes them, values and step counts kept."""
+        super().load_state_dict(state_dict)
+        self._flat_state.clear()
+        self._flat_params.clear()
+        for st in self.state.values():
+            if "step" in st and torch.is_tensor(st["step"]):
+                st["step"] = int(st["step"])
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
@@ -46,7 +77,7 @@ class AdamW(torch.optim.Optimizer):
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
                 continue
-            if gi not in self._flat_state or any(p not in self.state for p in params):
+            if not self._state_is_flat(gi, group["params"]):
                 self._init_group_state(gi, [p for p in group["params"]])
             hp = dict(lr=group["lr"], betas=group["betas"], eps=group["eps"], weight_decay=group["weight_decay"])
             for p in params:

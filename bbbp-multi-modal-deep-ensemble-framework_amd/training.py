@@ -48,10 +48,16 @@ def predict(model, fingerprints: torch.Tensor, images: torch.Tensor, batch_size:
 
 def train_fold(model, train, test=None, *, epochs: int = 50, batch_size: int = 32, lr: float = 1e-4, weight_decay: float = 1e-5,
                faithful_mode: bool = True, shuffle: bool = True, generator: Optional[torch.Generator] = None,
-               optimizer=None, batch_orders: Optional[List[np.ndarray]] = None) -> Dict[str, list]:
+               optimizer=None, batch_orders: Optional[List[np.ndarray]] = None, scheduler=None) -> Dict[str, list]:
     """Train ``model`` on ``train = (fingerprints[N,F], images[N,49152], labels[N])`` (device tensors).  Returns the per-epoch
     mean training / validation losses like the reference's ``train_losses`` / ``val_losses`` lists.  ``batch_orders``
-    (one permutation per epoch) overrides the shuffling for reproducible comparisons."""
+    (one permutation per epoch) overrides the shuffling for reproducible comparisons.
+
+    ``scheduler``: the canonical script anneals the learning rate with ``CosineAnnealingWarmRestarts(optimizer, T_0=10, T_mult=2)``
+    stepped once per EPOCH after the epoch's batches (Models/multi_input_data_regression_opt_transformer_cnn.py:161,177; the
+    published ...20250113.py has no scheduler).  Pass ``"cosine_warm_restarts"`` for exactly that, or a callable
+    ``optimizer -> torch.optim.lr_scheduler.LRScheduler``; the fused AdamW reads ``group["lr"]`` at every step.  The learning
+    rate used in each epoch is recorded in ``hist["lr"]``."""
     fp, img, y = train
     if not (fp.is_cuda and img.is_cuda and y.is_cuda):
         raise RuntimeError("train_fold expects device-resident tensors")
@@ -59,7 +65,11 @@ def train_fold(model, train, test=None, *, epochs: int = 50, batch_size: int = 3
     opt = optimizer if optimizer is not None else AdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
     crit = MSELoss()                      # nn.MSELoss semantics, fused value + gradient kernel
     N = fp.shape[0]
-    hist = {"train_loss": [], "val_loss": []}
+    if scheduler == "cosine_warm_restarts":
+        scheduler = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=10, T_mult=2)
+    elif callable(scheduler) and not hasattr(scheduler, "step"):
+        scheduler = scheduler(opt)
+    hist = {"train_loss": [], "val_loss": [], "lr": []}
     model.train()                                   # reference :179 -- once, outside the epoch loop
     for epoch in range(epochs):
         if not faithful_mode:
@@ -82,6 +92,9 @@ def train_fold(model, train, test=None, *, epochs: int = 50, batch_size: int = 3
             total += loss.detach()
             nb += 1
         hist["train_loss"].append(float(total) / nb)
+        hist["lr"].append(float(opt.param_groups[0]["lr"]))
+        if scheduler is not None:
+            scheduler.step()                        # canonical script :177 -- per epoch, after the batches
         if test is not None:
             tfp, timg, ty = test
             model.eval()                            # reference :195 -- and it stays in eval mode when faithful
@@ -92,3 +105,66 @@ def train_fold(model, train, test=None, *, epochs: int = 50, batch_size: int = 3
                     vl += float(crit(p, ty[i:i + batch_size].to(torch.float32))); vb += 1
             hist["val_loss"].append(vl / vb)
     return hist
+
+
+
+def kfold_indices(n: int, n_splits: int = 10, seed: int = 42):
+    """``KFold(n_splits, shuffle=True, random_state=42).split`` (...20250113.py:146; scikit-learn is the reference's own
+    third-party dependency, so its splitter is used as is)."""
+    from sklearn.model_selection import KFold
+    return list(KFold(n_splits=n_splits, shuffle=True, random_state=seed).split(np.zeros((n, 1))))
+
+
+def cross_validate_oof(fingerprints, images, labels, *, model_factory, n_splits: int = 10, epochs: int = 50, batch_size: int = 32,
+                       faithful_mode: bool = True, scheduler=None, rf_params: Optional[dict] = None, extra_columns: Optional[dict] = None,
+                       init_seed: Optional[int] = None, device=None, folds=None, batch_orders=None) -> Dict[str, np.ndarray]:
+    """The published script's fold loop (Models/multi_input_data_regression_opt_transformer_cnn_20250113.py:147-266): for each of
+    the ``KFold(10, shuffle=True, random_state=42)`` splits train a fresh network on the training rows (``train_fold``), write
+    its eval-mode predictions of the held-out rows into ``nn[test_idx]`` (:229-241), fit the random forest on
+    ``hstack([fingerprint, image])`` of the training rows (:262-266; scikit-learn on the host, third-party CPU code exactly
+    as in the reference) and write its held-out predictions -- walked on the GPU (``trees.ForestGPU``) -- into ``rf[test_idx]``.
+    XGBoost / CatBoost are not installed here: their out-of-fold columns enter precomputed through ``extra_columns``
+    (name -> [N]).  Returns the out-of-fold matrix the stack is fitted on: ``{"nn", "rf", <extra...>, "actuals", "X"}`` with
+    ``X = [nn, rf, *extra]`` column-stacked in the reference's order.
+
+    ``model_factory()`` builds the (CPU) model of a fold; ``init_seed`` (+ fold index) seeds torch before each call so runs are
+    reproducible (the reference sets no seeds).  ``rf_params`` defaults to the reference's (300 trees, depth 30, seed 42);
+    ``rf_params=False`` skips the forest.  ``folds`` overrides the splits, ``batch_orders[fold]`` the shuffling (tests)."""
+    from .trees import ForestGPU
+    fp_all = torch.as_tensor(fingerprints, dtype=torch.float32)
+    img_all = torch.as_tensor(images, dtype=torch.float32)
+    y_all = np.asarray(labels, dtype=np.float64)
+    N = fp_all.shape[0]
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    fp_d, img_d = fp_all.to(dev), img_all.to(dev)
+    y_d = torch.as_tensor(y_all, dtype=torch.float32, device=dev)          # MixedDataset casts labels to float32 (:44)
+    folds = kfold_indices(N, n_splits) if folds is None else folds
+    out = {"nn": np.zeros(N), "actuals": np.zeros(N), "train_loss": [], "val_loss": []}
+    if rf_params is not False:
+        out["rf"] = np.zeros(N)
+        rfp = dict(n_estimators=300, max_depth=30, random_state=42)
+        rfp.update(rf_params or {})
+    feats = None
+    for k, (train_idx, test_idx) in enumerate(folds):
+        tr = torch.as_tensor(train_idx, device=dev); te = torch.as_tensor(test_idx, device=dev)
+        if init_seed is not None:
+            torch.manual_seed(init_seed + k)
+        model = model_factory().to(dev)
+        hist = train_fold(model, (fp_d[tr], img_d[tr], y_d[tr]), (fp_d[te], img_d[te], y_d[te]), epochs=epochs, batch_size=batch_size,
+                          faithful_mode=faithful_mode, scheduler=scheduler,
+                          batch_orders=None if batch_orders is None else batch_orders[k])
+        out["train_loss"].append(hist["train_loss"]); out["val_loss"].append(hist["val_loss"])
+        out["nn"][test_idx] = predict(model, fp_d[te], img_d[te], batch_size=batch_size).double().cpu().numpy()
+        out["actuals"][test_idx] = y_all[test_idx]
+        if rf_params is not False:
+            from sklearn.ensemble import RandomForestRegressor
+            if feats is None:
+                feats = np.hstack([fp_all.numpy(), img_all.numpy()])
+            rf = RandomForestRegressor(**rfp).fit(feats[train_idx], y_all[train_idx])
+            out["rf"][test_idx] = ForestGPU.from_sklearn(rf, device=dev).predict(feats[test_idx])
+    cols = [out["nn"]] + ([out["rf"]] if "rf" in out else [])
+    for name, col in (extra_columns or {}).items():
+        out[name] = np.asarray(col, dtype=np.float64)
+        cols.append(out[name])
+    out["X"] = np.stack(cols, axis=1)
+    return out

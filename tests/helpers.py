@@ -87,3 +87,63 @@ def assert_close_or_as_accurate_as_fp32(actual, ref64, ref32, rtol=RTOL, atol_fr
     ref_err = float(np.abs(r - e).max())
     assert err.max() <= slack * ref_err + atol_frac * scale, (
         f"{what}: max err {err.max():.3e} vs float64 at scale {scale:.3e}; torch-CPU float32 is off by {ref_err:.3e}")
+
+
+# ---- multi-process launcher for the distributed tests ---------------------------------------------------------------------------
+_RENDEZVOUS_ERRORS = ("Address already in use", "EADDRINUSE", "Connection refused", "connection refused", "failed to connect",
+                      "The server socket has failed to listen")
+
+
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _rank_entry(worker, rank, world, port, q, done, args):
+    """Runs in the child: call ``worker(rank, world, port, *args)`` and report ("ok", result) or ("error", traceback).  The
+    child then stays until the parent has read every report: tensors in a result travel as shared-memory handles."""
+    try:
+        q.put((rank, "ok", worker(rank, world, port, *args)))
+    except BaseException as e:                     # noqa: BLE001 -- report instead of leaving the peer hanging in a collective
+        import traceback
+        q.put((rank, "error", "".join(traceback.format_exception(type(e), e, e.__traceback__))[-6000:]))
+    done.wait(timeout=120)
+
+
+def run_ranks(worker, world, args=(), timeout=300, launches=3):
+    """Spawn ``world`` processes running ``worker(rank, world, port, *args)`` and return their results by rank.
+    The LAUNCH is repeated only when a rank reports a rendezvous error (the probed port was taken before the store bound it).
+    A rank that times out, dies without reporting or raises anything else fails the test AT ONCE, with every traceback and
+    exit code of that one launch -- a hang or crash is never re-run."""
+    import queue
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    for attempt in range(launches):
+        port = _free_port()
+        q, done = ctx.Queue(), ctx.Event()
+        procs = [ctx.Process(target=_rank_entry, args=(worker, r, world, port, q, done, tuple(args))) for r in range(world)]
+        for p in procs:
+            p.start()
+        msgs, timed_out = [], False
+        for _ in procs:
+            try:
+                msgs.append(q.get(timeout=timeout))
+            except queue.Empty:
+                timed_out = True
+                break
+        done.set()
+        for p in procs:
+            p.join(timeout=5 if timed_out else 60)
+            if p.is_alive():
+                p.kill()
+                p.join(timeout=10)
+        errors = [(r, m) for r, kind, m in msgs if kind == "error"]
+        report = "\n".join([f"--- rank {r} ---\n{m}" for r, m in errors] + [f"exit codes: {[p.exitcode for p in procs]}"])
+        if timed_out or len(msgs) < world:
+            raise AssertionError(f"{world - len(msgs)} of {world} ranks did not report within {timeout} s (not retried)\n{report}")
+        if not errors:
+            return [m for _, _, m in sorted(msgs, key=lambda t: t[0])]
+        if all(any(s in m for s in _RENDEZVOUS_ERRORS) for _, m in errors) and attempt + 1 < launches:
+            continue                                  # rendezvous only: try another port
+        raise AssertionError(report)
+    raise AssertionError("unreachable")

@@ -9,16 +9,12 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
-
-
 def _make_model(seed):
     torch.manual_seed(seed)
     return torch.nn.Sequential(torch.nn.Linear(12, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1))
 
 
-def _worker(rank, world, port, flat, q):
+def _worker(rank, world, port, flat):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bbbp_amd import distributed as D
@@ -46,34 +42,16 @@ def _worker(rank, world, port, flat, q):
         loss.backward()
     ncoll = D.allreduce_gradients(model, average=True, bucket_bytes=256)
     preds = D.gather_predictions(out.detach())
-    q.put((rank, ncoll, [p.grad.clone() for p in model.parameters()], [p.detach().clone() for p in model.parameters()], preds))
+    res = (rank, ncoll, [p.grad.clone() for p in model.parameters()], [p.detach().clone() for p in model.parameters()], preds)
     dist.barrier()
     dist.destroy_process_group()
+    return res
 
 
 @pytest.mark.parametrize("flat", [True, False])
 def test_gloo_world2_matches_full_batch(flat):
-    world = 2
-    ctx = mp.get_context("spawn")
-    res = None
-    for attempt in range(3):             # a rendezvous port can be taken between probing and binding: retry the launch, not the maths
-        port = _free_port()
-        q = ctx.Queue()
-        procs = [ctx.Process(target=_worker, args=(r, world, port, flat, q)) for r in range(world)]
-        for p in procs:
-            p.start()
-        try:
-            res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
-        except Exception:                # noqa: BLE001  (queue.Empty: a worker died before reporting)
-            res = None
-        for p in procs:
-            p.join(timeout=60)
-            if p.is_alive():
-                p.kill()
-        if res is not None and all(p.exitcode == 0 for p in procs):
-            break
-        res = None
-    assert res is not None, "the two gloo ranks did not complete in three launches"
+    from helpers import run_ranks
+    res = run_ranks(_worker, 2, args=(flat,), timeout=120)
     ref = _make_model(100)
     g = torch.Generator().manual_seed(7)
     X, y = torch.randn(16, 12, generator=g), torch.randn(16, generator=g)

@@ -65,3 +65,28 @@ def test_forest_flattening_walks_to_sklearn_predictions():
                 node = left[node] if np.float64(Xt[i, feature[node]]) <= threshold[node] else right[node]
             got[i] += value[node]
     np.testing.assert_allclose(got / 7, rf.predict(Xt), rtol=1e-12, atol=1e-12)
+
+
+def test_stacking_regressor_semantics_match_sklearn():
+    """The published script's stack (…20250113.py:394-403) is sklearn's StackingRegressor fitted ON the [N,4] out-of-fold matrix:
+    base learners refit on those four columns, the final LinearRegression sees their 5-fold cross_val_predict.  Same numbers as
+    scikit-learn's own class with scikit-learn base learners (RandomForest / ExtraTrees stand in for the absent boosters)."""
+    from sklearn.ensemble import ExtraTreesRegressor, RandomForestRegressor
+    from sklearn.ensemble import StackingRegressor as SkStack
+    from sklearn.linear_model import LinearRegression
+    from bbbp_amd.ensemble import StackingRegressor
+    rng = np.random.default_rng(7)
+    X = rng.normal(size=(203, 4))                         # 203: KFold(5) folds of unequal size
+    y = X @ np.array([0.2, 0.5, 0.2, 0.1]) + 0.1 * np.sin(3 * X[:, 0]) + 0.05 * rng.normal(size=203)
+    ests = [("rf", RandomForestRegressor(n_estimators=20, max_depth=8, random_state=42)),
+            ("et", ExtraTreesRegressor(n_estimators=10, max_depth=6, random_state=42))]
+    sk = SkStack(estimators=ests, final_estimator=LinearRegression()).fit(X, y)
+    mine = StackingRegressor(ests).fit(X, y)
+    np.testing.assert_allclose(mine.final_estimator_.coef_, sk.final_estimator_.coef_, rtol=1e-9)
+    np.testing.assert_allclose(mine.final_estimator_.intercept_, sk.final_estimator_.intercept_, rtol=1e-9, atol=1e-12)
+    Xt = rng.normal(size=(50, 4))
+    np.testing.assert_allclose(mine.predict(Xt), sk.predict(Xt), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(mine.transform(Xt), sk.transform(Xt), rtol=1e-12, atol=1e-12)
+    assert not np.allclose(mine.predict(Xt), StackedEnsemble().fit(X, y).predict(Xt), atol=1e-3)   # it is NOT X c + b on the columns
+    with pytest.raises(ValueError):
+        StackingRegressor(ests).fit(X[:3], y[:3])

@@ -12,12 +12,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
-
-
-def _worker(rank, world, port, q):
-    try:
+def _worker(rank, world, port):
+    if True:
         sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         import torch.distributed as dist
@@ -52,31 +48,9 @@ def _worker(rank, world, port, q):
         dist.broadcast(ref, 0)
         assert torch.equal(ref.cpu(), g1)
         dist.destroy_process_group()
-        q.put((rank, "ok"))
-    except Exception as e:                                         # noqa: BLE001
-        import traceback
-        q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+        return "ok"
 
 
 def test_overlapped_allreduce_equals_plain_allreduce():
-    ctx = mp.get_context("spawn")
-    out = None
-    for attempt in range(3):             # retry the LAUNCH on a rendezvous failure (port taken between probe and bind), never the maths
-        port = _free_port()
-        q = ctx.Queue()
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-        for p in procs:
-            p.start()
-        try:
-            out = [q.get(timeout=300) for _ in procs]
-        except Exception:                # noqa: BLE001
-            out = None
-        for p in procs:
-            p.join(timeout=60)
-            if p.is_alive():
-                p.kill()
-        if out is not None and not any("Address already in use" in str(m) or "connect" in str(m).lower() and "refused" in str(m).lower() for _, m in out):
-            break
-    assert out is not None, "the two ranks did not report in three launches"
-    for rank, msg in sorted(out):
-        assert msg == "ok", f"rank {rank}:\n{msg}"
+    from helpers import run_ranks
+    assert run_ranks(_worker, 2, timeout=300) == ["ok", "ok"]

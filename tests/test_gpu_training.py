@@ -13,7 +13,7 @@ from helpers import synth_inputs
 pytestmark = pytest.mark.gpu
 
 
-def oracle_train(state, fp, img, y, orders, batch_size, faithful, test):
+def oracle_train(state, fp, img, y, orders, batch_size, faithful, test, lrs=None):
     p = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in state.items()}
     keys = [k for k, v in p.items() if v.requires_grad]
     m = {k: torch.zeros_like(p[k]) for k in keys}; v2 = {k: torch.zeros_like(p[k]) for k in keys}
@@ -32,7 +32,7 @@ def oracle_train(state, fp, img, y, orders, batch_size, faithful, test):
             step += 1
             with torch.no_grad():
                 for k in keys:
-                    oracle.adamw_step(p[k], p[k].grad, m[k], v2[k], step)
+                    oracle.adamw_step(p[k], p[k].grad, m[k], v2[k], step, **({} if lrs is None else {"lr": lrs[ep]}))
                 for k, val in st.items():
                     p[k] = val
             tot += float(loss.detach()); nb += 1
@@ -106,3 +106,132 @@ def test_fused_mse_loss_matches_torch(dev):
         torch.testing.assert_close(pred.grad, ref_pred.grad, rtol=1e-5, atol=1e-8)
     with pytest.raises(RuntimeError):
         bbbp_amd.MSELoss()(torch.zeros(3, device=dev), torch.zeros(4, device=dev))
+
+
+def small_model(F, seed):
+    torch.manual_seed(seed)
+    model = bbbp_amd.MixedInputModel(F, 128)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    return model
+
+
+def test_cosine_warm_restarts_schedule_is_followed(dev):
+    """a14: the canonical script's CosineAnnealingWarmRestarts(T_0=10, T_mult=2), stepped per epoch
+    (Models/multi_input_data_regression_opt_transformer_cnn.py:161,177).  Twelve epochs cross the first restart; the learning
+    rate of every epoch equals the closed form, and the fused AdamW follows it: losses match the oracle loop that calls
+    adamw_step(lr=lr_epoch) step for step."""
+    import math
+    F, N, BS, EPOCHS = 64, 16, 8, 12
+    fp, img, y = synth_inputs(77, N + 8, F, 49152)
+    model = small_model(F, 3)
+    state0 = {k: v.clone() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(1)
+    orders = [rng.permutation(N) for _ in range(EPOCHS)]
+    model = model.to(dev)
+    d = lambda t: t.to(dev)
+    hist = training.train_fold(model, (d(fp[:N]), d(img[:N]), d(y[:N])), None, epochs=EPOCHS, batch_size=BS, faithful_mode=False,
+                               batch_orders=orders, scheduler="cosine_warm_restarts")
+    want = [1e-4 * (1 + math.cos(math.pi * (e if e < 10 else e - 10) / (10 if e < 10 else 20))) / 2 for e in range(EPOCHS)]
+    np.testing.assert_allclose(hist["lr"], want, rtol=1e-12)
+    assert hist["lr"][10] == 1e-4 and hist["lr"][9] < 3e-6          # restart after T_0 = 10 epochs
+    ref_losses, _ = oracle_train(state0, fp[:N], img[:N], y[:N], orders, BS, False, (fp[N:], img[N:]), lrs=want)
+    for a, b in zip(hist["train_loss"], ref_losses):
+        assert abs(a - b) <= 3e-3 * abs(b) + 1e-6, (hist["train_loss"], ref_losses)
+    # a constant-lr run separates from the scheduled one: the schedule really reached the kernel
+    model2 = small_model(F, 3).to(dev)
+    hist2 = training.train_fold(model2, (d(fp[:N]), d(img[:N]), d(y[:N])), None, epochs=EPOCHS, batch_size=BS, faithful_mode=False,
+                                batch_orders=orders)
+    assert abs(hist2["train_loss"][-1] - hist["train_loss"][-1]) > 1e-3 * abs(hist["train_loss"][-1])
+
+
+def test_adamw_state_dict_resume_equals_uninterrupted_run(dev):
+    """optim.AdamW.load_state_dict: three steps, save, load into a FRESH optimizer (and, separately, into one that has already
+    stepped), three more steps == six uninterrupted steps, bit for bit."""
+    import copy
+    from bbbp_amd.optim import AdamW
+    F, B = 64, 8
+    fp, img, y = (t.to(dev) for t in synth_inputs(5, 2 * B, F, 49152))
+
+    def steps(model, opt, lo, hi):
+        for i in range(lo, hi):
+            s = (i % 2) * B
+            opt.zero_grad(set_to_none=True)
+            bbbp_amd.MSELoss()(model(fp[s:s + B], img[s:s + B]).squeeze(), y[s:s + B]).backward()
+            opt.step()
+
+    a = small_model(F, 9).to(dev).train()
+    opt_a = AdamW(a.parameters(), lr=1e-3, weight_decay=1e-5)
+    steps(a, opt_a, 0, 6)
+    want = torch.cat([q.detach().flatten() for q in a.parameters()]).cpu()
+    for already_stepped in (False, True):
+        b = small_model(F, 9).to(dev).train()
+        opt_b = AdamW(b.parameters(), lr=1e-3, weight_decay=1e-5)
+        steps(b, opt_b, 0, 3)
+        saved_opt, saved_model = copy.deepcopy(opt_b.state_dict()), copy.deepcopy(b.state_dict())
+        c = small_model(F, 10).to(dev).train()                       # different init: everything must come from the checkpoint
+        c.load_state_dict(saved_model)
+        opt_c = AdamW(c.parameters(), lr=1e-3, weight_decay=1e-5)
+        if already_stepped:
+            steps(c, opt_c, 0, 2)
+            c.load_state_dict(saved_model)
+        opt_c.load_state_dict(saved_opt)
+        p0 = next(iter(c.parameters()))
+        assert int(opt_c.state[p0]["step"]) == 3
+        steps(c, opt_c, 3, 6)
+        got = torch.cat([q.detach().flatten() for q in c.parameters()]).cpu()
+        assert torch.equal(got, want), float((got - want).abs().max())
+        assert int(opt_c.state[p0]["step"]) == 6
+
+
+def test_out_of_fold_driver_and_stack_against_oracle_folds(dev):
+    """The published fold loop end to end (...20250113.py:147-266, 394-415) on a 96-molecule synthetic set: KFold(10, shuffle,
+    random_state=42), a fresh seeded network per fold trained with the faithful loop, held-out predictions into nn[test_idx], a
+    random forest per fold (scikit-learn fit, GPU walk), then the linear meta-learner in-sample -- against the same folds run
+    with the CPU oracle + scikit-learn: every out-of-fold column, and R^2 / MSE of the stack within the north-star's +-0.002."""
+    from sklearn.ensemble import RandomForestRegressor
+    from bbbp_amd.ensemble import StackedEnsemble
+    F, N, BS, EPOCHS, SEED = 64, 96, 32, 2, 40
+    fp, img, y = synth_inputs(2025, N, F, 49152)
+    y = (0.5 * fp[:, 0] - 0.3 * fp[:, 1] + 0.2 * y)                   # something learnable
+    folds = training.kfold_indices(N, 10)
+    assert sorted(np.concatenate([te for _, te in folds]).tolist()) == list(range(N)) and len(folds) == 10
+    rng = np.random.default_rng(3)
+    orders = [[rng.permutation(len(tr)) for _ in range(EPOCHS)] for tr, _ in folds]
+    rfp = dict(n_estimators=12, max_depth=6, random_state=42)
+    xgb = y.numpy() + 0.3 * rng.normal(size=N)                        # stands in for the absent booster's out-of-fold column
+    got = training.cross_validate_oof(fp, img, y, model_factory=lambda: small_model_noseed(F), n_splits=10, epochs=EPOCHS, batch_size=BS,
+                                      rf_params=rfp, extra_columns={"xgb": xgb}, init_seed=SEED, device=dev, folds=folds,
+                                      batch_orders=orders)
+    assert got["X"].shape == (N, 3) and np.array_equal(got["actuals"], y.double().numpy())
+    feats = np.hstack([fp.numpy(), img.numpy()])
+    ref_nn, ref_rf = np.zeros(N), np.zeros(N)
+    for k, (tr, te) in enumerate(folds):
+        torch.manual_seed(SEED + k)
+        state0 = {kk: v.clone() for kk, v in small_model_noseed(F).state_dict().items()}
+        _, preds = oracle_train(state0, fp[tr], img[tr], y[tr], orders[k], BS, True, (fp[te], img[te]))
+        ref_nn[te] = preds.numpy()
+        ref_rf[te] = RandomForestRegressor(**rfp).fit(feats[tr], y.double().numpy()[tr]).predict(feats[te])
+    np.testing.assert_allclose(got["rf"], ref_rf, rtol=1e-12, atol=1e-12)
+    assert np.max(np.abs(got["nn"] - ref_nn)) <= 5e-3 * max(1.0, np.max(np.abs(ref_nn)))
+    yt = y.double().numpy()
+    stack_a = StackedEnsemble().fit(got["X"], yt)
+    stack_b = StackedEnsemble().fit(np.stack([ref_nn, ref_rf, xgb], axis=1), yt)
+    pa, pb = stack_a.predict(got["X"]), stack_b.predict(np.stack([ref_nn, ref_rf, xgb], axis=1))
+    mse_a, mse_b = training.mean_squared_error(yt, pa), training.mean_squared_error(yt, pb)
+    r2_a, r2_b = training.r2_score(yt, pa), training.r2_score(yt, pb)
+    assert abs(mse_a - mse_b) <= 0.002 and abs(r2_a - r2_b) <= 0.002 / min(1.0, float(np.var(yt))), (mse_a, mse_b, r2_a, r2_b)
+    np.testing.assert_allclose(stack_a.coef_, stack_b.coef_, atol=2e-2)
+
+
+def small_model_noseed(F):
+    model = bbbp_amd.MixedInputModel(F, 128)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    return model
