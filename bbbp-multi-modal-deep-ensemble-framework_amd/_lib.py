@@ -31,7 +31,7 @@ class GemmDesc(Structure):
                 ("bias", c_void_p), ("residual", c_void_p), ("ldr", c_int), ("act", c_int),
                 ("gate", c_void_p), ("ldg", c_int), ("gate_scale", c_float), ("batch", c_int),
                 ("strideA", c_long), ("strideB", c_long), ("strideC", c_long), ("strideR", c_long), ("strideG", c_long),
-                ("gate_after_residual", c_int)]
+                ("gate_after_residual", c_int), ("asum", c_void_p)]
 
 
 class MlpModel(Structure):
@@ -54,12 +54,14 @@ _SIGNATURES = {
     "bbbp_gemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "bbbp_gemm_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, _FP, c_int, _FP, c_int, _FP, c_int,
                               _FP, _FP, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_void_p, c_size_t]),
+    "bbbp_gemm_folds_asum": (c_int, [c_int, c_int, c_int, c_int]),
     "bbbp_gemm_f32_grouped": (c_int, [c_void_p, POINTER(GemmDesc), c_int, c_void_p, c_size_t]),
     "bbbp_mixed_backward_wait_bucket": (c_int, [c_void_p, c_int]),
     "bbbp_mixed_bucket_param": (c_int, [POINTER(MixedDesc), c_int]),
     "bbbp_mixed_debug_ffn_gate": (c_int, [c_void_p, POINTER(MixedDesc), c_void_p, c_int, c_void_p]),
     "bbbp_set_graphs": (c_int, [c_int]),
     "bbbp_set_fused_head_bwd": (c_int, [c_int]),
+    "bbbp_set_fused_encoder": (c_int, [c_int]),
     "bbbp_forest_groups": (c_int, [c_int]),
     "bbbp_forest_predict": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_void_p]),

@@ -61,6 +61,25 @@ int bbbp_head_backward_fused(hipStream_t st, const float* dout, const float* com
                              const float* const* fw1, const float* const* fw2, const float* w0, const float* w3, const float* w5,
                              const float* w7, float* dh3, float* dh2, float* dhb, float* dh, float* dlogit, float* dpre, float* dcomb,
                              float* dgamma, float* dbeta, float* partial, int B, int training);
+// encoder.hip: the row-local stretches of an encoder layer as single launches (see the file header)
+struct bbbp_enc_row_fwd_args {
+    const float* ctx; const float* xin;
+    const float *wo, *bo, *g1, *be1, *w1, *b1, *w2, *b2, *g2, *be2;
+    const float *wn, *bn; float* outn; int nn, ldn, actn;
+    float *z1, *y1, *hff, *z2, *y2, *mean1, *rstd1, *mean2, *rstd2;
+    int B, F, DFF; float p; uint64_t seed1, seed2, seed3;
+};
+struct bbbp_enc_row_bwd_args {
+    const float* dqkv_up; const float* win_up; const float* dz1_up; float* dyout;
+    const float *z2, *mean2, *rstd2, *g2, *w2, *hff, *w1, *z1, *mean1, *rstd1, *g1, *wo;
+    float *dz2, *dff, *dhff, *dy1, *dz1, *dsa, *dctx;
+    int B, F, DFF; float p; uint64_t seed1, seed3;
+};
+bool bbbp_enc_rows_supported(int F, int nhead, int dff);
+int bbbp_enc_row_fwd(hipStream_t st, const bbbp_enc_row_fwd_args* a);
+int bbbp_enc_row_bwd(hipStream_t st, const bbbp_enc_row_bwd_args* a);
+int bbbp_ln_param_grad_multi(hipStream_t st, int n, const float* const* dy, const float* const* z, const float* const* mean,
+                             const float* const* rstd, float* const* dgamma, float* const* dbeta, int rows, int cols);
 constexpr size_t BBBP_CONV_MIN_LDS = 120 * 1024;
 // conv_wino.hip: Winograd F(2x2,3x3) form of the 32 -> 64 @ 64x64 stage; workspace = 16*32*64 floats of transformed filters
 int bbbp_wino_conv2_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* y, uint8_t* mask, int B,

@@ -168,6 +168,15 @@ hipEvent_t g_bucket1_event[64];
 bool g_bucket1_recorded[64];
 int g_overlap = -1;
 int g_fused_head_bwd = -1;
+// Row-local stretches of an encoder layer as single launches (encoder.hip) instead of 6 + 6 per layer: BBBP_FUSED_ENCODER=1 /
+// bbbp_set_fused_encoder(1).  Correct (tests compare the two schedules) but OFF by default: a 16-row work-group streams a whole
+// layer's weights by itself (3.2 MB forward) through ONE wave per SIMD, which is bound by load latency -- 176 / 289 us per
+// forward / backward launch against ~50 us for the launch-per-op chain whose GEMMs spread over all CUs.
+int g_fused_encoder = -1;
+bool fused_encoder(const Plan& p) {
+    if (g_fused_encoder < 0) { const char* e = getenv("BBBP_FUSED_ENCODER"); g_fused_encoder = e ? atoi(e) != 0 : 0; }
+    return g_fused_encoder == 1 && p.L > 0 && bbbp_enc_rows_supported(p.F, p.NH, p.DFF);
+}
 bool overlap_enabled() {
     if (g_overlap < 0) { const char* e = getenv("BBBP_SINGLE_STREAM"); g_overlap = (e && e[0] == '1') ? 0 : 1; }
     return g_overlap == 1;
@@ -285,14 +294,34 @@ int linear_bwd_weight(const Ctx& c, const float* dy, int lddy, const float* x, i
 }
 
 bbbp_gemm_desc gemm_desc(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
-                         float* C, int ldc, int batch = 1, long sA = 0, long sB = 0, long sC = 0) {
+                         float* C, int ldc, int batch, long sA, long sB, long sC);
+// dW[N,K] = dy[M,N]^T x[M,K] and db[N] = column sums of dy: ONE launch when the product takes the small-GEMM path (the bias
+// gradient rides through the same MFMAs as a virtual all-ones column of x), else the GEMM plus a column-sum kernel
+int linear_bwd_weight_bias(const Ctx& c, const float* dy, int lddy, const float* x, int ldx, float* dW, float* db, int M, int N, int K) {
+    static const int fold = [] { const char* e = getenv("BBBP_FOLD_BIAS_GRAD"); return e ? atoi(e) : 1; }();
+    if (fold && bbbp_gemm_folds_asum(N, K, M, 1)) {
+        bbbp_gemm_desc g = gemm_desc(1, 0, N, K, M, 1.f, dy, lddy, x, ldx, dW, K, 1, 0, 0, 0);
+        g.asum = db;
+        return bbbp_gemm_f32_grouped(c.st, &g, 1, c.scratch(), c.scratch_bytes());
+    }
+    TRY(linear_bwd_weight(c, dy, lddy, x, ldx, dW, M, N, K));
+    return bbbp_bias_act_bwd(c.st, const_cast<float*>(dy), lddy, nullptr, 0, db, M, N, 0, 1.f);
+}
+
+bbbp_gemm_desc gemm_desc(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
+                         float* C, int ldc, int batch, long sA, long sB, long sC) {
     bbbp_gemm_desc g;
     g.transA = transA; g.transB = transB; g.M = M; g.N = N; g.K = K; g.alpha = alpha;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.bias = nullptr; g.residual = nullptr; g.ldr = 0; g.act = 0; g.gate = nullptr; g.ldg = 0; g.gate_scale = 1.f;
-    g.gate_after_residual = 0;
+    g.gate_after_residual = 0; g.asum = nullptr;
     g.batch = batch; g.strideA = sA; g.strideB = sB; g.strideC = sC; g.strideR = 0; g.strideG = 0;
     return g;
+}
+
+bbbp_gemm_desc gemm_desc(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
+                         float* C, int ldc) {
+    return gemm_desc(transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, 1, 0, 0, 0);
 }
 
 // per-site salt; the kernels mix it with the call's seed read from device memory (effective_seed)
@@ -369,6 +398,12 @@ int graph_lookup(const GraphKey& k, GraphEntry** slot) {
 extern "C" int bbbp_set_fused_head_bwd(int on) {
     const int prev = g_fused_head_bwd > 0 ? 1 : 0;
     g_fused_head_bwd = on ? 1 : 0;
+    return prev;
+}
+
+extern "C" int bbbp_set_fused_encoder(int on) {
+    const int prev = g_fused_encoder > 0 ? 1 : 0;
+    g_fused_encoder = on ? 1 : 0;
     return prev;
 }
 
@@ -468,7 +503,35 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
     const float* x = fingerprint;
     std::optional<Section> sec_enc;
     sec_enc.emplace(ce.st, SEC_ENCODER_FWD);
-    for (int l = 0; l < plan.L; ++l) {
+    const bool fused_rows = fused_encoder(plan);
+    if (fused_rows) {
+        // in_proj of layer 0; every later in_proj (and fingerprint_fc) is the tail of the previous layer's row kernel
+        TRY(linear_fwd(ce, x, F, P[ix.layer(0, L_INW)], P[ix.layer(0, L_INB)], c.f(plan.layer[0].qkv), 3 * F, B, 3 * F, F, 0));
+        for (int l = 0; l < plan.L; ++l) {
+            const LayerOff& o = plan.layer[l];
+            float* qkv = c.f(o.qkv); float* prob = c.f(o.prob); float* ctx = c.f(o.ctx); float* pd = c.f(o.pd);
+            TRY(bbbp_gemm_f32(ce.st, 0, 1, B, B, D, scale, qkv, 3 * F, qkv + F, 3 * F, prob, B, nullptr, nullptr, 0, 0, NH, D, D,
+                              (long)B * B, 0, ce.scratch(), ce.scratch_bytes()));
+            TRY(bbbp_softmax_fwd(ce.st, prob, pd, (long)NH * B, B, p_drop, site_seed(d->seed, l, 0)));
+            TRY(bbbp_gemm_f32(ce.st, 0, 0, B, D, B, 1.f, pd, B, qkv + 2 * F, 3 * F, ctx, F, nullptr, nullptr, 0, 0, NH, (long)B * B,
+                              D, D, 0, ce.scratch(), ce.scratch_bytes()));
+            bbbp_enc_row_fwd_args a;
+            a.ctx = ctx; a.xin = x;
+            a.wo = P[ix.layer(l, L_OUTW)]; a.bo = P[ix.layer(l, L_OUTB)]; a.g1 = P[ix.layer(l, L_N1W)]; a.be1 = P[ix.layer(l, L_N1B)];
+            a.w1 = P[ix.layer(l, L_W1)]; a.b1 = P[ix.layer(l, L_B1)]; a.w2 = P[ix.layer(l, L_W2)]; a.b2 = P[ix.layer(l, L_B2)];
+            a.g2 = P[ix.layer(l, L_N2W)]; a.be2 = P[ix.layer(l, L_N2B)];
+            const bool last = l + 1 == plan.L;
+            a.wn = last ? P[ix.fpfc_w()] : P[ix.layer(l + 1, L_INW)]; a.bn = last ? P[ix.fpfc_b()] : P[ix.layer(l + 1, L_INB)];
+            a.outn = last ? comb : c.f(plan.layer[l + 1].qkv); a.nn = last ? FC : 3 * F; a.ldn = last ? COMB : 3 * F; a.actn = last ? 1 : 0;
+            a.z1 = c.f(o.z1); a.y1 = c.f(o.y1); a.hff = c.f(o.hff); a.z2 = c.f(o.z2); a.y2 = c.f(o.y2);
+            a.mean1 = c.f(o.mean1); a.rstd1 = c.f(o.rstd1); a.mean2 = c.f(o.mean2); a.rstd2 = c.f(o.rstd2);
+            a.B = B; a.F = F; a.DFF = DFF; a.p = p_drop;
+            a.seed1 = site_seed(d->seed, l, 1); a.seed2 = site_seed(d->seed, l, 2); a.seed3 = site_seed(d->seed, l, 3);
+            TRY(bbbp_enc_row_fwd(ce.st, &a));
+            x = c.f(o.y2);
+        }
+    }
+    for (int l = 0; l < (fused_rows ? 0 : plan.L); ++l) {
         const LayerOff& o = plan.layer[l];
         float* qkv = c.f(o.qkv); float* prob = c.f(o.prob); float* ctx = c.f(o.ctx);
         TRY(linear_fwd(ce, x, F, P[ix.layer(l, L_INW)], P[ix.layer(l, L_INB)], qkv, 3 * F, B, 3 * F, F, 0));
@@ -493,7 +556,7 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         x = y2;
     }
     // fingerprint_fc (R:79-82, 112) -> combined[:, 0:128]
-    TRY(linear_fwd(ce, x, F, P[ix.fpfc_w()], P[ix.fpfc_b()], comb, COMB, B, FC, F, BBBP_ACT_RELU));
+    if (!fused_rows) TRY(linear_fwd(ce, x, F, P[ix.fpfc_w()], P[ix.fpfc_b()], comb, COMB, B, FC, F, BBBP_ACT_RELU));
     sec_enc.reset();
 
     if (ss) TRY(join_side(c.st, ss));        // fusion needs both halves of `combined`
@@ -585,24 +648,17 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
     float* dlogit = c.f(plan.dlogit); float* dpre = c.f(plan.dpre);
     bool head_leaves_pending = false;
     auto head_leaves = [&]() -> int {
-        TRY(linear_bwd_weight(cl, dout, 1, h3, H3, G[ix.fc7_w()], B, 1, H3));
-        TRY(bbbp_bias_act_bwd(cl.st, const_cast<float*>(dout), 1, nullptr, 0, G[ix.fc7_b()], B, 1, 0, 1.f));
-        TRY(bbbp_bias_act_bwd(cl.st, dh3, H3, nullptr, 0, G[ix.fc5_b()], B, H3, 0, 1.f));
-        TRY(linear_bwd_weight(cl, dh3, H3, h2, H2, G[ix.fc5_w()], B, H3, H2));
-        TRY(bbbp_bias_act_bwd(cl.st, dh2, H2, nullptr, 0, G[ix.fc3_b()], B, H2, 0, 1.f));
-        TRY(linear_bwd_weight(cl, dh2, H2, hb, H1, G[ix.fc3_w()], B, H2, H1));
-        TRY(bbbp_bias_act_bwd(cl.st, dh, H1, nullptr, 0, G[ix.fc0_b()], B, H1, 0, 1.f));
-        TRY(linear_bwd_weight(cl, dh, H1, fused, COMB, G[ix.fc0_w()], B, H1, COMB));
+        TRY(linear_bwd_weight_bias(cl, dout, 1, h3, H3, G[ix.fc7_w()], G[ix.fc7_b()], B, 1, H3));
+        TRY(linear_bwd_weight_bias(cl, dh3, H3, h2, H2, G[ix.fc5_w()], G[ix.fc5_b()], B, H3, H2));
+        TRY(linear_bwd_weight_bias(cl, dh2, H2, hb, H1, G[ix.fc3_w()], G[ix.fc3_b()], B, H2, H1));
+        TRY(linear_bwd_weight_bias(cl, dh, H1, fused, COMB, G[ix.fc0_w()], G[ix.fc0_b()], B, H1, COMB));
         for (int hh = 0; hh < (plan.concat ? 0 : NHEADS_FUSION); ++hh) {
             float* dl = dlogit + (size_t)hh * B;
             float* dp = dpre + (size_t)hh * B * FUS_HID;
             const float* hd = hid + (size_t)hh * B * FUS_HID;
-            TRY(linear_bwd_weight(cl, dl, 1, hd, FUS_HID, G[ix.fus(hh, 2)], B, 1, FUS_HID));
-            TRY(bbbp_bias_act_bwd(cl.st, dl, 1, nullptr, 0, G[ix.fus(hh, 3)], B, 1, 0, 1.f));
-            TRY(linear_bwd_weight(cl, dp, FUS_HID, comb, COMB, G[ix.fus(hh, 0)], B, FUS_HID, COMB));
-            TRY(bbbp_bias_act_bwd(cl.st, dp, FUS_HID, nullptr, 0, G[ix.fus(hh, 1)], B, FUS_HID, 0, 1.f));
+            TRY(linear_bwd_weight_bias(cl, dl, 1, hd, FUS_HID, G[ix.fus(hh, 2)], G[ix.fus(hh, 3)], B, 1, FUS_HID));
+            TRY(linear_bwd_weight_bias(cl, dp, FUS_HID, comb, COMB, G[ix.fus(hh, 0)], G[ix.fus(hh, 1)], B, FUS_HID, COMB));
         }
-        TRY(bbbp_bias_act_bwd(cl.st, dcomb, COMB, nullptr, 0, G[ix.fpfc_b()], B, FC, 0, 1.f));
         TRY(bbbp_bias_act_bwd(cl.st, dcomb + FC, COMB, nullptr, 0, G[ix.ifc_b()], B, FC, 0, 1.f));
         return BBBP_OK;
     };
@@ -618,8 +674,7 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         head_leaves_pending = true;          // enqueued after the image branch's kernels: the host reaches those sooner
     } else {
     // fc.7: out = h3 W7^T + b7
-    TRY(linear_bwd_weight(cl, dout, 1, h3, H3, G[ix.fc7_w()], B, 1, H3));
-    TRY(bbbp_bias_act_bwd(cl.st, const_cast<float*>(dout), 1, nullptr, 0, G[ix.fc7_b()], B, 1, 0, 1.f));   // act 0: dy untouched
+    TRY(linear_bwd_weight_bias(cl, dout, 1, h3, H3, G[ix.fc7_w()], G[ix.fc7_b()], B, 1, H3));
     // the ReLU masks ride in the input-gradient GEMMs' epilogues; the bias gradients (column sums) are leaves
     {
         bbbp_gemm_desc g = gemm_desc(0, 0, B, H3, 1, 1.f, dout, 1, P[ix.fc7_w()], H3, dh3, H3);
@@ -627,22 +682,19 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         TRY(bbbp_gemm_f32_grouped(c.st, &g, 1, c.scratch(), c.scratch_bytes()));
     }
     TRY(leaf_after(c));
-    TRY(bbbp_bias_act_bwd(cl.st, dh3, H3, nullptr, 0, G[ix.fc5_b()], B, H3, 0, 1.f));
-    TRY(linear_bwd_weight(cl, dh3, H3, h2, H2, G[ix.fc5_w()], B, H3, H2));
+    TRY(linear_bwd_weight_bias(cl, dh3, H3, h2, H2, G[ix.fc5_w()], G[ix.fc5_b()], B, H3, H2));
     {
         bbbp_gemm_desc g = gemm_desc(0, 0, B, H2, H3, 1.f, dh3, H3, P[ix.fc5_w()], H2, dh2, H2);
         g.gate = h2; g.ldg = H2;
         TRY(bbbp_gemm_f32_grouped(c.st, &g, 1, c.scratch(), c.scratch_bytes()));
     }
     TRY(leaf_after(c));
-    TRY(bbbp_bias_act_bwd(cl.st, dh2, H2, nullptr, 0, G[ix.fc3_b()], B, H2, 0, 1.f));
-    TRY(linear_bwd_weight(cl, dh2, H2, hb, H1, G[ix.fc3_w()], B, H2, H1));
+    TRY(linear_bwd_weight_bias(cl, dh2, H2, hb, H1, G[ix.fc3_w()], G[ix.fc3_b()], B, H2, H1));
     TRY(linear_bwd_input(c, dh2, H2, P[ix.fc3_w()], dhb, H1, B, H2, H1));
     TRY(bbbp_batchnorm1d_bwd_relu(c.st, dhb, h, P[ix.bn_w()], c.f(plan.bn_mean), c.f(plan.bn_rstd), dh, G[ix.bn_w()], G[ix.bn_b()],
                                   B, H1, d->training));
     TRY(leaf_after(c));
-    TRY(bbbp_bias_act_bwd(cl.st, dh, H1, nullptr, 0, G[ix.fc0_b()], B, H1, 0, 1.f));
-    TRY(linear_bwd_weight(cl, dh, H1, fused, COMB, G[ix.fc0_w()], B, H1, COMB));
+    TRY(linear_bwd_weight_bias(cl, dh, H1, fused, COMB, G[ix.fc0_w()], G[ix.fc0_b()], B, H1, COMB));
     if (plan.concat) {
         // torch.cat fusion: dcomb = dh W0, masked by the ReLUs that produced combined = [fp_out | img_out]
         bbbp_gemm_desc g = gemm_desc(0, 0, B, COMB, H1, 1.f, dh, H1, P[ix.fc0_w()], COMB, dcomb, COMB);
@@ -660,10 +712,8 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         float* dl = dlogit + (size_t)hh * B;
         float* dp = dpre + (size_t)hh * B * FUS_HID;
         const float* hd = hid + (size_t)hh * B * FUS_HID;
-        TRY(linear_bwd_weight(cl, dl, 1, hd, FUS_HID, G[ix.fus(hh, 2)], B, 1, FUS_HID));
-        TRY(bbbp_bias_act_bwd(cl.st, dl, 1, nullptr, 0, G[ix.fus(hh, 3)], B, 1, 0, 1.f));
-        TRY(linear_bwd_weight(cl, dp, FUS_HID, comb, COMB, G[ix.fus(hh, 0)], B, FUS_HID, COMB));
-        TRY(bbbp_bias_act_bwd(cl.st, dp, FUS_HID, nullptr, 0, G[ix.fus(hh, 1)], B, FUS_HID, 0, 1.f));
+        TRY(linear_bwd_weight_bias(cl, dl, 1, hd, FUS_HID, G[ix.fus(hh, 2)], G[ix.fus(hh, 3)], B, 1, FUS_HID));
+        TRY(linear_bwd_weight_bias(cl, dp, FUS_HID, comb, COMB, G[ix.fus(hh, 0)], G[ix.fus(hh, 1)], B, FUS_HID, COMB));
         // dcomb += dp W1_h; the last of the four also applies the ReLU mask of both branch outputs (combined = [fp_out | img_out])
         bbbp_gemm_desc g = gemm_desc(0, 0, B, COMB, FUS_HID, 1.f, dp, FUS_HID, P[ix.fus(hh, 0)], COMB, dcomb, COMB);
         g.residual = dcomb; g.ldr = COMB;
@@ -673,7 +723,6 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
     }
     // bias gradients of the two branch outputs: column sums of the masked dcomb, leaves
     TRY(leaf_after(c));
-    TRY(bbbp_bias_act_bwd(cl.st, dcomb, COMB, nullptr, 0, G[ix.fpfc_b()], B, FC, 0, 1.f));
     TRY(bbbp_bias_act_bwd(cl.st, dcomb + FC, COMB, nullptr, 0, G[ix.ifc_b()], B, FC, 0, 1.f));
 
     }
@@ -718,11 +767,54 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
     // ---- fingerprint branch: chain on `ce`, leaves on `cl` --------------------------------------------
     Section sec_encb(ce.st, SEC_ENCODER_BWD);
     const float* enc_out = plan.L > 0 ? c.f(plan.layer[plan.L - 1].y2) : fingerprint;
-    TRY(linear_bwd_weight(cl, dcomb, COMB, enc_out, F, G[ix.fpfc_w()], B, FC, F));
+    TRY(linear_bwd_weight_bias(cl, dcomb, COMB, enc_out, F, G[ix.fpfc_w()], G[ix.fpfc_b()], B, FC, F));
     float* dy = plan.L > 0 ? c.f(plan.lgrad[plan.L - 1].dyout) : c.f(plan.dA);
     if (plan.L > 0 || d->need_input_grad) TRY(linear_bwd_input(ce, dcomb, COMB, P[ix.fpfc_w()], dy, F, B, FC, F));
     float* dprob = c.f(plan.dprob); float* dctx = c.f(plan.dctx);
-    for (int l = plan.L - 1; l >= 0; --l) {
+    const bool fused_rows = fused_encoder(plan);
+    for (int l = fused_rows ? plan.L - 1 : -1; l >= 0; --l) {
+        const LayerOff& o = plan.layer[l];
+        const LayerGrad& g = plan.lgrad[l];
+        const float* xin = l > 0 ? c.f(plan.layer[l - 1].y2) : fingerprint;
+        float* qkv = c.f(o.qkv); float* prob = c.f(o.prob); float* ctx = c.f(o.ctx);
+        float* dff = c.f(g.dz2d); float* dhff = c.f(g.dhff); float* dsa = c.f(g.dz1d); float* dqkv = c.f(g.dqkv);
+        // one launch: (in_proj input gradient of the layer above + residual ->) norm2 bwd -> linear2 dgrad (.) gate -> linear1
+        // dgrad + residual -> norm1 bwd -> out_proj dgrad
+        bbbp_enc_row_bwd_args a;
+        const bool top = l + 1 == plan.L;
+        a.dqkv_up = top ? nullptr : c.f(plan.lgrad[l + 1].dqkv); a.win_up = top ? nullptr : P[ix.layer(l + 1, L_INW)];
+        a.dz1_up = top ? nullptr : c.f(plan.lgrad[l + 1].dz1); a.dyout = c.f(g.dyout);
+        a.z2 = c.f(o.z2); a.mean2 = c.f(o.mean2); a.rstd2 = c.f(o.rstd2); a.g2 = P[ix.layer(l, L_N2W)]; a.w2 = P[ix.layer(l, L_W2)];
+        a.hff = c.f(o.hff); a.w1 = P[ix.layer(l, L_W1)]; a.z1 = c.f(o.z1); a.mean1 = c.f(o.mean1); a.rstd1 = c.f(o.rstd1);
+        a.g1 = P[ix.layer(l, L_N1W)]; a.wo = P[ix.layer(l, L_OUTW)];
+        a.dz2 = c.f(g.dz2); a.dff = dff; a.dhff = dhff; a.dy1 = c.f(g.dy1); a.dz1 = c.f(g.dz1); a.dsa = dsa; a.dctx = dctx;
+        a.B = B; a.F = F; a.DFF = DFF; a.p = p_drop; a.seed1 = site_seed(d->seed, l, 1); a.seed3 = site_seed(d->seed, l, 3);
+        TRY(bbbp_enc_row_bwd(ce.st, &a));
+        TRY(leaf_after(ce));
+        TRY(linear_bwd_weight_bias(cl, dff, F, c.f(o.hff), DFF, G[ix.layer(l, L_W2)], G[ix.layer(l, L_B2)], B, F, DFF));
+        TRY(linear_bwd_weight_bias(cl, dhff, DFF, c.f(o.y1), F, G[ix.layer(l, L_W1)], G[ix.layer(l, L_B1)], B, DFF, F));
+        TRY(linear_bwd_weight_bias(cl, dsa, F, ctx, F, G[ix.layer(l, L_OUTW)], G[ix.layer(l, L_OUTB)], B, F, F));
+        // attention backward (products that become ready together share a launch)
+        const float* pdp = c.f(o.pd);
+        {
+            bbbp_gemm_desc gg[2] = {
+                gemm_desc(1, 0, B, D, B, 1.f, pdp, B, dctx, F, dqkv + 2 * F, 3 * F, NH, (long)B * B, D, D),
+                gemm_desc(0, 1, B, B, D, 1.f, dctx, F, qkv + 2 * F, 3 * F, dprob, B, NH, D, D, (long)B * B)};
+            TRY(bbbp_gemm_f32_grouped(ce.st, gg, 2, ce.scratch(), ce.scratch_bytes()));
+        }
+        TRY(bbbp_softmax_bwd(ce.st, dprob, prob, (long)NH * B, B, p_drop, site_seed(d->seed, l, 0)));
+        {
+            bbbp_gemm_desc gg[2] = {
+                gemm_desc(0, 0, B, D, B, scale, dprob, B, qkv + F, 3 * F, dqkv, 3 * F, NH, (long)B * B, D, D),
+                gemm_desc(1, 0, B, D, B, scale, dprob, B, qkv, 3 * F, dqkv + F, 3 * F, NH, (long)B * B, D, D)};
+            TRY(bbbp_gemm_f32_grouped(ce.st, gg, 2, ce.scratch(), ce.scratch_bytes()));
+        }
+        TRY(leaf_after(ce));
+        TRY(linear_bwd_weight_bias(cl, dqkv, 3 * F, xin, F, G[ix.layer(l, L_INW)], G[ix.layer(l, L_INB)], B, 3 * F, F));
+        if (l == 0 && d->need_input_grad)
+            TRY(linear_bwd_input(ce, dqkv, 3 * F, P[ix.layer(0, L_INW)], c.f(plan.dA), F, B, 3 * F, F, c.f(g.dz1), F));
+    }
+    for (int l = fused_rows ? -1 : plan.L - 1; l >= 0; --l) {
         const LayerOff& o = plan.layer[l];
         const LayerGrad& g = plan.lgrad[l];
         const float* xin = l > 0 ? c.f(plan.layer[l - 1].y2) : fingerprint;
@@ -742,12 +834,8 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         }
         // leaves of this half layer (they only read per-layer buffers, so ONE event per half layer orders them all)
         TRY(leaf_after(ce));
-        TRY(bbbp_layernorm_bwd(cl.st, dyout, z2, P[ix.layer(l, L_N2W)], c.f(o.mean2), c.f(o.rstd2), nullptr, nullptr,
-                               G[ix.layer(l, L_N2W)], G[ix.layer(l, L_N2B)], B, F, p_drop, 0));
-        TRY(linear_bwd_weight(cl, dff, F, hff, DFF, G[ix.layer(l, L_W2)], B, F, DFF));
-        TRY(bbbp_bias_act_bwd(cl.st, dff, F, nullptr, 0, G[ix.layer(l, L_B2)], B, F, 0, 1.f));
-        TRY(bbbp_bias_act_bwd(cl.st, dhff, DFF, nullptr, 0, G[ix.layer(l, L_B1)], B, DFF, 0, 1.f));
-        TRY(linear_bwd_weight(cl, dhff, DFF, y1, F, G[ix.layer(l, L_W1)], B, DFF, F));
+        TRY(linear_bwd_weight_bias(cl, dff, F, hff, DFF, G[ix.layer(l, L_W2)], G[ix.layer(l, L_B2)], B, F, DFF));
+        TRY(linear_bwd_weight_bias(cl, dhff, DFF, y1, F, G[ix.layer(l, L_W1)], G[ix.layer(l, L_B1)], B, DFF, F));
         // dy1 = dhff W1 + dz2
         TRY(linear_bwd_input(ce, dhff, DFF, P[ix.layer(l, L_W1)], dy1, F, B, DFF, F, dz2, F));
         // norm1
@@ -773,14 +861,25 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
             TRY(bbbp_gemm_f32_grouped(ce.st, g, 2, ce.scratch(), ce.scratch_bytes()));
         }
         TRY(leaf_after(ce));
-        TRY(bbbp_layernorm_bwd(cl.st, dy1, z1, P[ix.layer(l, L_N1W)], c.f(o.mean1), c.f(o.rstd1), nullptr, nullptr,
-                               G[ix.layer(l, L_N1W)], G[ix.layer(l, L_N1B)], B, F, p_drop, 0));
-        TRY(linear_bwd_weight(cl, dsa, F, ctx, F, G[ix.layer(l, L_OUTW)], B, F, F));
-        TRY(bbbp_bias_act_bwd(cl.st, dsa, F, nullptr, 0, G[ix.layer(l, L_OUTB)], B, F, 0, 1.f));
-        TRY(linear_bwd_weight(cl, dqkv, 3 * F, xin, F, G[ix.layer(l, L_INW)], B, 3 * F, F));
-        TRY(bbbp_bias_act_bwd(cl.st, dqkv, 3 * F, nullptr, 0, G[ix.layer(l, L_INB)], B, 3 * F, 0, 1.f));
+        TRY(linear_bwd_weight_bias(cl, dsa, F, ctx, F, G[ix.layer(l, L_OUTW)], G[ix.layer(l, L_OUTB)], B, F, F));
+        TRY(linear_bwd_weight_bias(cl, dqkv, 3 * F, xin, F, G[ix.layer(l, L_INW)], G[ix.layer(l, L_INB)], B, 3 * F, F));
         if (l > 0) TRY(linear_bwd_input(ce, dqkv, 3 * F, P[ix.layer(l, L_INW)], c.f(plan.lgrad[l - 1].dyout), F, B, 3 * F, F, dz1, F));
         else if (d->need_input_grad) TRY(linear_bwd_input(ce, dqkv, 3 * F, P[ix.layer(l, L_INW)], c.f(plan.dA), F, B, 3 * F, F, dz1, F));
+    }
+    if (plan.L > 0) {
+        // all LayerNorm weight / bias gradients (leaves: nothing waits for them before the optimizer) in one launch at the end of
+        // the leaf stream -- both schedules keep dyout / dy1 and z / mean / rstd per layer
+        const float *dy[64], *zz[64], *mm[64], *rr[64]; float *dg[64], *db[64];
+        int n = 0;
+        for (int l = 0; l < plan.L; ++l) {
+            const LayerOff& o = plan.layer[l]; const LayerGrad& g = plan.lgrad[l];
+            dy[n] = c.f(g.dyout); zz[n] = c.f(o.z2); mm[n] = c.f(o.mean2); rr[n] = c.f(o.rstd2);
+            dg[n] = G[ix.layer(l, L_N2W)]; db[n] = G[ix.layer(l, L_N2B)]; ++n;
+            dy[n] = c.f(g.dy1); zz[n] = c.f(o.z1); mm[n] = c.f(o.mean1); rr[n] = c.f(o.rstd1);
+            dg[n] = G[ix.layer(l, L_N1W)]; db[n] = G[ix.layer(l, L_N1B)]; ++n;
+        }
+        TRY(leaf_after(ce));
+        TRY(bbbp_ln_param_grad_multi(cl.st, n, dy, zz, mm, rr, dg, db, B, F));
     }
     {
         // bucket 1 is final when the chain AND the leaves are: make the leaf stream wait for the chain's tail, record there

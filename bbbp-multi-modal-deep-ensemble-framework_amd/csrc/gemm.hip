@@ -329,6 +329,7 @@ struct DirectParams {
     const float* gate; int ldg; long sG; float gate_scale; int gate_after;
     int wsm, wsn, ks;        // waves of a work-group: wsm x wsn output tiles, each computed by ks K-slices
     int batch, gx, gy;       // grid extent of THIS problem (a grouped launch covers the largest)
+    float* asum;             // LAYOUT 2 only: asum[m] = sum_k A[k][m] through a virtual all-ones column N of B
 };
 
 template <int T>
@@ -391,6 +392,17 @@ struct DirectOperand {
     }
     // matrix index of (sub-tile u, MFMA index i in 0..15)
     __device__ __forceinline__ int index(int u, int i) const { return KMAJ ? base + T * i + u : base + 16 * u + i; }
+    // k-major operand with a virtual all-ones column at index `extent`: overwrite what the clamped load fetched for it
+    __device__ __forceinline__ void ones(float (&r)[4][T], int c, int K) const {
+        if constexpr (KMAJ) {
+#pragma unroll
+            for (int u = 0; u < T; ++u)
+                if (base + T * q + u == extent) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) r[j][u] = (16 * c + 4 * kq + j) < K ? 1.f : 0.f;
+                }
+        }
+    }
 };
 
 template <int LAYOUT, int TM, int TN>
@@ -421,6 +433,9 @@ __device__ __forceinline__ void gemm_direct_body(const DirectParams& p, int batc
     };
 
     const int nch = (p.K + 15) / 16;
+    // the wave whose columns include the virtual ones column (wave-uniform; never taken by the other layouts)
+    bool has_ones = false;
+    if constexpr (LAYOUT == 2) has_ones = p.asum != nullptr && opb.base <= p.N && p.N < opb.base + 16 * TN;
     // this wave's chunks: c = ks + i * p.ks; all but the globally last one take the vector path
     const int nfast = (nch - 1 > ks) ? (nch - 1 - ks + p.ks - 1) / p.ks : 0;
     if (nfast > 0) {
@@ -433,7 +448,10 @@ __device__ __forceinline__ void gemm_direct_body(const DirectParams& p, int batc
         for (int i0 = 0; i0 < nfast; i0 += D) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                if (i0 + d < nfast) mfma_chunk(ra[d], rb[d]);
+                if (i0 + d < nfast) {
+                    if (has_ones) opb.ones(rb[d], 0, p.K);          // a full chunk: every k < K
+                    mfma_chunk(ra[d], rb[d]);
+                }
                 const int c = ks + min(i0 + d + D, nfast - 1) * p.ks;
                 opa.fetch(c, ra[d]); opb.fetch(c, rb[d]);
             }
@@ -442,6 +460,7 @@ __device__ __forceinline__ void gemm_direct_body(const DirectParams& p, int batc
     if (nch > 0 && (nch - 1) % p.ks == ks) {
         float ta[4][TM], tb[4][TN];
         opa.fetch_tail(nch - 1, p.K, ta); opb.fetch_tail(nch - 1, p.K, tb);
+        if (has_ones) opb.ones(tb, nch - 1, p.K);
         mfma_chunk(ta, tb);
     }
 
@@ -480,6 +499,9 @@ __device__ __forceinline__ void gemm_direct_body(const DirectParams& p, int batc
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = opa.index(um, 4 * kq + r);
+                if constexpr (LAYOUT == 2) {
+                    if (p.asum && n == p.N && m < p.M) p.asum[(long)batch * p.M + m] = acc[um][un][r];
+                }
                 if (m < p.M && n < p.N) {
                     float v = apply_act(p.alpha * acc[um][un][r] + bv, p.act);
                     const float gsel = p.gate ? (p.gate[(long)batch * p.sG + (long)m * p.ldg + n] > 0.f ? p.gate_scale : 0.f) : 1.f;
@@ -657,6 +679,12 @@ static void gemm_plan(int M, int N, int K, int batch, int* tile, int* splits, in
     *kchunk = kc;
 }
 
+extern "C" int bbbp_gemm_folds_asum(int M, int N, int K, int batch) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch < 1) return 0;
+    const DirectPlan dp = direct_plan(M, N, K, batch);
+    return (dp.use && batch <= 65535 && cdiv(M, 16 * dp.t * dp.wsm) <= 65535) ? 1 : 0;
+}
+
 extern "C" size_t bbbp_gemm_workspace_bytes(int M, int N, int K, int batch) {
     if (M <= 0 || N <= 0 || direct_plan(M, N, K, batch).use) return 0;
     int tile, splits, kchunk;
@@ -691,7 +719,8 @@ bool direct_params(const bbbp_gemm_desc& g, DirectParams* d, int* t) {
     d->alpha = g.alpha; d->act = g.act;
     d->gate = g.gate; d->ldg = g.ldg; d->sG = g.strideG; d->gate_scale = g.gate_scale; d->gate_after = g.gate_after_residual;
     d->wsm = dp.wsm; d->wsn = dp.wsn; d->ks = dp.ks;
-    d->batch = g.batch; d->gx = cdiv(g.N, 16 * dp.t * dp.wsn); d->gy = cdiv(g.M, 16 * dp.t * dp.wsm);
+    d->asum = (g.transA && !g.transB) ? g.asum : nullptr;
+    d->batch = g.batch; d->gx = cdiv(g.N + (d->asum ? 1 : 0), 16 * dp.t * dp.wsn); d->gy = cdiv(g.M, 16 * dp.t * dp.wsm);
     *t = dp.t;
     return true;
 }
@@ -706,6 +735,7 @@ int gemm_run(hipStream_t st, const bbbp_gemm_desc& g, void* workspace, size_t wo
         BBBP_CHECK_LAUNCH();
         return BBBP_OK;
     }
+    BBBP_CHECK_ARG(!g.asum, "gemm: asum is only produced by the small-product path (bbbp_gemm_folds_asum(%d, %d, %d, %d) == 0)", g.M, g.N, g.K, g.batch);
     const int M = g.M, N = g.N, K = g.K, batch = g.batch;
     GemmParams p;
     p.A = g.A; p.B = g.B; p.C = g.C; p.bias = g.bias; p.R = g.residual;
@@ -761,7 +791,7 @@ extern "C" int bbbp_gemm_f32(void* stream, int transA, int transB, int M, int N,
     g.transA = transA; g.transB = transB; g.M = M; g.N = N; g.K = K; g.alpha = alpha;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
-    g.gate = nullptr; g.ldg = 0; g.gate_scale = 1.f; g.gate_after_residual = 0;
+    g.gate = nullptr; g.ldg = 0; g.gate_scale = 1.f; g.gate_after_residual = 0; g.asum = nullptr;
     g.batch = batch; g.strideA = strideA; g.strideB = strideB; g.strideC = strideC; g.strideR = strideR; g.strideG = 0;
     return gemm_run(static_cast<hipStream_t>(stream), g, workspace, workspace_bytes);
 }

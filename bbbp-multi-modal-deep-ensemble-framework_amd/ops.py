@@ -127,6 +127,23 @@ def gemm_grouped(problems) -> list:
     return outs
 
 
+def linear_weight_bias_grad(dy: torch.Tensor, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """dW = dy^T x and db = column sums of dy for a Linear (2-D).  When the product takes the small-GEMM path both come out of
+    ONE launch: the bias gradient rides through the same MFMAs as a virtual all-ones column of x (bbbp_gemm_desc.asum)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    L = _lib.lib()
+    if not L.bbbp_gemm_folds_asum(N, K, M, 1):
+        return gemm(dy, x, trans_a=True), dy.sum(dim=0)
+    d, dw, wsb = _gemm_desc(dy, x, True, False, 1.0, None, None, None, None, None, 1.0)
+    db = torch.empty(N, device=dy.device, dtype=torch.float32)
+    d.asum = db.data_ptr()
+    arr = (_lib.GemmDesc * 1)(d)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dy.device)
+    _lib.check(L.bbbp_gemm_f32_grouped(_stream(), arr, 1, ws.data_ptr(), wsb), "bbbp_gemm_f32_grouped")
+    return dw, db
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
            residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """F.linear (+activation, +residual) on the MFMA GEMM."""

@@ -64,7 +64,12 @@ typedef struct bbbp_gemm_desc {
     int batch;
     long strideA, strideB, strideC, strideR, strideG;
     int gate_after_residual;      /* 0: gate(act(..)) + residual;  1: gate(act(..) + residual) */
+    float* asum;                  /* optional, layout A^T B only (a Linear's weight gradient dW = dY^T X): asum[m] = sum_k A[k][m], the
+                                     matching bias gradient, produced by the same MFMAs through a virtual all-ones column N of B.
+                                     Honoured by the small-product path only: ask bbbp_gemm_folds_asum first. */
 } bbbp_gemm_desc;
+/* 1 when a product of this shape (layout A^T B) takes the path that honours bbbp_gemm_desc.asum. */
+int bbbp_gemm_folds_asum(int M, int N, int K, int batch);
 /* `count` independent products (outputs must not alias another product's operands).  Products that become ready
  * together -- dV | dP and dQ | dK of the attention backward -- go out as ONE launch when both are small; anything
  * else runs back to back on `stream`.  Results are identical to `count` bbbp_gemm_f32 calls. */
@@ -245,6 +250,10 @@ int bbbp_set_partition(int reserved_cus, size_t small_lds_pad);   /* CU partitio
 /* The head / fusion-block input-gradient chain of bbbp_mixed_backward as two fused launches instead of ten (default off:
  * measured neutral at B = 512, slower at B = 256).  Returns the previous setting.  Initial value: BBBP_FUSED_HEAD_BWD. */
 int bbbp_set_fused_head_bwd(int on);
+/* The row-local stretches of an encoder layer (out_proj .. LayerNorm2 + the next in_proj forward; LayerNorm2 backward ..
+ * out_proj input gradient backward) as ONE launch each (csrc/encoder.hip) instead of 6 + 6, for d_model <= 192 (default OFF:
+ * measured slower, see csrc/engine.hip; initial value BBBP_FUSED_ENCODER).  Returns the previous setting.  Both schedules fill the same workspace. */
+int bbbp_set_fused_encoder(int on);
 int bbbp_set_overlap(int on);   /* two/three-stream branch overlap inside bbbp_mixed_forward/backward (default on) */
 /* Data-parallel overlap: the gradient of the image-FC weight (62 % of all gradient bytes at F = 167) is final after the
  * first GEMM of the image branch's backward.  wait_bucket(stream, 0) makes `stream` wait for exactly that point of the

@@ -278,3 +278,25 @@ def test_adamw_matches_oracle(dev):
         ops.adamw_step_(pd, gs.to(dev), md, vd, step)
     assert_close(pd.cpu().numpy(), p.numpy(), rtol=1e-5, what="adamw p")
     assert_close(vd.cpu().numpy(), v.numpy(), rtol=1e-5, what="adamw v")
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 167, 2048), (512, 2048, 167), (512, 501, 167), (37, 1, 64), (512, 128, 167), (7, 256, 256),
+                                   (512, 16, 16), (3, 5, 3)])
+def test_weight_gradient_gemm_folds_the_bias_gradient(dev, M, N, K):
+    """dW = dy^T x with db = column sums of dy out of the same launch (bbbp_gemm_desc.asum: a virtual all-ones column of x):
+    the Linear shapes of the encoder and the head, N a multiple of 16 (the ones column opens a new tile) or not."""
+    from bbbp_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    dy = torch.randn(M, N, generator=g).to(dev)
+    x = torch.randn(M, K, generator=g).to(dev)
+    dw, db = ops.linear_weight_bias_grad(dy, x)
+    ref_w = dy.double().t() @ x.double()
+    ref_b = dy.double().sum(dim=0)
+    assert_close(dw.cpu().numpy(), ref_w.cpu().numpy(), rtol=1e-5, atol_frac=2e-6, what="dW")
+    assert_close(db.cpu().numpy(), ref_b.cpu().numpy(), rtol=1e-5, atol_frac=2e-6, what="db")
+    # a strided dy (the first 128 of 256 columns, as fingerprint_fc's gradient inside `combined`)
+    if N >= 4:
+        wide = torch.randn(M, 2 * N, generator=g).to(dev)
+        dw2, db2 = ops.linear_weight_bias_grad(wide[:, :N], x)
+        assert_close(db2.cpu().numpy(), wide[:, :N].double().sum(dim=0).cpu().numpy(), rtol=1e-5, atol_frac=2e-6, what="db strided")
+        assert_close(dw2.cpu().numpy(), (wide[:, :N].double().t() @ x.double()).cpu().numpy(), rtol=1e-5, atol_frac=2e-6, what="dW strided")

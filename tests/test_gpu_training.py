@@ -125,7 +125,7 @@ def test_cosine_warm_restarts_schedule_is_followed(dev):
     rate of every epoch equals the closed form, and the fused AdamW follows it: losses match the oracle loop that calls
     adamw_step(lr=lr_epoch) step for step."""
     import math
-    F, N, BS, EPOCHS = 64, 16, 8, 12
+    F, N, BS, EPOCHS = 64, 32, 32, 12                # one step per epoch: 12 AdamW steps, each at a different learning rate
     fp, img, y = synth_inputs(77, N + 8, F, 49152)
     model = small_model(F, 3)
     state0 = {k: v.clone() for k, v in model.state_dict().items()}
@@ -140,7 +140,7 @@ def test_cosine_warm_restarts_schedule_is_followed(dev):
     assert hist["lr"][10] == 1e-4 and hist["lr"][9] < 3e-6          # restart after T_0 = 10 epochs
     ref_losses, _ = oracle_train(state0, fp[:N], img[:N], y[:N], orders, BS, False, (fp[N:], img[N:]), lrs=want)
     for a, b in zip(hist["train_loss"], ref_losses):
-        assert abs(a - b) <= 3e-3 * abs(b) + 1e-6, (hist["train_loss"], ref_losses)
+        assert abs(a - b) <= 5e-3 * abs(b) + 1e-6, (hist["train_loss"], ref_losses)
     # a constant-lr run separates from the scheduled one: the schedule really reached the kernel
     model2 = small_model(F, 3).to(dev)
     hist2 = training.train_fold(model2, (d(fp[:N]), d(img[:N]), d(y[:N])), None, epochs=EPOCHS, batch_size=BS, faithful_mode=False,
@@ -235,3 +235,33 @@ def small_model_noseed(F):
         if isinstance(mod, torch.nn.MultiheadAttention):
             mod.dropout = 0.0
     return model
+
+
+def test_fused_adamw_uses_the_groups_current_lr(dev):
+    """Optimizer level: the same gradients, a different group["lr"] before every step (what a scheduler does) -- the fused
+    single-launch AdamW equals the oracle's adamw_step(lr=...) element for element."""
+    from bbbp_amd.models import flatten_parameters
+    from bbbp_amd.optim import AdamW
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.Linear(19, 3)).to(dev)
+    flatten_parameters(lin)
+    params = list(lin.parameters())
+    ref = [q.detach().cpu().clone() for q in params]
+    m = [torch.zeros_like(r) for r in ref]; v = [torch.zeros_like(r) for r in ref]
+    opt = AdamW(params, lr=1e-3, weight_decay=1e-2)
+    sched = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=3, T_mult=2)
+    g = torch.Generator().manual_seed(1)
+    for step in range(1, 9):
+        grads = [torch.randn(r.shape, generator=g) for r in ref]
+        gflat = torch.cat([t.reshape(-1) for t in grads]).to(dev)
+        off = 0
+        for q in params:
+            q.grad = gflat[off:off + q.numel()].view_as(q); off += q.numel()
+        lr = opt.param_groups[0]["lr"]
+        opt.step()
+        sched.step()
+        for r, gr, mm, vv in zip(ref, grads, m, v):
+            oracle.adamw_step(r, gr, mm, vv, step, lr=lr, weight_decay=1e-2)
+        for q, r in zip(params, ref):
+            torch.testing.assert_close(q.detach().cpu(), r, rtol=2e-6, atol=1e-8)
+    assert len({round(x, 12) for x in [1e-3 * (1 + np.cos(np.pi * k / 3)) / 2 for k in range(3)]}) == 3
