@@ -247,9 +247,10 @@ int join_side(hipStream_t main, SideStream* ss) {
 
 // ---- optional per-section timing with HIP events on the launch stream (bench.py roofline leg) ----
 enum { SEC_CONV1_FWD = 0, SEC_CONV2_FWD, SEC_IMGFC_FWD, SEC_ENCODER_FWD, SEC_HEAD_FWD, SEC_HEAD_BWD, SEC_IMGFC_BWD,
-       SEC_CONV2_WGRAD, SEC_CONV2_DGRAD, SEC_CONV1_WGRAD, SEC_ENCODER_BWD, SEC_COUNT };
+       SEC_CONV2_WGRAD, SEC_CONV2_DGRAD, SEC_CONV1_WGRAD, SEC_ENCODER_BWD, SEC_FFN1_FWD, SEC_FFN2_FWD, SEC_COUNT };
 const char* const kSectionNames[SEC_COUNT] = {"conv1_fwd", "conv2_fwd", "imgfc_fwd", "encoder_fwd", "head_fwd", "head_bwd",
-                                              "imgfc_bwd", "conv2_wgrad", "conv2_dgrad", "conv1_wgrad", "encoder_bwd"};
+                                              "imgfc_bwd", "conv2_wgrad", "conv2_dgrad", "conv1_wgrad", "encoder_bwd",
+                                              "ffn1_fwd", "ffn2_fwd"};          // the encoder's two FFN GEMMs, one instance per layer
 constexpr int PROF_MAX = 4096;
 struct ProfState {
     bool on = false;
@@ -548,9 +549,15 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         TRY(bbbp_layernorm_fwd(ce.st, z1, x, y1, P[ix.layer(l, L_N1W)], P[ix.layer(l, L_N1B)], c.f(o.mean1), c.f(o.rstd1), B, F,
                                1e-5f, p_drop, site_seed(d->seed, l, 1)));
         float* hff = c.f(o.hff); float* z2 = c.f(o.z2); float* y2 = c.f(o.y2);
-        TRY(linear_fwd(ce, y1, F, P[ix.layer(l, L_W1)], P[ix.layer(l, L_B1)], hff, DFF, B, DFF, F, BBBP_ACT_RELU));
+        {
+            Section sf(ce.st, SEC_FFN1_FWD);
+            TRY(linear_fwd(ce, y1, F, P[ix.layer(l, L_W1)], P[ix.layer(l, L_B1)], hff, DFF, B, DFF, F, BBBP_ACT_RELU));
+        }
         if (plan.drop) TRY(bbbp_dropout(ce.st, hff, hff, (long)B * DFF, p_drop, site_seed(d->seed, l, 2)));
-        TRY(linear_fwd(ce, hff, DFF, P[ix.layer(l, L_W2)], P[ix.layer(l, L_B2)], z2, F, B, F, DFF, 0));
+        {
+            Section sf(ce.st, SEC_FFN2_FWD);
+            TRY(linear_fwd(ce, hff, DFF, P[ix.layer(l, L_W2)], P[ix.layer(l, L_B2)], z2, F, B, F, DFF, 0));
+        }
         TRY(bbbp_layernorm_fwd(ce.st, z2, y1, y2, P[ix.layer(l, L_N2W)], P[ix.layer(l, L_N2B)], c.f(o.mean2), c.f(o.rstd2), B, F,
                                1e-5f, p_drop, site_seed(d->seed, l, 3)));
         x = y2;

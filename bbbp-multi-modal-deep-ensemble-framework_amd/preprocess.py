@@ -121,3 +121,69 @@ def standardize_features(fingerprints_u8: torch.Tensor, images: torch.Tensor, ba
         _lib.check(L.bbbp_standardize_chunk(ops._stream(), fp[i:i + n].data_ptr(), img[i:i + n].data_ptr(), fo[i:i + n].data_ptr(),
                                             io[i:i + n].data_ptr(), None, None, n, F, I), "bbbp_standardize_chunk")
     return fo, io
+
+
+class HostFedBatches:
+    """Streaming input for data that lives in HOST memory (the step before the hot path: the reference's DataLoader hands over
+    per-sample ``torch.tensor`` copies and one synchronous ``.to(device)`` per batch, Models/...20250113.py:31-45,184-186 --
+    197 KB per molecule, 101 MB per batch of 512).  The dataset is pinned once; batches are consecutive rows (wrapping around),
+    copied by DMA on a dedicated copy stream into one of two device buffers ONE BATCH AHEAD of the step that consumes them, so
+    the transfer of batch k+1 runs under the compute of batch k.  ``next()`` makes the current stream wait for the batch's copy
+    event and returns device views; a buffer is refilled only after the step that read it has been enqueued (event on the
+    compute stream).  The tensors are bit-identical to ``host_rows.to(device)``.
+
+    Shuffled epochs over a dataset that fits in HBM (B3DB: 208 MB) should stay device-resident (``training.train_fold``); this
+    class is for libraries that do not (screening)."""
+
+    def __init__(self, fingerprints, images, labels, batch_size: int, device, start: int = 0):
+        self.host = tuple(torch.as_tensor(t).contiguous() for t in (fingerprints, images, labels))
+        n = self.host[0].shape[0]
+        if any(t.shape[0] != n for t in self.host) or batch_size < 1 or n < 1:
+            raise ValueError("HostFedBatches: fingerprints, images and labels must have the same, non-zero number of rows")
+        self.host = tuple(t if t.is_pinned() else t.pin_memory() for t in self.host)
+        self.n, self.batch, self.device = n, int(batch_size), torch.device(device)
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.bufs = [tuple(torch.empty((self.batch,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device) for t in self.host)
+                     for _ in range(2)]
+        self.ready = [torch.cuda.Event() for _ in range(2)]
+        self.free = [torch.cuda.Event() for _ in range(2)]
+        self.pos, self.k = start % n, 0
+        self._issue(0)
+
+    def _rows(self, pos):
+        """Row ranges of the batch that starts at ``pos`` (two ranges when it wraps around the end of the dataset)."""
+        out, need, p = [], self.batch, pos
+        while need:
+            take = min(need, self.n - p)
+            out.append((p, p + take)); need -= take; p = (p + take) % self.n
+        return out
+
+    def _issue(self, slot):
+        with torch.cuda.stream(self.copy_stream):
+            if self.k >= 2:
+                self.copy_stream.wait_event(self.free[slot])          # the step that read this buffer has been enqueued and must finish
+            off = 0
+            for lo, hi in self._rows(self.pos):
+                for dst, src in zip(self.bufs[slot], self.host):
+                    dst[off:off + hi - lo].copy_(src[lo:hi], non_blocking=True)
+                off += hi - lo
+            self.ready[slot].record(self.copy_stream)
+        self.pos = (self.pos + self.batch) % self.n
+
+    def next(self):
+        """Device tensors (fingerprints, images, labels) of the next batch; valid until the call after next."""
+        cur = torch.cuda.current_stream(self.device)
+        slot = self.k % 2
+        other = slot ^ 1
+        self.k += 1
+        if self.k >= 2:
+            self.free[other].record(cur)             # everything that read the other buffer is on the compute stream by now
+        cur.wait_event(self.ready[slot])
+        out = self.bufs[slot]
+        self._issue(other)                           # batch k+1 streams in while batch k is computed
+        return out
+
+    def host_batch(self, index: int):
+        """The host rows of batch ``index`` counted from ``start`` (for checks and CPU baselines)."""
+        rows = torch.cat([torch.arange(lo, hi) for lo, hi in self._rows((index * self.batch) % self.n)])
+        return tuple(t[rows] for t in self.host)

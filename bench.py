@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
-"""Headline benchmark: molecules/s of the 3-branch MixedInputModel training step (forward + MSE + backward +
-fused AdamW; BASELINE.json config 3: MACCS width F=167, 3x128x128 images, batch 512 per GPU, train mode) on N GPUs
-of one node, one process per GPU, gradients all-reduced over RCCL when N > 1 (weak scaling: 512 molecules per GPU).
+"""Benchmark of the BBBP multi-modal hot path on N GPUs of one node, one process per GPU.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 3                      # BASELINE config 3, the headline
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--config C] [--scaling weak|strong]
+
+--config selects the BASELINE.json configuration (default 3; the driver's command line is unchanged):
+  1  MLPClassifier grid of the model-selection stage (Models/model_opt_maccs.py:133,170-181): 270 fits on [6245, 100] float64,
+     a step = one epoch of every fit
+  2  two-branch MACCS-Linear + image-CNN + torch.cat + BatchNorm head, B = 256, training step
+  3  MixedInputModel F = 167 (MACCS), B = 512, training step (forward + MSE + backward + fused AdamW, dropout 0.1)
+  4  the same model at F = 2048 (Morgan, nhead 256, 160 M parameters), B = 512, training step
+  5  screening: eval-mode forward of (3) at B = 4096 + the shipped linear meta-learner over [nn, rf, xgb] columns
+--scaling weak (default) keeps the per-GPU batch fixed; strong shards the configuration's global batch over the ranks.
+--host-fed feeds every step's batch from pinned host memory through the double-buffered loader (preprocess.HostFedBatches).
 
 Prints ONE JSON line on rank 0 (contract in the build prompt) with two extra objects:
-  roofline     -- the dominant kernel (a conv2 implicit-GEMM), timed with HIP events on its own stream inside the
-                  timed region; achieved = algorithmic FLOPs per launch / mean launch time; peak = 157.3 TFLOP/s
-                  (dense f32 MFMA, /opt/skills/guides/MI355X_MICROARCH.md)
-  cpu_baseline -- the CPU oracle (a port of the reference arithmetic, oracle/reference_cpu.py) timed on the host
-                  cores for the same step on a bounded sample (rank 0, N = 1 only)
+  roofline     -- the configuration's dominant kernel, timed with HIP events on its own stream inside the timed region;
+                  achieved = algorithmic FLOPs per launch / mean launch time; peak = 157.3 TFLOP/s (dense f32 MFMA,
+                  /opt/skills/guides/MI355X_MICROARCH.md).  traffic = HBM bytes per launch from the PMC pass kept under profiles/
+                  (tools/profile_round.sh) -- only when that pass was made with these kernel sources, else null
+  cpu_baseline -- the CPU oracle (oracle/reference_cpu.py; scikit-learn itself for config 1) timed on the host cores for the
+                  same step on a bounded sample (rank 0, N = 1 only)
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -26,24 +36,46 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-F_DIM, BATCH, IMG_FLAT = 167, 512, 3 * 128 * 128
+IMG_FLAT = 3 * 128 * 128
 PEAK_F32_MFMA_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0
+ROUND = "r02"
+
+CONFIGS = {
+    2: dict(F=167, batch=256, train=True, model="TwoBranchConcatModel", layers=0, fusion=False,
+            workload="two-branch MACCS Linear(167,128)+ReLU + 2-stage image CNN + torch.cat + BatchNorm head (BASELINE config 2); "
+                     "forward + MSE + backward + fused AdamW, train mode",
+            metric="molecules/sec fwd+bwd (2-branch MACCS-MLP + image-CNN, B=256)", candidates=("conv2_fwd", "conv2_dgrad", "conv2_wgrad")),
+    3: dict(F=167, batch=512, train=True, model="MixedInputModel", layers=6, fusion=True,
+            workload="MixedInputModel F=167 (MACCS) + 3x128x128 image, 6-layer encoder + 2-stage CNN + fusion + BN head; "
+                     "forward + MSE + backward + fused AdamW, train mode (dropout 0.1)",
+            metric="molecules/sec fwd+bwd (3-branch ensemble, B=512)", candidates=("conv2_fwd", "conv2_dgrad", "conv2_wgrad")),
+    4: dict(F=2048, batch=512, train=True, model="MixedInputModel", layers=6, fusion=True,
+            workload="MixedInputModel F=2048 (Morgan, nhead 256, 160 M parameters) + 3x128x128 image (BASELINE config 4); "
+                     "forward + MSE + backward + fused AdamW, train mode (dropout 0.1)",
+            metric="molecules/sec fwd+bwd (3-branch ensemble, Morgan-2048, B=512)", candidates=("ffn1_fwd",)),
+    5: dict(F=167, batch=4096, train=False, model="MixedInputModel", layers=6, fusion=True,
+            workload="screening (BASELINE config 5): eval-mode forward of MixedInputModel F=167 at B=4096 + the shipped linear "
+                     "meta-learner over [nn, rf, xgb] with synthetic rf / xgb columns",
+            metric="molecules/sec stacked-ensemble inference (B=4096)", candidates=("conv2_fwd",)),
+}
 
 
-def fwd_flops(B, F, L=6, dff=2048):
+def fwd_flops(B, F, L=6, dff=2048, fusion=True):
     """algorithmic forward FLOPs (2 * MACs) per batch."""
     enc = L * (2 * B * F * 3 * F + 4 * B * B * F + 2 * B * F * F + 4 * B * F * dff)
     conv1 = 2 * B * 32 * 128 * 128 * 27
     conv2 = 2 * B * 64 * 64 * 64 * 288
     return dict(encoder=enc, fp_fc=2 * B * F * 128, conv1=conv1, conv2=conv2, img_fc=2 * B * 65536 * 128,
-                fusion=2 * B * 4 * (256 * 128 + 128), head=2 * B * (256 * 256 + 256 * 128 + 128 * 64 + 64))
+                fusion=2 * B * 4 * (256 * 128 + 128) if fusion else 0, head=2 * B * (256 * 256 + 256 * 128 + 128 * 64 + 64))
 
 
-def synthetic_b3db(n, F, seed, device):
-    """Bernoulli(0.25) MACCS bits (bit 0 unused) column-standardised; white images with ~6 % dark
-    bond pixels on three equal channels, standardised; labels N(-0.1, 0.8^2) clipped to [-2, 1.7]."""
+def synthetic_b3db(n, F, seed, device, bit_p=None):
+    """Bernoulli fingerprint bits (p = 0.25 MACCS with bit 0 unused, 0.02 Morgan-2048) column-standardised; white
+    images with ~6 % dark bond pixels on three equal channels, standardised; labels N(-0.1, 0.8^2) clipped to [-2, 1.7]."""
     g = torch.Generator().manual_seed(seed)
-    bits = (torch.rand(n, F, generator=g) < 0.25).float()
+    p = bit_p if bit_p is not None else (0.25 if F <= 256 else 0.02)
+    bits = (torch.rand(n, F, generator=g) < p).float()
     bits[:, 0] = 0
     fp = (bits - bits.mean(0)) / bits.std(0).clamp_min(1e-6)
     fp[:, 0] = 0
@@ -53,50 +85,80 @@ def synthetic_b3db(n, F, seed, device):
     img = plane.repeat(1, 3)
     img = (img - img.mean()) / img.std()
     y = (torch.randn(n, generator=g) * 0.8 - 0.1).clamp(-2.0, 1.7)
+    if device is None:
+        return fp, img, y
     return fp.to(device), img.to(device), y.to(device)
 
 
-def cpu_baseline(fp, img, y, state, iters=3):
-    """Time the CPU oracle for the same train step (forward + MSE + backward + AdamW) on the host cores."""
-    from oracle import reference_cpu as oracle
-    # a 1-GPU box shares a 256-thread host: its CPU share is 16 cores, and oversubscribing costs 20x
+def host_threads():
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(16, avail)))
-    p = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in state.items()}
-    keys = [k for k, v in p.items() if v.requires_grad]
-    m = {k: torch.zeros_like(p[k]) for k in keys}
-    v2 = {k: torch.zeros_like(p[k]) for k in keys}
+    return max(1, min(16, avail))        # a 1-GPU box shares a 256-thread host: its CPU share is 16 cores
+
+
+def cpu_baseline_model(cfg, fp, img, y, state):
+    """Time the CPU oracle for the same step on the host cores: a bounded sample (about 10-30 s of CPU work)."""
+    from oracle import reference_cpu as oracle
+    torch.set_num_threads(host_threads())
+    kw = dict(num_layers=cfg["layers"], fusion="attention" if cfg["fusion"] else "concat")
     fp, img, y = fp.cpu(), img.cpu(), y.cpu()
-    times = []
-    for it in range(iters + 1):
-        t0 = time.perf_counter()
-        for k in keys:
-            p[k].grad = None
-        loss = oracle.mse_loss(oracle.mixed_input_forward(p, fp, img, training=True, bn_state={}), y)
-        loss.backward()
-        with torch.no_grad():
+    B = fp.shape[0]
+    iters = 3 if cfg["F"] <= 256 and B <= 512 else 1
+    if not cfg["train"]:
+        p = {k: v.detach().cpu() for k, v in state.items()}
+        times = []
+        for it in range(iters + 1):
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                oracle.mixed_input_forward(p, fp, img, training=False, **kw)
+            times.append(time.perf_counter() - t0)
+        t = sum(times[1:]) / iters
+        what = "eval-mode forward"
+    else:
+        p = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in state.items()}
+        keys = [k for k, v in p.items() if v.requires_grad]
+        m = {k: torch.zeros_like(p[k]) for k in keys}
+        v2 = {k: torch.zeros_like(p[k]) for k in keys}
+        times = []
+        for it in range(iters + 1):
+            t0 = time.perf_counter()
             for k in keys:
-                oracle.adamw_step(p[k], p[k].grad, m[k], v2[k], it + 1)
-        times.append(time.perf_counter() - t0)
-    t = sum(times[1:]) / iters
-    return dict(value=round(fp.shape[0] / t, 2), unit="molecules/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{iters} steps of B={fp.shape[0]} forward+MSE+backward+AdamW after 1 warm-up ({t:.2f} s/step), "
-                       "oracle/reference_cpu.py on torch CPU fp32")
+                p[k].grad = None
+            loss = oracle.mse_loss(oracle.mixed_input_forward(p, fp, img, training=True, bn_state={}, **kw), y)
+            loss.backward()
+            with torch.no_grad():
+                for k in keys:
+                    oracle.adamw_step(p[k], p[k].grad, m[k], v2[k], it + 1)
+            times.append(time.perf_counter() - t0)
+        t = sum(times[1:]) / iters
+        what = "forward+MSE+backward+AdamW"
+    return dict(value=round(B / t, 2), unit="molecules/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{iters} step(s) of B={B} {what} after 1 warm-up ({t:.2f} s/step), oracle/reference_cpu.py on torch CPU fp32")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)      # 0.75 s of timed work: long enough for the clocks to settle
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-isolated", action="store_true",
-                    help="skip the untimed overlap-off leg (profiles: every launch of the rocprofv3 kernel table is then an in-step one)")
-    args = ap.parse_args()
+def sources_sha():
+    """Hash of the kernel sources: a PMC traffic file is only quoted when it was collected with exactly these kernels."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "bbbp-multi-modal-deep-ensemble-framework_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
+
+def traffic_for(config, kernel):
+    path = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_traffic_config{config}.json")
+    if not os.path.exists(path):
+        return None, f"no PMC pass under profiles/ for config {config}"
+    d = json.load(open(path))
+    if d.get("sources_sha") != sources_sha():
+        return None, f"{os.path.basename(path)} was collected with other kernel sources ({d.get('sources_sha')})"
+    return d.get(kernel), os.path.basename(path)
+
+
+def setup_dist(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,31 +180,68 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, dev, dist
 
+
+def bench_model(args, cfg_id, rank, world, dev, dist):
     import bbbp_amd
     from bbbp_amd import _lib
     from bbbp_amd import distributed as D
     from bbbp_amd.optim import AdamW
 
+    cfg = CONFIGS[cfg_id]
+    F, train = cfg["F"], cfg["train"]
+    global_batch = args.batch or cfg["batch"]
+    if args.scaling == "strong":
+        if global_batch % world:
+            raise SystemExit(f"strong scaling: global batch {global_batch} is not divisible by {world} ranks")
+        BATCH = global_batch // world
+    else:
+        BATCH = global_batch
     torch.manual_seed(20250113)           # same initial weights on every rank
-    model = bbbp_amd.MixedInputModel(F_DIM, 128).to(dev).train()
-    opt = AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5)
+    model = getattr(bbbp_amd, cfg["model"])(F, 128).to(dev).train(train)
+    opt = AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5) if train else None
     crit = bbbp_amd.MSELoss()             # nn.MSELoss semantics, value + gradient in one kernel
-    fp, img, y = synthetic_b3db(2 * BATCH, F_DIM, 20250113 + rank, dev)
     params = list(model.parameters())
-    # N > 1: the image-FC weight gradient (62 % of the bytes) is all-reduced under the rest of the backward pass, the
-    # remainder after it (distributed.OverlappedGradAllReduce); BBBP_BENCH_PLAIN_ALLREDUCE=1 selects the single collective
+    stack = rf_col = xgb_col = None
+    feeder = None
+    if args.host_fed:
+        from bbbp_amd.preprocess import HostFedBatches
+        hfp, himg, hy = synthetic_b3db(2 * BATCH, F, 20250113 + rank, None)
+        feeder = HostFedBatches(hfp, himg, hy, BATCH, dev)
+        fp = img = y = None
+    else:
+        fp, img, y = synthetic_b3db(2 * BATCH, F, 20250113 + rank, dev)
+    if cfg_id == 5:
+        from bbbp_amd.ensemble import StackedEnsemble
+        stack = StackedEnsemble.from_coefficients([0.19813994153864287, 0.8730076113813537, 0.16470120078934247], 0.019492486407121146)
+        g = torch.Generator().manual_seed(5)
+        rf_col = torch.randn(2 * BATCH, generator=g, dtype=torch.float64).to(dev)
+        xgb_col = torch.randn(2 * BATCH, generator=g, dtype=torch.float64).to(dev)
+    # N > 1: gradient buckets are all-reduced under the rest of the backward pass (distributed.OverlappedGradAllReduce);
+    # BBBP_BENCH_PLAIN_ALLREDUCE=1 selects the single collective after the pass
     reducer = None
-    if world > 1 and os.environ.get("BBBP_BENCH_PLAIN_ALLREDUCE", "0") != "1":
+    if train and world > 1 and os.environ.get("BBBP_BENCH_PLAIN_ALLREDUCE", "0") != "1":
         reducer = D.OverlappedGradAllReduce(model)
 
     opt_events = []                       # (start, end) around the optimizer step, only while `time_opt` is set (untimed pass)
     time_opt = [False]
 
-    def step(i, collective=True):
+    def batch_of(i):
+        if feeder is not None:
+            return feeder.next()
         s = (i % 2) * BATCH
-        out = model(fp[s:s + BATCH], img[s:s + BATCH]).squeeze()
-        loss = crit(out, y[s:s + BATCH])
+        return fp[s:s + BATCH], img[s:s + BATCH], y[s:s + BATCH]
+
+    def step(i, collective=True):
+        bfp, bimg, by = batch_of(i)
+        if not train:
+            s = (i % 2) * BATCH
+            with torch.no_grad():
+                nn_col = model(bfp, bimg).reshape(-1)
+                return stack.predict_device(nn_col, rf_col[s:s + BATCH], xgb_col[s:s + BATCH])
+        out = model(bfp, bimg).squeeze()
+        loss = crit(out, by)
         loss.backward()
         if time_opt[0]:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -153,7 +252,7 @@ def main():
             opt.zero_grad(set_to_none=True)
             return loss
         if world > 1 and collective:
-            # ONE RCCL sum over xGMI when the gradients are one flat buffer (they are); 1/world folded into AdamW
+            # the 1/world of the mean is folded into AdamW (grad_scale)
             if reducer is not None:
                 reducer(params, average=False)
             else:
@@ -172,21 +271,21 @@ def main():
     L = _lib.lib()
     nsec = L.bbbp_profile_num_sections()
     names = [L.bbbp_profile_section_name(i).decode() for i in range(nsec)]
-    # HIP events on the launch stream, recorded INSIDE the timed region, around the three conv2 kernels only (the
-    # candidates for the dominant kernel); the full per-section breakdown comes from an untimed pass below
-    L.bbbp_profile_select(sum(1 << i for i, n in enumerate(names) if n.startswith("conv2_")))
+    # HIP events on the launch stream, recorded INSIDE the timed region, around the candidates for the dominant kernel only;
+    # the full per-section breakdown comes from an untimed pass below
+    L.bbbp_profile_select(sum(1 << i for i, n in enumerate(names) if n in cfg["candidates"]))
     L.bbbp_profile_enable(1)
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = step(i)
+        last = step(i)
     fence()
     elapsed = time.perf_counter() - t0
     ms_sum = (ctypes.c_float * nsec)()
     cnt = (ctypes.c_int * nsec)()
     _lib.check(L.bbbp_profile_collect(ms_sum, cnt), "bbbp_profile_collect")     # events of the timed region itself
     L.bbbp_profile_enable(0)
-    sections = {L.bbbp_profile_section_name(i).decode(): ms_sum[i] / cnt[i] for i in range(nsec) if cnt[i]}
+    sections = {names[i]: ms_sum[i] / cnt[i] for i in range(nsec) if cnt[i]}
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -195,7 +294,7 @@ def main():
     # outside the timed region: every section with the overlap on (where the step goes) ...
     if rank == 0:
         L.bbbp_profile_enable(1)
-        time_opt[0] = True
+        time_opt[0] = train
         for i in range(5):
             step(i, collective=False)        # rank 0 only: no collective here, the other ranks wait in the barrier below
         time_opt[0] = False
@@ -205,9 +304,8 @@ def main():
         for i in range(nsec):
             if cnt[i] and names[i] not in sections:
                 sections[names[i]] = ms_sum[i] / cnt[i]
-    # ... and the same kernels with the branch overlap off, i.e. each conv kernel alone on the GPU
-    isolated = {}
-    clock = {}
+    # ... and the same kernels with the branch overlap off, i.e. each kernel alone on the GPU
+    isolated, clock = {}, {}
     if rank == 0 and not args.no_isolated:
         old = L.bbbp_set_overlap(0)
         for i in range(2):
@@ -219,76 +317,196 @@ def main():
         _lib.check(L.bbbp_profile_collect(ms_sum, cnt), "bbbp_profile_collect")
         L.bbbp_profile_enable(0)
         L.bbbp_set_overlap(old)
-        isolated = {L.bbbp_profile_section_name(i).decode(): ms_sum[i] / cnt[i] for i in range(nsec) if cnt[i]}
-        # the last forward / data-gradient conv launch of a step is conv2's data gradient: its work-group 0 counted
-        # shader cycles and 100 MHz wall ticks (include/bbbp_hip.h: bbbp_conv_last_clock)
-        cyc, ticks = ctypes.c_uint64(0), ctypes.c_uint64(0)
-        _lib.check(L.bbbp_conv_last_clock(ctypes.byref(cyc), ctypes.byref(ticks)), "bbbp_conv_last_clock")
-        clock = dict(cycles=int(cyc.value), ghz=(cyc.value / (ticks.value * 10.0)) if ticks.value else None)
+        isolated = {names[i]: ms_sum[i] / cnt[i] for i in range(nsec) if cnt[i]}
+        if train:
+            # the last forward / data-gradient conv launch of a training step is conv2's data gradient: its work-group 0 counted
+            # shader cycles and 100 MHz wall ticks (include/bbbp_hip.h: bbbp_conv_last_clock)
+            cyc, ticks = ctypes.c_uint64(0), ctypes.c_uint64(0)
+            _lib.check(L.bbbp_conv_last_clock(ctypes.byref(cyc), ctypes.byref(ticks)), "bbbp_conv_last_clock")
+            clock = dict(cycles=int(cyc.value), ghz=(cyc.value / (ticks.value * 10.0)) if ticks.value else None)
     if world > 1:
         dist.barrier()
+    if rank != 0:
+        return None
 
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * BATCH * args.steps / elapsed
+    fl = fwd_flops(BATCH, F, L=cfg["layers"], fusion=cfg["fusion"])
+    conv2 = fl["conv2"]
+    ffn1 = 2 * BATCH * F * 2048
+    kernel_flops = {"conv2_fwd": conv2, "conv2_dgrad": conv2, "conv2_wgrad": conv2, "ffn1_fwd": ffn1}
+    cand = {k: sections[k] for k in cfg["candidates"] if k in sections}
+    # conv2's forward / data gradient may run as Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36.  The roofline
+    # line prices the kernel at the algorithmic (direct) flop count of SURVEY.md 8(d); `winograd` also gives the executed flops.
+    wmask = L.bbbp_get_conv_winograd()
+    wino = {k: bool(wmask & bit) for k, bit in (("conv2_fwd", 1), ("conv2_dgrad", 2))}
+    roofline = None
+    if cand:
+        dom = max(cand, key=cand.get)
+        kf = kernel_flops[dom]
+        achieved = kf / (cand[dom] * 1e-3) / 1e12
+        traffic, tsrc = traffic_for(cfg_id, dom)
+        roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=tsrc,
+                        flops_per_launch=kf, ms_per_launch=round(cand[dom], 4),
+                        note="timed inside the step, where the kernel shares the GPU with the other branch's side-stream "
+                             "kernels; *_isolated = same kernel, overlap off, after the timed region",
+                        ms_per_launch_isolated=round(isolated.get(dom, 0.0), 4),
+                        frac_isolated=round(kf / (isolated[dom] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if isolated.get(dom) else None,
+                        sections_ms={k: round(v, 4) for k, v in sections.items()})
+        roofline["algorithm"] = ("winograd F(2x2,3x3) f32" if wino.get(dom) else "direct implicit GEMM f32") if dom.startswith("conv2") \
+            else "f32 MFMA GEMM (linear1 of one encoder layer, M=B, N=2048, K=F)"
+        if any(wino.get(k) and k in sections for k in wino):
+            roofline["winograd"] = {
+                k: dict(ms_per_launch=round(sections[k], 4), ms_per_launch_isolated=round(isolated.get(k, 0.0), 4),
+                        executed_flops_per_launch=conv2 * 16 // 36,
+                        direct_equivalent_tflops=round(conv2 / (sections[k] * 1e-3) / 1e12, 2),
+                        executed_frac_of_peak=round(conv2 * 16 / 36 / (sections[k] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+                for k in wino if wino[k] and k in sections}
+        if clock.get("ghz"):
+            # one v_mfma_f32_32x32x2_f32 = 4096 flop and occupies its SIMD's matrix pipe for 64 cycles
+            n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+            executed = conv2 * 16 / 36 if wino["conv2_dgrad"] else conv2
+            roofline["conv2_dgrad_isolated_clock"] = dict(
+                sustained_ghz=round(clock["ghz"], 3), kernel_cycles=clock["cycles"],
+                mfma_pipe_busy=round(executed / 4096 * 64 / n_simd / clock["cycles"], 4),
+                note="shader clock while the kernel runs alone; the 157.3 TFLOP/s peak assumes 2.4 GHz")
+    fwd_total = sum(fl.values())
+    total_flops = (fwd_total * 3 - fl["conv1"]) if train else fwd_total          # bwd = 2 * fwd - conv1 dgrad
+    result = {
+        "metric": cfg["metric"], "value": round(value, 1), "unit": "molecules/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": cfg["workload"], "baseline_config": cfg_id, "global_batch": BATCH * world, "per_gpu_batch": BATCH,
+                   "parallelism": f"dp{world}", "gflop_per_step_per_gpu": round(total_flops / 1e9, 1),
+                   "input": "host-fed (pinned, double-buffered copy stream)" if args.host_fed else "device-resident"},
+        "model_tflops_per_gpu": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
+        "roofline": roofline,
+    }
+    if train:
+        # the metric's "+ optimizer step reported separately": fused AdamW over the flat parameter buffer (one launch,
+        # 16 B read + 12 B written per parameter), included in ms_per_step
+        result["optimizer_ms_per_step"] = round(sum(a.elapsed_time(b) for a, b in opt_events) / len(opt_events), 4) if opt_events else None
+        result["final_loss"] = round(float(last.detach()), 5)
+    if world == 1 and not args.no_cpu_baseline:
+        if feeder is not None:
+            bfp, bimg, by = feeder.host_batch(0)
+        else:
+            bfp, bimg, by = fp[:BATCH], img[:BATCH], y[:BATCH]
+        result["cpu_baseline"] = cpu_baseline_model(cfg, bfp, bimg, by, model.state_dict())
+    return result
+
+
+def bench_mlp_grid(args, rank, world, dev, dist):
+    """BASELINE config 1: the reference's MLPClassifier grid (54 parameter points x 5 folds = 270 fits on [6245, 100] float64,
+    Models/model_opt_maccs.py:133,170-181) as one batched job per rank (csrc/mlp.hip: one persistent work-group per fit,
+    scikit-learn's float64 arithmetic).  A step = one epoch of every fit; N ranks split the fits (weak: 270 each)."""
+    import numpy as np
+    from itertools import product
+    from sklearn.model_selection import StratifiedKFold
+    from bbbp_amd.mlp import GridMLPTrainer, MLPConfig
+    rs = np.random.RandomState(rank)
+    n, f = 6245, 100
+    X = rs.randn(n, f)
+    y = ((X @ rs.randn(f) + 2.0 * rs.randn(n)) > 0).astype(np.float64)
+    grid = {"hidden_layer_sizes": [(100,), (100, 50), (200, 100)], "activation": ["relu", "tanh"],
+            "learning_rate_init": [0.001, 0.01, 0.1], "batch_size": [32, 64, 128]}
+    keys = sorted(grid)
+    points = [dict(zip(keys, vals)) for vals in product(*(grid[k] for k in keys))]
+    folds = list(StratifiedKFold(5).split(X, y))
+
+    def configs(epochs):
+        out = []
+        for pt in points:
+            for tr, _ in folds:
+                out.append(MLPConfig(max_iter=epochs, tol=0.0, n_iter_no_change=10 ** 9, train_rows=tr, random_state=0, **pt))
+        if args.scaling == "strong":
+            out = out[rank::world]
+        return out
+
+    trainer = GridMLPTrainer(X, y, device=dev)
+    if args.warmup:
+        trainer.fit(configs(args.warmup), epochs_per_launch=args.warmup)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fitted = trainer.fit(configs(args.steps), epochs_per_launch=min(8, args.steps))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    visits = sum(m.n_iter_ * len(m.config.train_rows) for m in fitted)
+    if world > 1:
+        t = torch.tensor([elapsed, float(visits)], device=dev, dtype=torch.float64)
+        dist.all_reduce(t[0:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:2], op=dist.ReduceOp.SUM)
+        elapsed, visits = float(t[0]), float(t[1])
+    if rank != 0:
+        return None
+    assert all(m.n_iter_ == args.steps for m in fitted), "every fit must run exactly --steps epochs"
+    flops = 0
+    for m in fitted:
+        u = [f] + list(m.config.hidden_layer_sizes) + [1]
+        flops += 6 * sum(a * b for a, b in zip(u[:-1], u[1:])) * m.n_iter_ * len(m.config.train_rows)      # fwd + 2 x bwd GEMMs
+    result = {
+        "metric": "sample-visits/sec fwd+bwd (MLPClassifier grid, 270 fits, [6245,100] f64)", "value": round(visits / elapsed, 1),
+        "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "MLPClassifier grid of Models/model_opt_maccs.py:170-181 (hidden (100,)/(100,50)/(200,100) x relu/tanh x lr "
+                               "1e-3/1e-2/1e-1 x batch 32/64/128, 5 folds), one epoch of all fits per step (BASELINE config 1)",
+                   "baseline_config": 1, "fits_per_gpu": len(fitted), "rows": n, "features": f, "parallelism": f"dp{world}"},
+        # serial mini-batch chains, one work-group per fit: the kernel is bound by dependent-instruction latency, not by a roofline;
+        # priced against the f32 matrix peak only to put a number on it (float64 FMA loops on the vector ALU)
+        "roofline": {"bound": "mfma", "kernel": "mlp_train_kernel", "achieved": round(flops / elapsed / 1e12, 4), "peak": PEAK_F32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(flops / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 6), "traffic": None,
+                     "note": "latency-bound by construction (270 work-groups, each a serial chain of mini-batch updates in float64); wall "
+                             "time of the whole fit() call incl. the host-side row shuffles"},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        import warnings
+        from sklearn.neural_network import MLPClassifier
+        sample = [0, 100, 200, 269]
+        t_cpu, v_cpu = 0.0, 0
+        ep = max(2, min(args.steps, 10))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for i in sample:
+                c = fitted[i].config
+                t1 = time.perf_counter()
+                m = MLPClassifier(hidden_layer_sizes=tuple(c.hidden_layer_sizes), activation=c.activation, learning_rate_init=c.learning_rate_init,
+                                  batch_size=c.batch_size, max_iter=ep, tol=0.0, n_iter_no_change=10 ** 9, random_state=0).fit(X[c.train_rows], y[c.train_rows])
+                t_cpu += time.perf_counter() - t1; v_cpu += m.n_iter_ * len(c.train_rows)
+        result["cpu_baseline"] = dict(value=round(v_cpu / t_cpu, 1), unit="molecules/s", cores=1, kind="reference",
+                                      sample=f"scikit-learn MLPClassifier.fit itself (the reference's third-party arithmetic), {len(sample)} of the 270 fits x {ep} epochs, one process")
+    return result
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)     # default per config: ~0.7 s of timed work, long enough for the clocks to settle
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=3, choices=(1, 2, 3, 4, 5), help="BASELINE.json configuration (default 3, the headline)")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
+    ap.add_argument("--batch", type=int, default=None, help="override the configuration's (global) batch size")
+    ap.add_argument("--host-fed", action="store_true", help="feed batches from pinned host memory through the double-buffered loader")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-isolated", action="store_true",
+                    help="skip the untimed overlap-off leg (profiles: every launch of the rocprofv3 kernel table is then an in-step one)")
+    args = ap.parse_args()
+    default_steps = {1: (10, 2), 2: (300, 20), 3: (200, 20), 4: (40, 5), 5: (60, 5)}[args.config]
+    if args.steps is None:
+        args.steps = default_steps[0]
+    if args.warmup is None:
+        args.warmup = default_steps[1]
+    rank, world, dev, dist = setup_dist(args)
+    if args.config == 1:
+        result = bench_mlp_grid(args, rank, world, dev, dist)
+    else:
+        result = bench_model(args, args.config, rank, world, dev, dist)
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = world * BATCH * args.steps / elapsed
-        fl = fwd_flops(BATCH, F_DIM)
-        conv2 = fl["conv2"]
-        cand = {k: sections[k] for k in ("conv2_fwd", "conv2_dgrad", "conv2_wgrad") if k in sections}
-        # conv2's forward / data gradient may run as Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36.  The
-        # roofline line is the slowest conv2 kernel priced at the algorithmic (direct) flop count of SURVEY.md 8(d); for the
-        # Winograd kernels `winograd` below also gives the MFMA flops they actually execute.
-        wmask = L.bbbp_get_conv_winograd()
-        wino = {k: bool(wmask & bit) for k, bit in (("conv2_fwd", 1), ("conv2_dgrad", 2))}
-        roofline = None
-        if cand:
-            dom = max(cand, key=cand.get)
-            achieved = conv2 / (cand[dom] * 1e-3) / 1e12
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(dom)
-            roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                            frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
-                            flops_per_launch=conv2, ms_per_launch=round(cand[dom], 4),
-                            note="timed inside the training step, where the kernel shares the GPU with the fingerprint "
-                                 "branch's side-stream kernels; *_isolated = same kernel, overlap off, after the timed region",
-                            ms_per_launch_isolated=round(isolated.get(dom, 0.0), 4),
-                            frac_isolated=round(conv2 / (isolated[dom] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if isolated.get(dom) else None,
-                            sections_ms={k: round(v, 4) for k, v in sections.items()})
-            roofline["algorithm"] = "winograd F(2x2,3x3) f32" if wino.get(dom) else "direct implicit GEMM f32"
-            if any(wino.values()):
-                roofline["winograd"] = {
-                    k: dict(ms_per_launch=round(sections[k], 4), ms_per_launch_isolated=round(isolated.get(k, 0.0), 4),
-                            executed_flops_per_launch=conv2 * 16 // 36,
-                            direct_equivalent_tflops=round(conv2 / (sections[k] * 1e-3) / 1e12, 2),
-                            executed_frac_of_peak=round(conv2 * 16 / 36 / (sections[k] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
-                    for k in wino if wino[k] and k in sections}
-            if clock.get("ghz"):
-                # one v_mfma_f32_32x32x2_f32 = 4096 flop and occupies its SIMD's matrix pipe for 64 cycles
-                n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
-                executed = conv2 * 16 / 36 if wino["conv2_dgrad"] else conv2
-                roofline["conv2_dgrad_isolated_clock"] = dict(
-                    sustained_ghz=round(clock["ghz"], 3), kernel_cycles=clock["cycles"],
-                    mfma_pipe_busy=round(executed / 4096 * 64 / n_simd / clock["cycles"], 4),
-                    note="shader clock while the kernel runs alone; the 157.3 TFLOP/s peak assumes 2.4 GHz")
-        total_flops = sum(fl.values()) * 3 - fl["conv1"]          # bwd = 2 * fwd - conv1 dgrad
-        result = {
-            "metric": "molecules/sec fwd+bwd (3-branch ensemble, B=512)", "value": round(value, 1), "unit": "molecules/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "MixedInputModel F=167 (MACCS) + 3x128x128 image, 6-layer encoder + 2-stage CNN + fusion + "
-                                   "BN head; forward + MSE + backward + fused AdamW, train mode (dropout 0.1)",
-                       "global_batch": BATCH * world, "per_gpu_batch": BATCH, "parallelism": f"dp{world}",
-                       "gflop_per_step_per_gpu": round(total_flops / 1e9, 1)},
-            "model_tflops_per_gpu": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
-            # the metric's "+ optimizer step reported separately": fused AdamW over the flat parameter buffer (one launch,
-            # 16 B read + 12 B written per parameter), included in ms_per_step
-            "optimizer_ms_per_step": round(sum(a.elapsed_time(b) for a, b in opt_events) / len(opt_events), 4) if opt_events else None,
-            "final_loss": round(float(loss.detach()), 5),
-            "roofline": roofline,
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(fp[:BATCH], img[:BATCH], y[:BATCH], model.state_dict())
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()

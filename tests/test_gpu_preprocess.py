@@ -58,3 +58,30 @@ def test_chunked_standard_scaler_matches_sklearn(dev):
         assert (diff <= tol).all(), f"{nm}: max diff {diff.max():.3e}"
         assert np.mean(got == want) > 0.99, f"{nm}: only {np.mean(got == want):.4f} of the values are bit-identical"
     assert float(np.abs(got_fp[:, 0].cpu().numpy()).max()) == 0.0
+
+
+def test_host_fed_batches_are_bit_identical_to_synchronous_copies(dev):
+    """preprocess.HostFedBatches: pinned dataset, copy stream, two device buffers filled one batch ahead -- every batch equals the
+    synchronous `rows.to(device)` bit for bit, across the wrap-around, while a consumer kernel is still reading the previous
+    buffer (the consumer here is a slow elementwise chain on the compute stream)."""
+    import torch
+    from bbbp_amd.preprocess import HostFedBatches
+    g = torch.Generator().manual_seed(0)
+    n, F, I, B = 37, 167, 49152, 8
+    fp = torch.randn(n, F, generator=g); img = torch.randn(n, I, generator=g); y = torch.randn(n, generator=g)
+    feeder = HostFedBatches(fp, img, y, B, dev)
+    sums = []
+    for k in range(12):                                  # 96 rows: wraps the 37-row dataset twice
+        bfp, bimg, by = feeder.next()
+        rows = torch.arange(k * B, (k + 1) * B) % n
+        hfp, himg, hy = feeder.host_batch(k)
+        assert torch.equal(hfp, fp[rows]) and torch.equal(hy, y[rows])
+        acc = bimg
+        for _ in range(20):                               # keep the compute stream busy with this buffer
+            acc = acc * 1.0000001 + 0.0
+        sums.append((acc.sum(), bimg.clone(), bfp.clone(), by.clone(), rows))
+    torch.cuda.synchronize()
+    for s, cimg, cfp, cy, rows in sums:
+        assert torch.equal(cimg.cpu(), img[rows]) and torch.equal(cfp.cpu(), fp[rows]) and torch.equal(cy.cpu(), y[rows])
+    with pytest.raises(ValueError):
+        HostFedBatches(fp, img[:5], y, B, dev)

@@ -1,13 +1,26 @@
 """HBM traffic per launch of the conv kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
 
-usage: pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv OUT.json
+usage: pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv OUT.json [CONFIG]
+The output records a hash of the kernel sources it was collected with (bench.py quotes the traffic only for those sources).
 Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters
 are in KiB; on gfx950 FETCH_SIZE counts 64-byte units of the 128-byte wide reads as one, so fetched bytes = raw x 1024 x 2.
 """
 import collections
 import csv
+import hashlib
 import json
+import os
 import sys
+
+
+def sources_sha():
+    """Same hash as bench.py: sources_sha()."""
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bbbp-multi-modal-deep-ensemble-framework_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 KERNELS = {            # a section maps to whichever of its kernels ran (direct or Winograd form of conv2)
     "conv2_fwd": ("conv3x3_kernel<32, 64, 64, 0>", "wino_conv_kernel<0>"),
@@ -39,7 +52,9 @@ def main():
             out[k] = fb + wb
             out["_detail"][k] = dict(fetch_bytes_corrected=fb, write_bytes=wb, hbm_bytes=fb + wb, raw_FETCH_SIZE_KiB=fetch[k],
                                      raw_WRITE_SIZE_KiB=write[k])
-    out["_note"] = ("per launch, B=512; FETCH_SIZE KiB x1024 x2 (gfx950 wide-read correction, MI355X_MICROARCH.md HBM), "
+    out["sources_sha"] = sources_sha()
+    out["config"] = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+    out["_note"] = ("per launch at the configuration's batch size; FETCH_SIZE KiB x1024 x2 (gfx950 wide-read correction, MI355X_MICROARCH.md HBM), "
                     "WRITE_SIZE KiB x1024; separate --pmc passes")
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print({k: round(v / 1e6, 1) for k, v in out.items() if not k.startswith("_")}, "MB per launch")
