@@ -166,6 +166,21 @@ bool g_bucket_recorded[64];
 // and all weight-gradient leaves are done (~0.25 ms before the image branch's last kernel); recorded on the leaf stream
 hipEvent_t g_bucket1_event[64];
 bool g_bucket1_recorded[64];
+// buckets 2 + l: the twelve tensors of encoder layer l (one contiguous slice in named_parameters order) -- final when that
+// layer's weight-gradient leaves are, layer L-1 first.  At F = 2048 these are 100 MB each and 94 % of all gradient bytes.
+hipEvent_t g_layer_event[64][32];
+bool g_layer_recorded[64][32];
+int record_layer_bucket(hipStream_t leaf, int layer) {
+    int dev = 0;
+    BBBP_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || layer < 0 || layer >= 32) return BBBP_OK;
+    if (!g_layer_event[dev][layer]) BBBP_CHECK_HIP(hipEventCreateWithFlags(&g_layer_event[dev][layer], hipEventDisableTiming));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(leaf, &cap);
+    g_layer_recorded[dev][layer] = cap == hipStreamCaptureStatusNone;       // an event recorded inside a graph capture means nothing outside it
+    if (g_layer_recorded[dev][layer]) BBBP_CHECK_HIP(hipEventRecord(g_layer_event[dev][layer], leaf));
+    return BBBP_OK;
+}
 int g_overlap = -1;
 int g_fused_head_bwd = -1;
 // Row-local stretches of an encoder layer as single launches (encoder.hip) instead of 6 + 6 per layer: BBBP_FUSED_ENCODER=1 /
@@ -633,6 +648,17 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         cl.st = ss->leaf; cl.side = 2;
     }
     auto leaf_after = [&](const Ctx& producer) -> int { return ss ? after(ss, producer.st, cl.st) : BBBP_OK; };
+    // both LayerNorms' weight / bias gradients of layer l in ONE leaf launch (dgamma = sum_rows dy * xhat, dbeta = sum_rows dy),
+    // the last leaf of the layer: its gradient bucket (all twelve tensors, one contiguous slice) is final after it
+    auto layer_norm_leaves = [&](int l) -> int {
+        const LayerOff& o = plan.layer[l]; const LayerGrad& g = plan.lgrad[l];
+        const PIdx ixl(d);
+        const float* dy[2] = {c.f(g.dyout), c.f(g.dy1)}; const float* zz[2] = {c.f(o.z2), c.f(o.z1)};
+        const float* mm[2] = {c.f(o.mean2), c.f(o.mean1)}; const float* rr[2] = {c.f(o.rstd2), c.f(o.rstd1)};
+        float* dg[2] = {G[ixl.layer(l, L_N2W)], G[ixl.layer(l, L_N1W)]}; float* db[2] = {G[ixl.layer(l, L_N2B)], G[ixl.layer(l, L_N1B)]};
+        TRY(bbbp_ln_param_grad_multi(cl.st, 2, dy, zz, mm, rr, dg, db, plan.B, plan.F));
+        return record_layer_bucket(cl.st, l);
+    };
     const PIdx ix(d);
     const int B = plan.B, F = plan.F, NH = plan.NH, D = plan.D, DFF = plan.DFF;
     const float p_drop = plan.drop ? d->dropout_p : 0.f;
@@ -818,6 +844,7 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         }
         TRY(leaf_after(ce));
         TRY(linear_bwd_weight_bias(cl, dqkv, 3 * F, xin, F, G[ix.layer(l, L_INW)], G[ix.layer(l, L_INB)], B, 3 * F, F));
+        TRY(layer_norm_leaves(l));
         if (l == 0 && d->need_input_grad)
             TRY(linear_bwd_input(ce, dqkv, 3 * F, P[ix.layer(0, L_INW)], c.f(plan.dA), F, B, 3 * F, F, c.f(g.dz1), F));
     }
@@ -870,23 +897,9 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         TRY(leaf_after(ce));
         TRY(linear_bwd_weight_bias(cl, dsa, F, ctx, F, G[ix.layer(l, L_OUTW)], G[ix.layer(l, L_OUTB)], B, F, F));
         TRY(linear_bwd_weight_bias(cl, dqkv, 3 * F, xin, F, G[ix.layer(l, L_INW)], G[ix.layer(l, L_INB)], B, 3 * F, F));
+        TRY(layer_norm_leaves(l));
         if (l > 0) TRY(linear_bwd_input(ce, dqkv, 3 * F, P[ix.layer(l, L_INW)], c.f(plan.lgrad[l - 1].dyout), F, B, 3 * F, F, dz1, F));
         else if (d->need_input_grad) TRY(linear_bwd_input(ce, dqkv, 3 * F, P[ix.layer(l, L_INW)], c.f(plan.dA), F, B, 3 * F, F, dz1, F));
-    }
-    if (plan.L > 0) {
-        // all LayerNorm weight / bias gradients (leaves: nothing waits for them before the optimizer) in one launch at the end of
-        // the leaf stream -- both schedules keep dyout / dy1 and z / mean / rstd per layer
-        const float *dy[64], *zz[64], *mm[64], *rr[64]; float *dg[64], *db[64];
-        int n = 0;
-        for (int l = 0; l < plan.L; ++l) {
-            const LayerOff& o = plan.layer[l]; const LayerGrad& g = plan.lgrad[l];
-            dy[n] = c.f(g.dyout); zz[n] = c.f(o.z2); mm[n] = c.f(o.mean2); rr[n] = c.f(o.rstd2);
-            dg[n] = G[ix.layer(l, L_N2W)]; db[n] = G[ix.layer(l, L_N2B)]; ++n;
-            dy[n] = c.f(g.dy1); zz[n] = c.f(o.z1); mm[n] = c.f(o.mean1); rr[n] = c.f(o.rstd1);
-            dg[n] = G[ix.layer(l, L_N1W)]; db[n] = G[ix.layer(l, L_N1B)]; ++n;
-        }
-        TRY(leaf_after(ce));
-        TRY(bbbp_ln_param_grad_multi(cl.st, n, dy, zz, mm, rr, dg, db, B, F));
     }
     {
         // bucket 1 is final when the chain AND the leaves are: make the leaf stream wait for the chain's tail, record there
@@ -963,12 +976,12 @@ GraphKey make_key(int kind, const bbbp_mixed_desc* d, const void* a, const void*
 // that weight and the four conv tensors.  Returns BBBP_ERR_ARG when no such
 // event exists (no backward yet, or the backward was replayed from a graph): the caller then waits for the whole stream.
 extern "C" int bbbp_mixed_backward_wait_bucket(void* stream, int bucket) {
-    BBBP_CHECK_ARG(bucket == 0 || bucket == 1, "wait_bucket: unknown bucket %d", bucket);
+    BBBP_CHECK_ARG(bucket >= 0 && bucket < 2 + 32, "wait_bucket: unknown bucket %d", bucket);
     int dev = 0;
     BBBP_CHECK_HIP(hipGetDevice(&dev));
     BBBP_CHECK_ARG(dev >= 0 && dev < 64, "wait_bucket: device %d", dev);
-    hipEvent_t ev = bucket == 0 ? g_bucket_event[dev] : g_bucket1_event[dev];
-    const bool ok = bucket == 0 ? g_bucket_recorded[dev] : g_bucket1_recorded[dev];
+    hipEvent_t ev = bucket == 0 ? g_bucket_event[dev] : bucket == 1 ? g_bucket1_event[dev] : g_layer_event[dev][bucket - 2];
+    const bool ok = bucket == 0 ? g_bucket_recorded[dev] : bucket == 1 ? g_bucket1_recorded[dev] : g_layer_recorded[dev][bucket - 2];
     BBBP_CHECK_ARG(ev && ok, "wait_bucket: no event for bucket %d on device %d", bucket, dev);
     BBBP_CHECK_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), ev, 0));
     return BBBP_OK;
@@ -992,6 +1005,15 @@ extern "C" int bbbp_mixed_debug_ffn_gate(void* stream, const bbbp_mixed_desc* d,
 extern "C" int bbbp_mixed_bucket_param(const bbbp_mixed_desc* d, int bucket) {
     if (!d || bucket != 0) return -1;
     return PIdx(d).ifc_w();
+}
+// first parameter index and tensor count of a bucket whose tensors are consecutive in params[] order (0: the image-FC weight;
+// 2 + l: the twelve tensors of encoder layer l).  Bucket 1 (everything else) is not one range: returns -1.
+extern "C" int bbbp_mixed_bucket_range(const bbbp_mixed_desc* d, int bucket, int* first, int* count) {
+    if (!d || !first || !count || d->num_layers < 0 || d->num_layers > 32) return -1;
+    const PIdx ix(d);
+    if (bucket == 0) { *first = ix.ifc_w(); *count = 1; return 0; }
+    if (bucket >= 2 && bucket < 2 + d->num_layers) { *first = ix.layer(bucket - 2, L_INW); *count = L_COUNT; return 0; }
+    return -1;
 }
 
 extern "C" int bbbp_set_graphs(int on) { const int old = graphs_mode(); g_graphs_mode = on ? 1 : 0; return old; }

@@ -96,62 +96,96 @@ def allreduce_gradients(module_or_params, average: bool = True, group=None, buck
 
 
 class OverlappedGradAllReduce:
-    """Gradient all-reduce for the fused ``MixedInputModel`` that starts before the backward pass has finished.
+    """Gradient all-reduce for the fused engine models (``MixedInputModel`` and its concat variants) that starts before the
+    backward pass has finished.
 
-    The fused backward writes all gradients into one flat buffer.  Two slices are final early: the image-FC weight (62 % of
-    the bytes at F = 167) after the first GEMM of the image branch, and everything except it and the four conv tensors
-    when the fingerprint branch and its weight-gradient leaves are done (the image branch's last kernel is still
-    running).  Call this right after ``loss.backward()`` returns (the GPU is then still ~2 ms from the end of the pass):
-    those slices are reduced on a communication stream that waits only for the engine's bucket events, the conv tensors
-    (76 KB) on the current stream, i.e. after the pass.  Every rank issues the same collectives in the same order.
-    Falls back to ``allreduce_gradients`` whenever the layout or the events are not what it expects."""
+    The fused backward writes all gradients into one flat buffer, and slices of it are final early (engine.hip records an event
+    for each): the image-FC weight (62 % of the bytes at F = 167) after the first GEMM of the image branch; the twelve tensors of
+    encoder layer l when that layer's weight-gradient leaves are done -- layer L-1 first, 100 MB each at F = 2048, where the
+    encoder is 94 % of the gradient bytes; and everything except the four conv tensors when the fingerprint
+    branch and its leaves are done (the image branch's last kernel is still running).  Call this right after
+    ``loss.backward()`` returns: every early slice is reduced on a communication stream that waits only for its event, the conv
+    tensors (76 KB) on the current stream, i.e. after the pass.
 
-    def __init__(self, model, group=None):
-        self.model, self.group = model, group
-        self.early = model.image_cnn[7].weight
-        self.late = [model.image_cnn[0].weight, model.image_cnn[0].bias, model.image_cnn[3].weight, model.image_cnn[3].bias]
+    The SCHEDULE -- which slices, in which order -- is fixed at construction from the parameter layout, which is the same on
+    every rank, so all ranks issue the same collectives in the same order by construction.  Nothing falls back silently: a
+    missing event or an unexpected gradient layout raises.  HIP-graph replay of the engine calls is switched off while a reducer
+    exists (a replayed backward records no bucket events, and ranks could capture on different steps)."""
+
+    def __init__(self, model, group=None, min_world: int = 2):
+        import ctypes
+        from . import _lib
+        self.model, self.group, self.min_world = model, group, int(min_world)
         self.comm = None
+        L = _lib.lib()
+        L.bbbp_set_graphs(0)
+        params = list(model.parameters())
+        offs, o = [], 0
+        for p in params:
+            offs.append(o); o += p.numel()
+        self.total = o
+        offs.append(o)
+        desc = model._descriptor(2)
+        if L.bbbp_mixed_num_params(ctypes.byref(desc)) != len(params):
+            raise RuntimeError("OverlappedGradAllReduce: the model's parameter list is not the fused engine's")
+        first, count = ctypes.c_int(0), ctypes.c_int(0)
+        self.early = []                                   # (bucket id, lo, hi) in reduction order
+        order = [0] + [2 + l for l in range(desc.num_layers - 1, -1, -1)]
+        for b in order:
+            if L.bbbp_mixed_bucket_range(ctypes.byref(desc), b, ctypes.byref(first), ctypes.byref(count)) != 0:
+                raise RuntimeError(f"OverlappedGradAllReduce: no range for gradient bucket {b}")
+            self.early.append((b, offs[first.value], offs[first.value + count.value]))
+        conv = [model.image_cnn[0].weight, model.image_cnn[0].bias, model.image_cnn[3].weight, model.image_cnn[3].bias]
+        ids = [next(i for i, q in enumerate(params) if q is c) for c in conv]
+        if ids != list(range(ids[0], ids[0] + 4)):
+            raise RuntimeError("OverlappedGradAllReduce: the conv tensors are not consecutive parameters")
+        self.late = (offs[ids[0]], offs[ids[0] + 4])
+        # bucket 1: the complement of the early slices and the conv tensors
+        taken = sorted([(lo, hi) for _, lo, hi in self.early] + [self.late])
+        self.rest, cur = [], 0
+        for lo, hi in taken:
+            if lo > cur:
+                self.rest.append((cur, lo))
+            cur = max(cur, hi)
+        if cur < self.total:
+            self.rest.append((cur, self.total))
+
+    def schedule(self):
+        """The collectives of one call, in order: (stream, bucket event waited for, lo, hi) -- identical on every rank."""
+        return ([("comm", b, lo, hi) for b, lo, hi in self.early] + [("comm", 1, lo, hi) for lo, hi in self.rest]
+                + [("current", None, self.late[0], self.late[1])])
 
     def __call__(self, params, average: bool = False) -> int:
         from . import _lib
         world = world_size(self.group)
-        if world == 1:
+        if world < self.min_world:
             return 0
-        params = _params_with_grad(list(params))
-        flat = flat_view_of([p.grad for p in params]) if params else None
-        g = self.early.grad
-        if flat is None or g is None or not flat.is_cuda or any(p.grad is None for p in self.late):
-            return allreduce_gradients(params, average=average, group=self.group)
-        es = flat.element_size()
-        a0 = (g.data_ptr() - flat.data_ptr()) // es
-        a1 = a0 + g.numel()
-        c0 = (self.late[0].grad.data_ptr() - flat.data_ptr()) // es
-        c1 = (self.late[-1].grad.data_ptr() - flat.data_ptr()) // es + self.late[-1].grad.numel()
-        # expected order in the flat buffer: [ ... | conv tensors | image-FC weight | ... ]
-        if not (0 <= c0 < c1 == a0 < a1 <= flat.numel()) or c1 - c0 != sum(p.grad.numel() for p in self.late):
-            return allreduce_gradients(params, average=average, group=self.group)
+        params = list(params)
+        if any(p.grad is None for p in params):
+            raise RuntimeError("OverlappedGradAllReduce: every parameter must have a gradient (call it right after backward())")
+        flat = flat_view_of([p.grad for p in params])
+        if flat is None or not flat.is_cuda or flat.numel() != self.total:
+            raise RuntimeError("OverlappedGradAllReduce: gradients are not the engine's one flat buffer; use allreduce_gradients")
         L = _lib.lib()
         if self.comm is None:
             self.comm = torch.cuda.Stream(device=flat.device)
-        if L.bbbp_mixed_backward_wait_bucket(self.comm.cuda_stream, 0) != 0:
-            return allreduce_gradients(params, average=average, group=self.group)     # no bucket event: plain path
         works, n = [], 0
-        with torch.cuda.stream(self.comm):
-            works.append(dist.all_reduce(flat[a0:a1], group=self.group, async_op=True)); n += 1
-        second_early = L.bbbp_mixed_backward_wait_bucket(self.comm.cuda_stream, 1) == 0
-        rest = [(0, c0), (a1, flat.numel())]
-        if second_early:
-            with torch.cuda.stream(self.comm):
-                for lo, hi in rest:
-                    if hi > lo:
-                        works.append(dist.all_reduce(flat[lo:hi], group=self.group, async_op=True)); n += 1
-            rest = []
-        for lo, hi in rest + [(c0, c1)]:            # on the current stream: after the whole pass
-            if hi > lo:
-                dist.all_reduce(flat[lo:hi], group=self.group); n += 1
+        for where, bucket, lo, hi in self.schedule():
+            if hi <= lo:
+                continue
+            if where == "comm":
+                _lib.check(L.bbbp_mixed_backward_wait_bucket(self.comm.cuda_stream, bucket), "bbbp_mixed_backward_wait_bucket")
+                with torch.cuda.stream(self.comm):
+                    w = dist.all_reduce(flat[lo:hi], group=self.group, async_op=True)
+                if w is not None:
+                    works.append(w)
+            else:
+                dist.all_reduce(flat[lo:hi], group=self.group)        # after the whole pass, on the current stream
+            n += 1
         for w in works:
-            w.wait()                             # the current stream waits for the early buckets
-        flat.record_stream(torch.cuda.current_stream())
+            w.wait()                             # the current stream waits for the early slices
+        torch.cuda.current_stream(flat.device).wait_stream(self.comm)
+        flat.record_stream(self.comm)
         if average:
             flat.div_(world)
         return n

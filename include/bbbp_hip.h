@@ -268,6 +268,10 @@ int bbbp_mixed_backward_wait_bucket(void* stream, int bucket);
  * zero may legitimately fall on either side, and ONE such element changes that unit's weight-gradient row by percents. */
 int bbbp_mixed_debug_ffn_gate(void* stream, const bbbp_mixed_desc* d, const void* workspace, int layer, uint8_t* gate);
 int bbbp_mixed_bucket_param(const bbbp_mixed_desc* d, int bucket);
+/* Buckets 2 + l (l = encoder layer): the layer's twelve tensors, final when its weight-gradient leaves are (layer L-1 first,
+ * layer 0 last).  bucket_range gives first parameter index and tensor count of bucket 0 or 2 + l (consecutive in params[]
+ * order, hence one slice of a flat gradient buffer); -1 otherwise. */
+int bbbp_mixed_bucket_range(const bbbp_mixed_desc* d, int bucket, int* first, int* count);
 /* HIP-graph replay of bbbp_mixed_forward / bbbp_mixed_backward: the second call with identical arguments is captured,
  * later ones are replayed with one hipGraphLaunch.  Opt-in (env BBBP_GRAPHS=1 or bbbp_set_graphs(1), which returns the
  * previous setting): measured slower than the eager three-stream enqueue on ROCm 7.2.  Counters since load. */

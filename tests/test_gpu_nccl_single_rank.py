@@ -1,0 +1,62 @@
+"""GPU, ONE rank on RCCL (backend "nccl" is RCCL on ROCm; world size 1 is legal): the communication-stream / async / wait /
+record_stream path of distributed.OverlappedGradAllReduce runs against the real library -- the 2-rank tests on a one-GPU box can
+only use gloo -- and leaves the gradients bit-unchanged (the sum over one rank is the identity)."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    import bbbp_amd
+    from bbbp_amd import distributed as D
+    from bbbp_amd.optim import AdamW
+    from helpers import synth_inputs
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    assert dist.get_backend() == "nccl"
+    F, B = 167, 24
+    fp, img, y = (t.to(dev) for t in synth_inputs(5, B, F, 49152))
+    out = {}
+    for use_reducer in (False, True):
+        torch.manual_seed(3)
+        m = bbbp_amd.MixedInputModel(F, 128).to(dev).train()
+        params = list(m.parameters())
+        opt = AdamW(params, lr=1e-3, weight_decay=1e-5)
+        reducer = D.OverlappedGradAllReduce(m, min_world=1) if use_reducer else None
+        torch.manual_seed(11)
+        for step in range(3):
+            bbbp_amd.MSELoss()(m(fp, img).squeeze(), y).backward()
+            if reducer is not None:
+                assert reducer(params, average=False) == 10          # image-FC weight, six layers, two remaining slices, conv tensors
+            g = torch.cat([p.grad.flatten() for p in params]).clone()
+            opt.step(grad_scale=1.0)
+            opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        out[use_reducer] = (g.cpu(), torch.cat([p.detach().flatten() for p in params]).cpu())
+    assert torch.equal(out[False][0], out[True][0]), "RCCL sum over one rank must leave the gradients bit-unchanged"
+    assert torch.equal(out[False][1], out[True][1])
+    # the plain helpers on RCCL too: one collective over the flat buffer, a parameter broadcast, a prediction gather
+    m = bbbp_amd.MixedInputModel(F, 128).to(dev).train()
+    bbbp_amd.MSELoss()(m(fp, img).squeeze(), y).backward()
+    assert D.allreduce_gradients(m, average=True) == 0            # world 1: nothing to do
+    flat = torch.cat([p.grad.flatten() for p in m.parameters()])
+    dist.all_reduce(flat)
+    D.broadcast_parameters(m, src=0)
+    assert D.gather_predictions(torch.arange(4.0, device=dev)).shape == (4,)
+    dist.barrier()
+    dist.destroy_process_group()
+    return "ok"
+
+
+def test_overlapped_allreduce_on_rccl_world_size_one():
+    from helpers import run_ranks
+    assert run_ranks(_worker, 1, timeout=300) == ["ok"]

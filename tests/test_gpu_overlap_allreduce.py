@@ -41,7 +41,13 @@ def _worker(rank, world, port):
                     p.grad = None
             results.append((n, g.cpu()))
         (n0, g0), (n1, g1) = results
-        assert n0 == 1 and n1 == 4, (n0, n1)                       # one collective vs image-FC weight + two early remainders + conv tensors
+        # one collective vs image-FC weight + six encoder layers (last layer first) + the two remaining slices + conv tensors
+        assert n0 == 1 and n1 == 10, (n0, n1)
+        sched = reducer.schedule()
+        assert [b for _, b, _, _ in sched] == [0, 7, 6, 5, 4, 3, 2, 1, 1, None]
+        covered = sorted((lo, hi) for _, _, lo, hi in sched)
+        assert covered[0][0] == 0 and covered[-1][1] == sum(p.numel() for p in params)
+        assert all(a[1] == b[0] for a, b in zip(covered, covered[1:])), "the slices tile the flat gradient buffer exactly once"
         assert torch.equal(g0, g1), f"rank {rank}: max diff {float((g0 - g1).abs().max()):.3e}"
         # and it really is the mean over ranks: rank 1's view equals rank 0's
         ref = g1.to(dev).clone()
