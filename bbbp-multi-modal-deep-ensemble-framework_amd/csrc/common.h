@@ -80,6 +80,11 @@ int bbbp_enc_row_fwd(hipStream_t st, const bbbp_enc_row_fwd_args* a);
 int bbbp_enc_row_bwd(hipStream_t st, const bbbp_enc_row_bwd_args* a);
 int bbbp_ln_param_grad_multi(hipStream_t st, int n, const float* const* dy, const float* const* z, const float* const* mean,
                              const float* const* rstd, float* const* dgamma, float* const* dbeta, int rows, int cols);
+// attention.hip: fused (flash-style) self-attention for many heads of head_dim 8 / 16, one work-group per head
+bool bbbp_attn_small_supported(int B, int nhead, int head_dim);
+int bbbp_attn_small_fwd(hipStream_t st, const float* qkv, float* ctx, float* lse, int B, int F, int nhead, float scale, float p, uint64_t seed);
+int bbbp_attn_small_bwd(hipStream_t st, const float* qkv, const float* ctx, const float* lse, const float* dctx, float* dqkv, int B, int F,
+                        int nhead, float scale, float p, uint64_t seed);
 constexpr size_t BBBP_CONV_MIN_LDS = 120 * 1024;
 // conv_wino.hip: Winograd F(2x2,3x3) form of the 32 -> 64 @ 64x64 stage; workspace = 16*32*64 floats of transformed filters
 int bbbp_wino_conv2_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* y, uint8_t* mask, int B,

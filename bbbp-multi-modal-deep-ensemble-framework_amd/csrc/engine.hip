@@ -53,7 +53,7 @@ struct Bump {
     size_t f(size_t n) { return take(n * sizeof(float)); }
 };
 
-struct LayerOff { size_t qkv, prob, pd, ctx, z1, y1, hff, z2, y2, mean1, rstd1, mean2, rstd2; };
+struct LayerOff { size_t qkv, prob, pd, ctx, z1, y1, hff, z2, y2, mean1, rstd1, mean2, rstd2, lse; };
 // per-layer gradient buffers: weight-gradient kernels read them on a third stream while the dependency
 // chain moves on to the next layer, so they must not be recycled within one backward pass
 struct LayerGrad { size_t dyout, dz2, dz2d, dhff, dy1, dz1, dz1d, dqkv; };
@@ -61,6 +61,7 @@ struct LayerGrad { size_t dyout, dz2, dz2d, dhff, dy1, dz1, dz1d, dqkv; };
 struct Plan {
     int B, F, NH, D, L, DFF;
     bool drop, concat, inference;
+    bool flash;            // many heads of head_dim 8 / 16: fused attention (attention.hip), no [NH,B,B] probability tensors
     LayerOff layer[32];
     LayerGrad lgrad[32];
     size_t scratch3, scratch3_bytes;
@@ -72,6 +73,9 @@ struct Plan {
     size_t dA, dB, dqkv, dprob, dctx, dhff, dpool2, dpool1, dcomb, dfused, dlogit, dpre, dh, dhb, dh2, dh3;
     size_t total;
 };
+
+// Fused attention for many small heads (attention.hip); 0 selects the GEMM + softmax schedule with materialised probabilities.
+int g_flash_attention = -1;
 
 int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     BBBP_CHECK_ARG(d, "null desc");
@@ -87,6 +91,8 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     p->B = d->batch; p->F = d->fingerprint_size; p->NH = d->nhead; p->D = p->F / p->NH; p->L = d->num_layers;
     p->DFF = d->dim_feedforward;
     p->drop = d->training && d->dropout_p > 0.f;
+    if (g_flash_attention < 0) { const char* e = getenv("BBBP_FLASH_ATTENTION"); g_flash_attention = e ? atoi(e) != 0 : 1; }
+    p->flash = g_flash_attention == 1 && p->L > 0 && bbbp_attn_small_supported(p->B, p->NH, p->D);
     const size_t B = p->B, F = p->F, NH = p->NH, DFF = p->DFF;
     Bump b;
     p->seed_slot = b.take(256);
@@ -95,10 +101,11 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
         // forward only: nothing is kept for a backward pass, every layer runs in layer 0's buffers (layer l reads its input
         // y2 before it writes y2 again: qkv <- y2, y1 <- LN(z1 + y2), y2 <- LN(z2 + y1))
         if (p->inference && l > 0) { o = p->layer[0]; continue; }
-        o.qkv = b.f(B * 3 * F); o.prob = b.f(NH * B * B); o.ctx = b.f(B * F);
+        o.qkv = b.f(B * 3 * F); o.prob = p->flash ? 0 : b.f(NH * B * B); o.ctx = b.f(B * F);
         // dropped attention weights are KEPT per layer (1 MB at B = 512, one head) rather than recomputed in backward:
         // every launch on the encoder's chain costs more than the bytes
-        o.pd = p->drop ? b.f(NH * B * B) : o.prob;
+        o.pd = (p->drop && !p->flash) ? b.f(NH * B * B) : o.prob;
+        o.lse = b.f(NH * B);
         o.z1 = b.f(B * F); o.y1 = b.f(B * F); o.hff = b.f(B * DFF); o.z2 = b.f(B * F); o.y2 = b.f(B * F);
         o.mean1 = b.f(B); o.rstd1 = b.f(B); o.mean2 = b.f(B); o.rstd2 = b.f(B);
     }
@@ -128,7 +135,7 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     }
     p->scratch3_bytes = (size_t)32 << 20;
     p->scratch3 = b.take(p->scratch3_bytes);
-    p->dA = b.f(B * F); p->dB = b.f(B * F); p->dqkv = b.f(B * 3 * F); p->dprob = b.f(NH * B * B); p->dctx = b.f(B * F);
+    p->dA = b.f(B * F); p->dB = b.f(B * F); p->dqkv = b.f(B * 3 * F); p->dprob = p->flash ? 0 : b.f(NH * B * B); p->dctx = b.f(B * F);
     p->dhff = b.f(B * DFF); p->dpool2 = b.f(B * IMG_FLAT); p->dpool1 = b.f(B * C1 * (IMG / 2) * (IMG / 2));
     p->dcomb = b.f(B * COMB); p->dfused = b.f(B * COMB); p->dlogit = b.f(NHEADS_FUSION * B);
     p->dpre = b.f(NHEADS_FUSION * B * FUS_HID); p->dh = b.f(B * H1); p->dhb = b.f(B * H1); p->dh2 = b.f(B * H2);
@@ -190,7 +197,7 @@ int g_fused_head_bwd = -1;
 int g_fused_encoder = -1;
 bool fused_encoder(const Plan& p) {
     if (g_fused_encoder < 0) { const char* e = getenv("BBBP_FUSED_ENCODER"); g_fused_encoder = e ? atoi(e) != 0 : 0; }
-    return g_fused_encoder == 1 && p.L > 0 && bbbp_enc_rows_supported(p.F, p.NH, p.DFF);
+    return g_fused_encoder == 1 && p.L > 0 && !p.flash && bbbp_enc_rows_supported(p.F, p.NH, p.DFF);
 }
 bool overlap_enabled() {
     if (g_overlap < 0) { const char* e = getenv("BBBP_SINGLE_STREAM"); g_overlap = (e && e[0] == '1') ? 0 : 1; }
@@ -423,6 +430,12 @@ extern "C" int bbbp_set_fused_encoder(int on) {
     return prev;
 }
 
+extern "C" int bbbp_set_flash_attention(int on) {
+    const int prev = g_flash_attention != 0 ? 1 : 0;
+    g_flash_attention = on ? 1 : 0;
+    return prev;
+}
+
 extern "C" int bbbp_set_overlap(int on) { int old = overlap_enabled() ? 1 : 0; g_overlap = on ? 1 : 0; return old; }
 
 // Profiling: enable, run steps, synchronise the stream, then collect {sum of ms, launches} per section.
@@ -551,6 +564,9 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         const LayerOff& o = plan.layer[l];
         float* qkv = c.f(o.qkv); float* prob = c.f(o.prob); float* ctx = c.f(o.ctx);
         TRY(linear_fwd(ce, x, F, P[ix.layer(l, L_INW)], P[ix.layer(l, L_INB)], qkv, 3 * F, B, 3 * F, F, 0));
+        if (plan.flash) {
+            TRY(bbbp_attn_small_fwd(ce.st, qkv, ctx, c.f(o.lse), B, F, NH, scale, p_drop, site_seed(d->seed, l, 0)));
+        } else {
         // scores_h = scale * Q_h K_h^T
         TRY(bbbp_gemm_f32(ce.st, 0, 1, B, B, D, scale, qkv, 3 * F, qkv + F, 3 * F, prob, B, nullptr, nullptr, 0, 0, NH, D, D,
                           (long)B * B, 0, ce.scratch(), ce.scratch_bytes()));
@@ -559,6 +575,7 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         // ctx_h = Pd_h V_h
         TRY(bbbp_gemm_f32(ce.st, 0, 0, B, D, B, 1.f, pd, B, qkv + 2 * F, 3 * F, ctx, F, nullptr, nullptr, 0, 0, NH, (long)B * B,
                           D, D, 0, ce.scratch(), ce.scratch_bytes()));
+        }
         float* z1 = c.f(o.z1); float* y1 = c.f(o.y1);
         TRY(linear_fwd(ce, ctx, F, P[ix.layer(l, L_OUTW)], P[ix.layer(l, L_OUTB)], z1, F, B, F, F, 0));
         TRY(bbbp_layernorm_fwd(ce.st, z1, x, y1, P[ix.layer(l, L_N1W)], P[ix.layer(l, L_N1B)], c.f(o.mean1), c.f(o.rstd1), B, F,
@@ -880,6 +897,9 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         // attention backward.  Products that become ready together share a launch (bbbp_gemm_f32_grouped):
         //   dV_h = Pd_h^T dctx_h -> dqkv[:, 2F + hD]   |   dPd_h = dctx_h V_h^T
         const float* pdp = c.f(o.pd);
+        if (plan.flash) {
+            TRY(bbbp_attn_small_bwd(ce.st, qkv, ctx, c.f(o.lse), dctx, dqkv, B, F, NH, scale, p_drop, site_seed(d->seed, l, 0)));
+        } else {
         {
             bbbp_gemm_desc g[2] = {
                 gemm_desc(1, 0, B, D, B, 1.f, pdp, B, dctx, F, dqkv + 2 * F, 3 * F, NH, (long)B * B, D, D),
@@ -893,6 +913,7 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
                 gemm_desc(0, 0, B, D, B, scale, dprob, B, qkv + F, 3 * F, dqkv, 3 * F, NH, (long)B * B, D, D),
                 gemm_desc(1, 0, B, D, B, scale, dprob, B, qkv, 3 * F, dqkv + F, 3 * F, NH, (long)B * B, D, D)};
             TRY(bbbp_gemm_f32_grouped(ce.st, g, 2, ce.scratch(), ce.scratch_bytes()));
+        }
         }
         TRY(leaf_after(ce));
         TRY(linear_bwd_weight_bias(cl, dsa, F, ctx, F, G[ix.layer(l, L_OUTW)], G[ix.layer(l, L_OUTB)], B, F, F));

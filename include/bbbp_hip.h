@@ -254,6 +254,10 @@ int bbbp_set_fused_head_bwd(int on);
  * out_proj input gradient backward) as ONE launch each (csrc/encoder.hip) instead of 6 + 6, for d_model <= 192 (default OFF:
  * measured slower, see csrc/engine.hip; initial value BBBP_FUSED_ENCODER).  Returns the previous setting.  Both schedules fill the same workspace. */
 int bbbp_set_fused_encoder(int on);
+/* Many heads of head_dim 8 / 16 (F = 2048: 256 x 8): fused flash-style self-attention, one work-group per head, scores in
+ * registers, no [nhead, B, B] tensors (csrc/attention.hip; default on, initial value BBBP_FLASH_ATTENTION).  0 selects the batched
+ * GEMM + softmax schedule.  Changes the workspace layout: set it before the forward call, not between forward and backward. */
+int bbbp_set_flash_attention(int on);
 int bbbp_set_overlap(int on);   /* two/three-stream branch overlap inside bbbp_mixed_forward/backward (default on) */
 /* Data-parallel overlap: the gradient of the image-FC weight (62 % of all gradient bytes at F = 167) is final after the
  * first GEMM of the image branch's backward.  wait_bucket(stream, 0) makes `stream` wait for exactly that point of the
