@@ -20,8 +20,8 @@
 namespace {
 
 constexpr int ROWS = 16;
-constexpr int NTH = 256, NW = NTH / 64;
-constexpr int PD = 3;                 // chunks of weight loads in flight per wave
+constexpr int NTH = 512, NW = NTH / 64;      // two waves per SIMD: the second one's loads and MFMAs fill the first one's load latency
+constexpr int PD = 4;                 // chunks of weight loads in flight per wave
 typedef float f32x4g __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2g __attribute__((ext_vector_type(2), aligned(4)));
 
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(NTH) void enc_row_fwd_kernel(RowFwdParams P) {
     rows_to_lds(sA, LD, ldz, P.ctx + row0 * F, F, nrows, t);
     __syncthreads();
     // ---- z1 = dropout(ctx Wo^T + bo) + x ----
-    rb_gemm_nt<3>(ALds{sA, LD}, P.wo, F, F, F, wave, lane, [&](int n0, int r, const f32x4& acc) {
+    rb_gemm_nt<2>(ALds{sA, LD}, P.wo, F, F, F, wave, lane, [&](int n0, int r, const f32x4& acc) {
         const long row = row0 + min(r, nrows - 1);
         float ks[4] = {1.f, 1.f, 1.f, 1.f};
         if (drop) dropout_scale4(s1, (uint64_t)row * F + n0, P.p, inv_keep, ks);
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(NTH) void enc_row_fwd_kernel(RowFwdParams P) {
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     // ---- z2 = dropout(hff W2^T + b2) + y1 ----
-    rb_gemm_nt<3>(AGlb{P.hff + row0 * P.DFF, P.DFF, nrows}, P.w2, P.DFF, F, P.DFF, wave, lane, [&](int n0, int r, const f32x4& acc) {
+    rb_gemm_nt<2>(AGlb{P.hff + row0 * P.DFF, P.DFF, nrows}, P.w2, P.DFF, F, P.DFF, wave, lane, [&](int n0, int r, const f32x4& acc) {
         const long row = row0 + min(r, nrows - 1);
         float ks[4] = {1.f, 1.f, 1.f, 1.f};
         if (drop) dropout_scale4(s3, (uint64_t)row * F + n0, P.p, inv_keep, ks);
@@ -355,14 +355,14 @@ __global__ __launch_bounds__(NTH) void enc_row_bwd_kernel(RowBwdParams P) {
         // pad columns of sA are zeroed once; the epilogue fills columns < F
         for (int idx = t; idx < ROWS * LD; idx += NTH) sA[idx] = 0.f;
         __syncthreads();
-        rb_gemm_kmajor<4>(AGlb{P.dqkv_up + row0 * P.k_up, P.k_up, nrows}, P.win_up, F, F, P.k_up, wave, lane,
-                          [&](int col0, int r0, const f32x4 (&acc)[4]) {
+        rb_gemm_kmajor<2>(AGlb{P.dqkv_up + row0 * P.k_up, P.k_up, nrows}, P.win_up, F, F, P.k_up, wave, lane,
+                          [&](int col0, int r0, const f32x4 (&acc)[2]) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rr = r0 + r;
                 if (rr >= nrows) continue;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 2; ++u) {
                     const int n = col0 + u;
                     if (n < F) { const float v = acc[u][r] + P.dz1_up[(row0 + rr) * F + n]; sA[rr * LD + n] = v; P.dyout[(row0 + rr) * F + n] = v; }
                 }
@@ -398,13 +398,13 @@ __global__ __launch_bounds__(NTH) void enc_row_bwd_kernel(RowBwdParams P) {
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     // ---- dy1 = dhff W1 + dz2 ----
-    rb_gemm_kmajor<4>(AGlb{P.dhff + row0 * P.DFF, P.DFF, nrows}, P.w1, F, F, P.DFF, wave, lane, [&](int col0, int r0, const f32x4 (&acc)[4]) {
+    rb_gemm_kmajor<2>(AGlb{P.dhff + row0 * P.DFF, P.DFF, nrows}, P.w1, F, F, P.DFF, wave, lane, [&](int col0, int r0, const f32x4 (&acc)[2]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int rr = r0 + r;
             const long row = row0 + min(rr, nrows - 1);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 2; ++u) {
                 const int n = col0 + u;
                 if (n < F) {
                     const float v = rr < nrows ? acc[u][r] + P.dz2[row * F + n] : 0.f;
@@ -419,13 +419,13 @@ __global__ __launch_bounds__(NTH) void enc_row_bwd_kernel(RowBwdParams P) {
     ln_bwd_rows(sB, sA, LD, ldz, F, nrows, row0, P.z1, P.g1, P.mean1, P.rstd1, P.dz1, P.dsa, P.p, s1, wave, lane);
     __syncthreads();
     // ---- dctx = dsa Wo ----
-    rb_gemm_kmajor<4>(ALds{sA, LD}, P.wo, F, F, F, wave, lane, [&](int col0, int r0, const f32x4 (&acc)[4]) {
+    rb_gemm_kmajor<2>(ALds{sA, LD}, P.wo, F, F, F, wave, lane, [&](int col0, int r0, const f32x4 (&acc)[2]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int rr = r0 + r;
             if (rr >= nrows) continue;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (col0 + u < F) P.dctx[(row0 + rr) * F + col0 + u] = acc[u][r];
+            for (int u = 0; u < 2; ++u) if (col0 + u < F) P.dctx[(row0 + rr) * F + col0 + u] = acc[u][r];
         }
     });
 }

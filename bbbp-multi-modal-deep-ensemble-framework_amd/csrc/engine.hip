@@ -691,9 +691,10 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
     std::optional<Section> sec;
     sec.emplace(c.st, SEC_HEAD_BWD);
     auto next_section = [&](int id) { sec.reset(); sec.emplace(c.st, id); };
-    // opt-in (bbbp_set_fused_head_bwd / BBBP_FUSED_HEAD_BWD=1): measured neutral at B = 512 (the head section shrinks 0.126 ->
-    // 0.070 ms but the step does not: the leaves it feeds finish no earlier) and slower at B = 256
-    if (g_fused_head_bwd < 0) { const char* e = getenv("BBBP_FUSED_HEAD_BWD"); g_fused_head_bwd = e ? atoi(e) != 0 : 0; }
+    // default ON since round 2 (bbbp_set_fused_head_bwd / BBBP_FUSED_HEAD_BWD=0 select the launch-per-op chain): with the bias
+    // gradients folded into the weight-gradient GEMMs the leaves it feeds are short enough that the shorter chain shows --
+    // B = 512 3.32 -> 3.27 ms, B = 256 2.12 -> 2.08, B = 128 2.36 -> 2.23 (round 1, with 38 separate column-sum leaves: neutral)
+    if (g_fused_head_bwd < 0) { const char* e = getenv("BBBP_FUSED_HEAD_BWD"); g_fused_head_bwd = e ? atoi(e) != 0 : 1; }
     const int fused_head_bwd = g_fused_head_bwd && !plan.concat;
     float* dlogit = c.f(plan.dlogit); float* dpre = c.f(plan.dpre);
     bool head_leaves_pending = false;

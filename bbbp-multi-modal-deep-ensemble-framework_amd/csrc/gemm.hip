@@ -664,8 +664,13 @@ static void gemm_plan(int M, int N, int K, int batch, int* tile, int* splits, in
     // Few output tiles and a deep K (weight gradients over the batch, the 65536-wide image FC, FFN2): these
     // launches are latency-bound at one work-group per tile, so spread K over ~2 work-groups per CU.
     int s = 1;
-    if (tiles < ncu && K >= 256) {
-        s = (int)((2L * ncu + tiles - 1) / tiles);
+    // BBBP_GEMM_SPLIT_X10: target work-groups per CU x 10 when K is split (default 20 = two per CU)
+    static const int split_x10 = [] { const char* e = getenv("BBBP_GEMM_SPLIT_X10"); return e ? atoi(e) : 20; }();
+    // BBBP_GEMM_SPLIT_FULL: also split when the tiles already cover the chip once but not twice (one work-group per CU leaves
+    // every barrier stall of its single wave per SIMD exposed)
+    static const int split_full = [] { const char* e = getenv("BBBP_GEMM_SPLIT_FULL"); return e ? atoi(e) : 0; }();
+    if ((tiles < ncu || (split_full && tiles < 2 * ncu && K >= 512)) && K >= 256) {
+        s = (int)(((long)split_x10 * ncu / 10 + tiles - 1) / tiles);
         int maxs = K / 64;
         if (s > maxs) s = maxs;
         if (s < 1) s = 1;

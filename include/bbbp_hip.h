@@ -247,8 +247,8 @@ int bbbp_forest_predict(void* stream, const float* X, long n, int n_features, co
 /* ---- optional per-section timing (HIP events on the launch stream; used by bench.py's roofline leg) ----
  * enable(1), run steps, synchronise the stream, collect(ms_sum[n], count[n]) with n = num_sections(). */
 int bbbp_set_partition(int reserved_cus, size_t small_lds_pad);   /* CU partition knob, see csrc/common.h */
-/* The head / fusion-block input-gradient chain of bbbp_mixed_backward as two fused launches instead of ten (default off:
- * measured neutral at B = 512, slower at B = 256).  Returns the previous setting.  Initial value: BBBP_FUSED_HEAD_BWD. */
+/* The head / fusion-block input-gradient chain of bbbp_mixed_backward as two fused launches instead of ten (default on since
+ * round 2: 3.32 -> 3.27 ms per step at B = 512).  Returns the previous setting.  Initial value: BBBP_FUSED_HEAD_BWD. */
 int bbbp_set_fused_head_bwd(int on);
 /* The row-local stretches of an encoder layer (out_proj .. LayerNorm2 + the next in_proj forward; LayerNorm2 backward ..
  * out_proj input gradient backward) as ONE launch each (csrc/encoder.hip) instead of 6 + 6, for d_model <= 192 (default OFF:
