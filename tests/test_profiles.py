@@ -1,51 +1,83 @@
 """The committed evidence under profiles/ is internally consistent: the traffic summary is what tools/pmc_traffic.py
-derives from the committed PMC dumps, and the bench line carries the fields the measurement contract asks for."""
+derives from the committed PMC dumps, every configuration's bench line carries the fields the measurement contract asks for, and
+the rocprofv3 kernel table of the same command agrees with the duration bench.py measured with its own HIP events."""
+import csv
 import json
 import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
+ROUND = "r02"
+# compulsory HBM bytes per launch of the conv kernels at batch B (fp32 NCHW, u8 masks)
+CONV_BYTES = {"conv2_fwd": lambda B: B * (32 * 64 * 64 * 4 + 64 * 32 * 32 * 5), "conv1_fwd": lambda B: B * (3 * 128 * 128 * 4 + 32 * 64 * 64 * 5)}
+
+
+def bench(config):
+    return json.load(open(os.path.join(PROF, f"{ROUND}_bench_config{config}.json")))
 
 
 def test_pmc_traffic_is_reproducible_from_the_dumps(tmp_path):
     out = tmp_path / "traffic.json"
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(PROF, "r01_pmc_fetch_size.csv"),
-                    os.path.join(PROF, "r01_pmc_write_size.csv"), str(out)], check=True, capture_output=True)
-    got, want = json.load(open(out)), json.load(open(os.path.join(PROF, "r01_pmc_traffic.json")))
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(PROF, f"{ROUND}_pmc_fetch_size.csv"),
+                    os.path.join(PROF, f"{ROUND}_pmc_write_size.csv"), str(out)], check=True, capture_output=True)
+    got, want = json.load(open(out)), json.load(open(os.path.join(PROF, f"{ROUND}_pmc_traffic_config3.json")))
     for k in ("conv2_fwd", "conv2_dgrad", "conv2_wgrad", "conv1_fwd", "conv1_wgrad"):
         assert abs(got[k] - want[k]) <= 1e-6 * want[k], k
-        # HBM traffic can only exceed the compulsory bytes; conv2 forward: 268 MB in + 168 MB out
-    assert got["conv2_fwd"] >= 436e6 and got["conv2_fwd"] < 2 * 436e6
+    # HBM traffic can only exceed the compulsory bytes, and the XCD-aware strip mapping keeps it within 5 % of them:
+    # conv2 forward at B = 512: 268 MB in + 168 MB out
+    for k, f in CONV_BYTES.items():
+        assert f(512) <= want[k] < 1.05 * f(512), (k, want[k], f(512))
 
 
-def test_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(PROF, "r01_bench_n1.json")))
+@pytest.mark.parametrize("config", [1, 2, 3, 4, 5])
+def test_bench_lines_have_the_contract_fields(config):
+    d = bench(config)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["n_gpus"] == 1 and "workload" in d["config"]
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and "workload" in d["config"] and d["config"]["baseline_config"] == config
+    assert d["dtype"] == ("f64" if config == 1 else "f32") and d["scaling"] == "weak" and d["data"] == "synthetic"
     r = d["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 0
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["peak"] == 157.3
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
-    # consistency: value = batch / step time
-    assert abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) / d["value"] < 2e-3
+    if config != 1:
+        # consistency: value = batch / step time
+        B = d["config"]["per_gpu_batch"]
+        assert B == {2: 256, 3: 512, 4: 512, 5: 4096}[config]
+        assert abs(d["value"] - B / (d["ms_per_step"] * 1e-3)) / d["value"] < 2e-3
+        assert abs(r["achieved"] - r["flops_per_launch"] / (r["ms_per_launch"] * 1e-3) / 1e12) < 0.02 * r["achieved"]
 
 
-def test_rocprof_kernel_table_agrees_with_the_bench_line():
+@pytest.mark.parametrize("config", [2, 3, 5])
+def test_rocprof_kernel_table_agrees_with_the_bench_line(config):
     """The measurement contract: the rocprofv3 --kernel-trace --stats average of the roofline kernel agrees with the duration
     bench.py measured with its own HIP events (profiles are collected by tools/profile_round.sh with --no-isolated, so every
-    launch in the table is an in-step one)."""
-    import csv
-    d = json.load(open(os.path.join(PROF, "r01_bench_n1.json")))
+    launch in the table is an in-step one), and the PMC traffic quoted in the line is the committed pass of that configuration."""
+    d = bench(config)
     r = d["roofline"]
     pattern = {"conv2_wgrad": "conv_wgrad32_kernel", "conv2_fwd": "wino_conv_kernel<0>", "conv2_dgrad": "wino_conv_kernel<1>"}[r["kernel"]]
-    rows = [x for x in csv.DictReader(open(os.path.join(PROF, "r01_kernel_stats.csv"))) if pattern in x["Name"]]
+    rows = [x for x in csv.DictReader(open(os.path.join(PROF, f"{ROUND}_kernel_stats_config{config}.csv"))) if pattern in x["Name"]]
     assert len(rows) == 1
     avg_ms = float(rows[0]["AverageNs"]) * 1e-6
     assert abs(avg_ms - r["ms_per_launch"]) <= 0.05 * r["ms_per_launch"], (avg_ms, r["ms_per_launch"])
-    # and the PMC traffic of that kernel is what the bench line reports
-    t = json.load(open(os.path.join(PROF, "r01_pmc_traffic.json")))
-    assert abs(t[r["kernel"]] - r["traffic"]) <= 0.05 * r["traffic"]
+    t = json.load(open(os.path.join(PROF, f"{ROUND}_pmc_traffic_config{config}.json")))
+    assert r["traffic_source"] == f"{ROUND}_pmc_traffic_config{config}.json" and t["config"] == config
+    assert abs(t[r["kernel"]] - r["traffic"]) <= 1e-6 * r["traffic"]
+    # traffic close to the algorithmic bytes: nothing is re-read from HBM
+    B = d["config"]["per_gpu_batch"]
+    conv2_bytes = B * (32 * 64 * 64 * 4 + 64 * 32 * 32 * 5)
+    assert conv2_bytes <= r["traffic"] < 1.12 * conv2_bytes, (r["traffic"], conv2_bytes)
+
+
+def test_config4_line_is_the_ffn_gemm_and_improved_over_round_1():
+    d = bench(4)
+    r = d["roofline"]
+    assert r["kernel"] == "ffn1_fwd" and r["flops_per_launch"] == 2 * 512 * 2048 * 2048 and r["traffic"] is None
+    assert d["ms_per_step"] < 13.0           # round 1: 19.5 ms (tools/time_configs.py); the fused small-head attention removed ~6.5 ms
+    rows = [x for x in csv.DictReader(open(os.path.join(PROF, f"{ROUND}_kernel_stats_config4.csv"))) if "attn_small" in x["Name"]]
+    assert len(rows) == 2, "the fused attention kernels ran in the profiled command"
