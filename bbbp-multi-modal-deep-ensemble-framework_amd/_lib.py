@@ -74,6 +74,7 @@ _SIGNATURES = {
     "bbbp_set_conv_winograd": (c_int, [c_int]),
     "bbbp_get_conv_winograd": (c_int, []),
     "bbbp_conv_winograd_phases": (c_int, [POINTER(c_uint64)]),
+    "bbbp_conv_b3_phases": (c_int, [POINTER(c_uint64)]),
     "bbbp_conv3x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "bbbp_conv3x3_relu_pool_fwd": (c_int, [c_void_p, _FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                            c_void_p, c_size_t]),

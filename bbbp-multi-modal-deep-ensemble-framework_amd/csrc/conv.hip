@@ -798,18 +798,23 @@ inline bool supported(int cin, int cout, int h, int w) {
            (cin == 64 && cout == 128 && w == 64) || (cin == 128 && cout == 256 && w == 32);
 }
 
-// Winograd form of the 32 -> 64 @ 64x64 stage (conv_wino.hip): bit 0 = forward, bit 1 = data gradient
+// Algorithm of the 32 -> 64 @ 64x64 stage.  bit 0 / 1: forward / data gradient as Winograd F(2x2,3x3) (conv_wino.hip);
+// bit 2 / 3: forward / data gradient as the split-bf16 direct form (conv_b3.hip; takes precedence over the Winograd bit).
 int g_winograd = -1;
 int g_last_clock_wino = 0;
 inline int winograd_mask() {
-    if (g_winograd < 0) { const char* e = getenv("BBBP_CONV_WINOGRAD"); g_winograd = e ? atoi(e) & 3 : 3; }
+    // default since round 2: both as split-bf16 (12) -- alone as fast as the Winograd form (0.42 / 0.41 vs 0.42 / 0.44 ms at B = 512), and in
+    // the training step 0.47 / 0.42 vs 0.57 / 0.61 ms: 66 KB of LDS and 160 registers per wave leave room for the other branch's
+    // kernels on every CU (the Winograd work-groups take whole CUs and give 64 of them up), and a bf16 MFMA holds the vector issue
+    // for 8 of its 32 cycles where the f32 MFMA blocks it for all 64
+    if (g_winograd < 0) { const char* e = getenv("BBBP_CONV_WINOGRAD"); g_winograd = e ? atoi(e) & 15 : 12; }
     return g_winograd;
 }
 
 }  // namespace
 
 extern "C" int bbbp_set_conv_winograd(int mask) {
-    BBBP_CHECK_ARG(mask >= 0 && mask <= 3, "set_conv_winograd: mask %d (bit 0 forward, bit 1 data gradient)", mask);
+    BBBP_CHECK_ARG(mask >= 0 && mask <= 15, "set_conv_winograd: mask %d (bits 0/1 Winograd forward / data gradient, bits 2/3 split-bf16)", mask);
     g_winograd = mask;
     return BBBP_OK;
 }
@@ -823,6 +828,7 @@ extern "C" int bbbp_conv_winograd_phases(unsigned long long* phases4) {
 // workspace: prepped weights (fwd / dgrad) or partial slabs (wgrad)
 extern "C" int bbbp_conv_last_clock(unsigned long long* shader_cycles, unsigned long long* ticks_100mhz) {
     BBBP_CHECK_ARG(shader_cycles && ticks_100mhz, "conv_last_clock: null pointer");
+    if (g_last_clock_wino == 2) { *shader_cycles = 0; *ticks_100mhz = 0; return BBBP_OK; }
     if (g_last_clock_wino) return bbbp_wino_last_clock(shader_cycles, ticks_100mhz);
     unsigned long long h[2] = {0, 0};
     BBBP_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_conv_clock), sizeof(h)));
@@ -852,6 +858,11 @@ extern "C" int bbbp_conv3x3_relu_pool_fwd(void* stream, const float* x, const fl
     BBBP_CHECK_ARG(workspace_bytes >= need, "conv fwd: workspace %zu < %zu", workspace_bytes, need);
     float* wt = static_cast<float*>(workspace);
     g_last_clock_wino = 0;
+    if (cin == 32 && cout == 64 && (winograd_mask() & 4)) {
+        BBBP_CHECK_ARG(workspace_bytes >= bbbp_b3_workspace_bytes(), "conv fwd: workspace too small");
+        g_last_clock_wino = 2;               // no clock stamps in the split-bf16 kernels
+        return bbbp_b3_conv2_fwd(st, x, w, bias, y, mask, B, workspace);
+    }
     if (cin == 32 && cout == 64 && (winograd_mask() & 1)) {
         BBBP_CHECK_ARG(workspace_bytes >= (size_t)16 * 32 * 64 * sizeof(float), "conv fwd: workspace too small");
         g_last_clock_wino = 1;
@@ -881,6 +892,11 @@ extern "C" int bbbp_conv3x3_relu_pool_bwd_data(void* stream, const float* gy, co
     BBBP_CHECK_ARG(workspace_bytes >= need, "conv bwd_data: workspace %zu < %zu", workspace_bytes, need);
     float* wt = static_cast<float*>(workspace);
     g_last_clock_wino = 0;
+    if (cin == 32 && cout == 64 && (winograd_mask() & 8)) {
+        BBBP_CHECK_ARG(workspace_bytes >= bbbp_b3_workspace_bytes(), "conv bwd_data: workspace too small");
+        g_last_clock_wino = 2;
+        return bbbp_b3_conv2_dgrad(st, gy, mask, w, dx, B, workspace);
+    }
     if (cin == 32 && cout == 64 && (winograd_mask() & 2)) {
         BBBP_CHECK_ARG(workspace_bytes >= (size_t)16 * 32 * 64 * sizeof(float), "conv bwd_data: workspace too small");
         g_last_clock_wino = 1;

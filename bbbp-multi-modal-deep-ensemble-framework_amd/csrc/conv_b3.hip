@@ -1,0 +1,359 @@
+// The flagship CNN's second conv stage (32 -> 64 channels on 64x64 maps: `nn.Conv2d(32, 64, 3, 1, 1) -> ReLU -> MaxPool2d(2, 2)`,
+// Models/multi_input_data_regression_opt_transformer_cnn_20250113.py:87-89) as a direct implicit GEMM whose
+// float32 products run on the BF16 matrix pipe: every operand x is split ONCE, when it is staged into LDS, into three bfloat16
+// pieces  x = hi + mid + lo  (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 24 significand bits, the subtractions
+// are exact), and a product a*b becomes the six bf16 products  hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid  accumulated in
+// float32 inside v_mfma_f32_32x32x16_bf16 (the three dropped terms are <= 2^-24 |a b|: below the rounding of the float32 product).
+// gfx950's f32-input MFMA runs at 1/16 of the bf16 rate and blocks the SIMD's vector issue for its whole 64 cycles; six bf16
+// MFMAs do the work of eight of them in 6 x 32 cycles and hold the vector issue for 8 of every 32, so the same float32 arithmetic
+// (to ~1 ulp per product) gets 2.67x the matrix rate and leaves the VALU to the stage loader and to the other stream's kernels.
+//
+// GEMM view (forward): D[co][pixel] = sum_{tap, ci} W[co][ci][tap] X[ci][pixel + tap]; a k-step is one tap x 16 channels.  LDS
+// holds the input strip channel-INNERMOST per pixel ([plane][row][px][16 ch] bf16), so a lane's B fragment -- 8 consecutive
+// channels of its pixel -- is one aligned ds_read_b128 and a tap only moves the pixel index; the weights arrive pre-split from a
+// prep kernel in exactly the A-fragment order ([tap][plane][k-half][m 32][8]).  A work-group = 4 waves (one per SIMD) owns a strip
+// of 4 output rows x 64 pixels x 32 output channels; a wave owns 2 rows x 32 columns (two accumulator tiles: the 2x2 pool partners
+// are its own two tiles and the neighbouring lane), channels stream through a double-buffered stage of 16.
+// The data gradient is the same kernel: the loader expands the pooled gradient through the arg-max mask, the prep kernel flips the
+// filter taps and swaps the channel roles, the epilogue stores full-resolution rows.
+#include "common.h"
+#include "bbbp_hip.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // clang vectors stay in registers; arrays of HIP's uint4 struct were demoted to scratch
+
+constexpr int B3_FWD = 0, B3_DGRAD = 1;
+constexpr int IMG = 64;
+constexpr int R = 4, ROWS = R + 2;            // output rows per strip, staged rows (halo)
+constexpr int PXW = IMG + 2;                  // staged pixels per row: index 0 is x = -1, index 65 is x = 64 (always zero)
+constexpr int CH = 16;                        // channels per stage = K of one MFMA
+constexpr int XPLANE = ROWS * PXW * CH;       // bf16 elements of one plane of one stage
+constexpr int XBUF = 3 * XPLANE;
+constexpr int WSTAGE = 9 * 3 * 2 * 32 * 8;    // bf16 elements: [tap][plane][k-half][m][8]
+constexpr size_t LDS_BYTES = (size_t)(XBUF + WSTAGE) * 2;      // 65.7 KB: two work-groups per CU
+
+struct B3Params {
+    const float* x;         // FWD: input [B][32][64][64];  DGRAD: pooled gradient [B][64][32][32]
+    const uint8_t* xmask;   // DGRAD: its arg-max / ReLU mask
+    const uint16_t* wp;     // pre-split filters: [m-block][chunk][WSTAGE]
+    const float* bias;      // FWD: [64]
+    float* y;               // FWD: pooled [B][64][32][32];  DGRAD: [B][32][64][64]
+    uint8_t* ymask;         // FWD
+    int B;
+};
+
+// hi / mid / lo of two floats, packed pairwise
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    f32x2v v = {a, b};
+    bf16x2 h = __builtin_convertvector(v, bf16x2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    v[0] -= __builtin_bit_cast(float, hi << 16); v[1] -= __builtin_bit_cast(float, hi & 0xffff0000u);
+    bf16x2 m = __builtin_convertvector(v, bf16x2);
+    mid = __builtin_bit_cast(uint32_t, m);
+    v[0] -= __builtin_bit_cast(float, mid << 16); v[1] -= __builtin_bit_cast(float, mid & 0xffff0000u);
+    bf16x2 l = __builtin_convertvector(v, bf16x2);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// filters -> [m-block][chunk][tap][plane][k-half][m 32][8] bf16.
+//   FWD  : m = output channel co (2 blocks of 32), k = input channel ci (2 chunks of 16), tap = kh * 3 + kw
+//   DGRAD: m = input channel ci (1 block), k = output channel co (4 chunks of 16), tap' = the flipped tap
+__global__ void b3_prep_kernel(const float* __restrict__ w, uint16_t* __restrict__ wp, int mode) {
+    const int nmb = mode == B3_FWD ? 2 : 1, nch = mode == B3_FWD ? 2 : 4;
+    const int total = nmb * nch * 9 * 2 * 32 * 4;                 // (mb, chunk, tap, half, m, pair-of-k)
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        int r = idx;
+        const int pr = r % 4; r /= 4;
+        const int m = r % 32; r /= 32;
+        const int h = r % 2; r /= 2;
+        const int tap = r % 9; r /= 9;
+        const int chunk = r % nch; r /= nch;
+        const int mb = r;
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = chunk * 16 + 8 * h + 2 * pr + e;
+            if (mode == B3_FWD) v[e] = w[((mb * 32 + m) * 32 + k) * 9 + tap];          // W[co][ci][tap]
+            else v[e] = w[(k * 32 + m) * 9 + (8 - tap)];                                // W[co = k][ci = m][flipped tap]
+        }
+        uint32_t hi, mid, lo;
+        split2(v[0], v[1], hi, mid, lo);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(wp + (size_t)(mb * nch + chunk) * WSTAGE);
+        const int base = ((tap * 3 * 2 + h) * 32 + m) * 4 + pr;       // plane stride: 2 * 32 * 4 words
+        dst[base] = hi; dst[base + 2 * 32 * 4] = mid; dst[base + 2 * 2 * 32 * 4] = lo;
+    }
+}
+
+// phase breakdown of work-group 0 / wave 0 (BBBP_B3_PROBE=1 selects the stamping instantiation; tools/bench_conv2.py prints it): shader
+// cycles in [0] global-load issue, [1] MFMA block of a stage, [2] split + LDS writes + barriers, [3] epilogue
+__device__ unsigned long long g_b3_phase[4];
+
+template <int MODE, bool PROBE>
+__device__ __forceinline__ void conv_b3_body(const B3Params& p) {
+    constexpr int KIN = MODE == B3_FWD ? 32 : 64;            // reduction channels
+    constexpr int NCHUNK = KIN / CH;
+    constexpr int NMB = MODE == B3_FWD ? 2 : 1;              // blocks of 32 produced channels
+    constexpr int SRC_PLANE = MODE == B3_FWD ? IMG * IMG : (IMG / 2) * (IMG / 2);     // floats per source channel plane
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    uint16_t* Xs = smem;                                     // [plane 3][row][px][16]
+    uint16_t* Ws = smem + XBUF;                              // [WSTAGE]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+
+    // the produced-channel block is fixed per work-group; blocks of one strip sit on one XCD (ids w and w + 8: common.h)
+    const bool pairs = NMB == 2 && (gridDim.x & 15) == 0;
+    const int mb = NMB == 1 ? 0 : pairs ? (blockIdx.x >> 3) & 1 : blockIdx.x % NMB;
+    const int nstrips = p.B * (IMG / R);
+    const int stride = gridDim.x / NMB;
+    const int first = NMB == 1 ? xcd_adjacent(blockIdx.x, gridDim.x)
+                    : pairs ? ((stride & 7) ? (blockIdx.x & 7) + 8 * (blockIdx.x >> 4) : (blockIdx.x & 7) * (stride >> 3) + (blockIdx.x >> 4))
+                    : blockIdx.x / NMB;
+
+    for (int i = t * 8; i < XBUF; i += 256 * 8) *reinterpret_cast<u32x4*>(Xs + i) = u32x4{0, 0, 0, 0};
+
+    // ---- stage loader: item = (channel group of 8, row, pixel); 8 dword loads -> split -> three 16-byte LDS writes.
+    //      Everything that does not depend on the strip is computed once: a stage costs one uniform base + 32-bit offsets. ----
+    constexpr int ITEMS = 2 * ROWS * IMG, NIT = ITEMS / 256;
+    constexpr int WPIECES = WSTAGE * 2 / 16, WIT = (WPIECES + 255) / 256;       // 16-byte pieces of a filter stage per thread
+    int goff[NIT], loff[NIT], irow[NIT], ipar[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int idx = t + i * 256;
+        const int px = idx % IMG, row = (idx / IMG) % ROWS, cg = idx / (IMG * ROWS);
+        goff[i] = cg * 8 * SRC_PLANE + (MODE == B3_FWD ? px : px >> 1);
+        loff[i] = (row * PXW + px + 1) * CH + cg * 8;
+        irow[i] = row; ipar[i] = px & 1;
+    }
+    float xr[NIT][8];
+    uint32_t mr[NIT][2];                                     // DGRAD: the eight mask bytes of an item
+    u32x4 wr[WIT];
+    uint32_t okbits = 0;
+    auto load_stage = [&](int strip, int chunk) __attribute__((always_inline)) {
+        const int b = strip / (IMG / R), h0 = (strip % (IMG / R)) * R;
+        const char* xb = reinterpret_cast<const char*>(p.x + ((long)b * KIN + chunk * CH) * SRC_PLANE);
+        const uint8_t* mbp = MODE == B3_DGRAD ? p.xmask + ((long)b * KIN + chunk * CH) * SRC_PLANE : nullptr;
+        okbits = 0;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int yr = h0 - 1 + irow[i];
+            const int yy = min(max(yr, 0), IMG - 1);
+            okbits |= (yr >= 0 && yr < IMG ? 1u : 0u) << i;
+            const unsigned o = goff[i] + (MODE == B3_FWD ? yy * IMG : (yy >> 1) * (IMG / 2));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xr[i][j] = *reinterpret_cast<const float*>(xb + (size_t)(4u * (o + j * SRC_PLANE)));
+            if (MODE == B3_DGRAD) {
+                uint32_t m0 = 0, m1 = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { m0 |= (uint32_t)mbp[o + j * SRC_PLANE] << (8 * j); m1 |= (uint32_t)mbp[o + (j + 4) * SRC_PLANE] << (8 * j); }
+                mr[i][0] = m0; mr[i][1] = m1;
+            }
+        }
+        const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.wp + (size_t)(mb * NCHUNK + chunk) * WSTAGE);
+#pragma unroll
+        for (int i = 0; i < WIT; ++i) wr[i] = wsrc[min(t + i * 256, WPIECES - 1)];
+    };
+    auto store_stage = [&](int strip) __attribute__((always_inline)) {
+        const int h0 = (strip % (IMG / R)) * R;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const bool ok = (okbits >> i) & 1u;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (MODE == B3_FWD) v[j] = ok ? xr[i][j] : 0.f;
+                else {
+                    const uint32_t want = (uint32_t)(((h0 - 1 + irow[i]) & 1) * 2 + ipar[i]);
+                    v[j] = (ok && ((mr[i][j >> 2] >> (8 * (j & 3))) & 0xff) == want) ? xr[i][j] : 0.f;
+                }
+            }
+            uint32_t hi[4], mid[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], hi[j], mid[j], lo[j]);
+            uint16_t* d = Xs + loff[i];
+            *reinterpret_cast<u32x4*>(d) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<u32x4*>(d + XPLANE) = u32x4{mid[0], mid[1], mid[2], mid[3]};
+            *reinterpret_cast<u32x4*>(d + 2 * XPLANE) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+        }
+        u32x4* wd = reinterpret_cast<u32x4*>(Ws);
+#pragma unroll
+        for (int i = 0; i < WIT; ++i)
+            if (t + i * 256 < WPIECES) wd[t + i * 256] = wr[i];
+    };
+
+    // this wave's two accumulator tiles: rows y0, y0 + 1 of the strip, columns cb .. cb + 31
+    const int y0 = (wave >> 1) * 2, cb = (wave & 1) * 32;
+    unsigned long long ph[4] = {0, 0, 0, 0}, tprev = PROBE ? __builtin_readcyclecounter() : 0;
+    auto mark = [&](int k) __attribute__((always_inline)) {
+        if (PROBE) { const unsigned long long now = __builtin_readcyclecounter(); ph[k] += now - tprev; tprev = now; }
+    };
+    int strip = first;
+    __syncthreads();                                         // the zero fill (halo columns stay zero for the kernel's life)
+    if (strip < nstrips) { load_stage(strip, 0); store_stage(strip); }
+    mark(2);
+    const uint16_t* xs = Xs + 8 * h;
+    const uint16_t* ws = Ws + (h * 32 + r) * 8;
+    for (; strip < nstrips; strip += stride) {
+        const int b = strip / (IMG / R), h0 = (strip % (IMG / R)) * R;
+        f32x16 acc[2];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float bv = MODE == B3_FWD ? p.bias[mb * 32 + mfma_row(q, lane)] : 0.f;
+            acc[0][q] = bv; acc[1][q] = bv;
+        }
+        for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+            int nstrip = strip, nchunk = chunk + 1;
+            if (nchunk == NCHUNK) { nchunk = 0; nstrip = strip + stride; }
+            const bool have_next = nstrip < nstrips;
+            __syncthreads();                                 // this stage's LDS image is complete
+            // the next stage's global loads are in flight under this stage's MFMAs; its split and LDS writes follow the block.
+            // ONE LDS image per work-group (66 KB): two work-groups share a CU, and while one splits and stores the other
+            // one's waves keep the matrix pipe busy (a bf16 MFMA holds the vector issue for only 8 of its 32 cycles)
+            if (have_next) load_stage(nstrip, nchunk);
+            mark(0);
+            // fragments of tap t + 1 are fetched while the MFMAs of tap t run
+            bf16x8 a[2][3], bq[2][2][3];
+            auto fetch = [&](int tap, int slot) __attribute__((always_inline)) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[slot][pl] = *reinterpret_cast<const bf16x8*>(ws + (tap * 3 + pl) * (2 * 32 * 8));
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        bq[slot][nt][pl] = *reinterpret_cast<const bf16x8*>(xs + pl * XPLANE + ((y0 + nt + dy + 1) * PXW + (cb + r + dx + 1)) * CH);
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int sl = tap & 1;
+                if (tap + 1 < 9) fetch(tap + 1, sl ^ 1);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    // small terms first, the leading product last
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sl][1], bq[sl][nt][1], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sl][2], bq[sl][nt][0], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sl][0], bq[sl][nt][2], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sl][1], bq[sl][nt][0], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sl][0], bq[sl][nt][1], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sl][0], bq[sl][nt][0], acc[nt], 0, 0, 0);
+                }
+                // issue order of this tap: one LDS read of the next tap's fragments in each of the first nine MFMA gaps
+                if (tap + 1 < 9) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                }
+            }
+            mark(1);
+            __syncthreads();                                 // every wave is done reading this stage
+            if (have_next) store_stage(nstrip);
+            mark(2);
+        }
+        // ---- epilogue ----
+        const int x = cb + r;
+        if (MODE == B3_FWD) {
+            // ReLU + 2x2 max-pool + arg-max mask (PyTorch scan order, first maximum wins; 4 = ReLU inactive).  The window of pixel
+            // pair (x even, x + 1) x rows (y0, y0 + 1): the even lane finishes even accumulator registers, the odd lane odd ones.
+            const int odd = lane & 1;
+            const int ph2 = (h0 + y0) >> 1, pw = x >> 1;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int mine = 2 * k + odd;
+                // each lane sends the register its partner finishes, receives the partner's copy of the one it finishes
+                const float s0 = odd ? acc[0][2 * k] : acc[0][2 * k + 1], s1 = odd ? acc[1][2 * k] : acc[1][2 * k + 1];
+                const float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+                const float m0 = odd ? acc[0][2 * k + 1] : acc[0][2 * k], m1 = odd ? acc[1][2 * k + 1] : acc[1][2 * k];
+                // window in scan order: (y0, xe), (y0, xe + 1), (y0 + 1, xe), (y0 + 1, xe + 1); this lane is xe + odd
+                const float v0 = odd ? r0 : m0, v1 = odd ? m0 : r0, v2 = odd ? r1 : m1, v3 = odd ? m1 : r1;
+                float best = v0; int arg = 0;
+                if (v1 > best) { best = v1; arg = 1; }
+                if (v2 > best) { best = v2; arg = 2; }
+                if (v3 > best) { best = v3; arg = 3; }
+                const bool act = best > 0.f;
+                const int co = mb * 32 + mfma_row(mine, lane);
+                const long o = (((long)b * 64 + co) * (IMG / 2) + ph2) * (IMG / 2) + pw;
+                p.y[o] = act ? best : 0.f;
+                p.ymask[o] = act ? (uint8_t)arg : (uint8_t)4;
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int ci = mfma_row(q, lane);
+                    p.y[(((long)b * 32 + ci) * IMG + (h0 + y0 + nt)) * IMG + x] = acc[nt][q];
+                }
+        }
+        mark(3);
+    }
+    if (PROBE && blockIdx.x == 0 && t == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g_b3_phase[k] = ph[k];
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void conv_b3_kernel(B3Params p) { conv_b3_body<MODE, false>(p); }
+template <int MODE>
+__global__ __launch_bounds__(256) void conv_b3_probe_kernel(B3Params p) { conv_b3_body<MODE, true>(p); }
+
+template <int MODE>
+int launch_b3(const B3Params& p, hipStream_t st) {
+    static const int probe = [] { const char* e = getenv("BBBP_B3_PROBE"); return e ? atoi(e) : 0; }();
+    auto kernel = probe ? conv_b3_probe_kernel<MODE> : conv_b3_kernel<MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)LDS_BYTES);
+        if (e != hipSuccess) {
+            bbbp_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", LDS_BYTES, hipGetErrorString(e));
+            return BBBP_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    constexpr int NMB = MODE == B3_FWD ? 2 : 1;
+    const int nwork = p.B * (IMG / R) * NMB;
+    static const int per_cu = [] { const char* e = getenv("BBBP_B3_PER_CU"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 2 ? 2 : v); }();
+    int grid = bbbp_num_cus() * per_cu;
+    if (grid >= 8 * NMB) grid -= grid % (8 * NMB);
+    if (grid > nwork) grid = nwork - nwork % NMB;
+    if (grid < NMB) grid = NMB;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), LDS_BYTES, st, p);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+}  // namespace
+
+// conv.hip dispatches the 32 -> 64 @ 64x64 stage here when the split-bf16 form is selected (bbbp_set_conv_algo).
+// workspace: 2 * 2 * WSTAGE (forward) / 4 * WSTAGE (data gradient) bf16 of pre-split filters = 110 KB.
+size_t bbbp_b3_workspace_bytes() { return (size_t)4 * WSTAGE * 2; }
+
+int bbbp_b3_conv2_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* y, uint8_t* mask, int B, void* workspace) {
+    hipLaunchKernelGGL(b3_prep_kernel, dim3(72), dim3(256), 0, st, w, static_cast<uint16_t*>(workspace), B3_FWD);
+    BBBP_CHECK_LAUNCH();
+    B3Params p{x, nullptr, static_cast<const uint16_t*>(workspace), bias, y, mask, B};
+    return launch_b3<B3_FWD>(p, st);
+}
+
+int bbbp_b3_conv2_dgrad(hipStream_t st, const float* gy, const uint8_t* gmask, const float* w, float* dx, int B, void* workspace) {
+    hipLaunchKernelGGL(b3_prep_kernel, dim3(72), dim3(256), 0, st, w, static_cast<uint16_t*>(workspace), B3_DGRAD);
+    BBBP_CHECK_LAUNCH();
+    B3Params p{gy, gmask, static_cast<const uint16_t*>(workspace), nullptr, dx, nullptr, B};
+    return launch_b3<B3_DGRAD>(p, st);
+}
+
+extern "C" int bbbp_conv_b3_phases(unsigned long long* phases4) {
+    BBBP_CHECK_ARG(phases4, "conv_b3_phases: null pointer");
+    BBBP_CHECK_HIP(hipMemcpyFromSymbol(phases4, HIP_SYMBOL(g_b3_phase), 4 * sizeof(unsigned long long)));
+    return BBBP_OK;
+}

@@ -339,7 +339,8 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
     # conv2's forward / data gradient may run as Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36.  The roofline
     # line prices the kernel at the algorithmic (direct) flop count of SURVEY.md 8(d); `winograd` also gives the executed flops.
     wmask = L.bbbp_get_conv_winograd()
-    wino = {k: bool(wmask & bit) for k, bit in (("conv2_fwd", 1), ("conv2_dgrad", 2))}
+    b3 = {k: bool(wmask & bit) for k, bit in (("conv2_fwd", 4), ("conv2_dgrad", 8))}          # split-bf16 form takes precedence
+    wino = {k: bool(wmask & bit) and not b3[k] for k, bit in (("conv2_fwd", 1), ("conv2_dgrad", 2))}
     roofline = None
     if cand:
         dom = max(cand, key=cand.get)
@@ -354,8 +355,19 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
                         ms_per_launch_isolated=round(isolated.get(dom, 0.0), 4),
                         frac_isolated=round(kf / (isolated[dom] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if isolated.get(dom) else None,
                         sections_ms={k: round(v, 4) for k, v in sections.items()})
-        roofline["algorithm"] = ("winograd F(2x2,3x3) f32" if wino.get(dom) else "direct implicit GEMM f32") if dom.startswith("conv2") \
+        roofline["algorithm"] = ("winograd F(2x2,3x3) f32" if wino.get(dom) else
+                                 "direct implicit GEMM, f32 operands split into 3 bf16 pieces (6 bf16 MFMAs per f32 product, f32 accumulate)" if b3.get(dom)
+                                 else "direct implicit GEMM f32") if dom.startswith("conv2") \
             else "f32 MFMA GEMM (linear1 of one encoder layer, M=B, N=2048, K=F)"
+        if any(b3.get(k) and k in sections for k in b3):
+            # priced at the algorithmic (f32) flop count against the f32 MFMA peak, like every conv line; the kernel executes 6 bf16
+            # MFMA flops per algorithmic flop on the bf16 pipe (dense peak ~2.5 PFLOP/s)
+            roofline["split_bf16"] = {
+                k: dict(ms_per_launch=round(sections[k], 4), ms_per_launch_isolated=round(isolated.get(k, 0.0), 4),
+                        algorithmic_tflops=round(conv2 / (sections[k] * 1e-3) / 1e12, 2),
+                        executed_bf16_tflops=round(6 * conv2 / (sections[k] * 1e-3) / 1e12, 1),
+                        executed_frac_of_bf16_peak=round(6 * conv2 / (sections[k] * 1e-3) / 1e12 / 2500.0, 4))
+                for k in b3 if b3[k] and k in sections}
         if any(wino.get(k) and k in sections for k in wino):
             roofline["winograd"] = {
                 k: dict(ms_per_launch=round(sections[k], 4), ms_per_launch_isolated=round(isolated.get(k, 0.0), 4),

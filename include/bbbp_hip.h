@@ -92,6 +92,8 @@ int bbbp_get_conv_winograd(void);
 /* Measurement aid: with BBBP_WINO_PROBE=1 in the environment the Winograd kernels stamp the shader clock at phase boundaries;
  * phases4 = cycles work-group 0 spent in {accumulator init, k-steps, stage hand-over, output transform} of the last launch. */
 int bbbp_conv_winograd_phases(unsigned long long* phases4);
+/* Same for the split-bf16 kernels (BBBP_B3_PROBE=1): [0] global-load issue, [1] MFMA block, [2] split + LDS writes + barrier, [3] epilogue. */
+int bbbp_conv_b3_phases(unsigned long long* phases4);
 int bbbp_conv3x3_relu_pool_fwd(void* stream, const float* x, const float* w, const float* bias,
                                float* y, uint8_t* mask, int B, int cin, int cout, int H, int W,
                                void* workspace, size_t workspace_bytes);

@@ -139,5 +139,5 @@ def test_hip_adamw_follows_the_reference_trajectory(dev):
                                        tight_lr_frac=0.02 if step == 1 else 0.6, min_frac=0.9 if step == 1 else 0.75)
             sd = m.state_dict()
             for k in ("fc.2.running_mean", "fc.2.running_var"):
-                assert_close(sd[k].cpu().numpy(), g[f"adamw/B{B}/step{step}/bn/{k}"], rtol=2e-4 if step == 1 else 5e-3, what=k)
+                assert_close(sd[k].cpu().numpy(), g[f"adamw/B{B}/step{step}/bn/{k}"], rtol=2e-4 if step == 1 else 5e-3, atol_frac=2e-4, what=k)
     assert opt.state[next(iter(m.parameters()))]["step"] == 3
