@@ -799,22 +799,24 @@ inline bool supported(int cin, int cout, int h, int w) {
 }
 
 // Algorithm of the 32 -> 64 @ 64x64 stage.  bit 0 / 1: forward / data gradient as Winograd F(2x2,3x3) (conv_wino.hip);
-// bit 2 / 3: forward / data gradient as the split-bf16 direct form (conv_b3.hip; takes precedence over the Winograd bit).
+// bit 2 / 3 / 4: forward / data gradient / weight gradient as the split-bf16 direct form (conv_b3.hip; takes precedence over
+// the Winograd bit).
 int g_winograd = -1;
 int g_last_clock_wino = 0;
 inline int winograd_mask() {
-    // default since round 2: both as split-bf16 (12) -- alone as fast as the Winograd form (0.42 / 0.41 vs 0.42 / 0.44 ms at B = 512), and in
+    // default since round 2: all three as split-bf16 (28; the weight gradient alone 0.63 -> 0.42 ms, and beside it the encoder's
+    // backward chain runs 1.93 -> 1.45 ms: 4 waves x 180 registers instead of conv_wgrad32's 8 x 224) -- alone as fast as the Winograd form (0.42 / 0.41 vs 0.42 / 0.44 ms at B = 512), and in
     // the training step 0.47 / 0.42 vs 0.57 / 0.61 ms: 66 KB of LDS and 160 registers per wave leave room for the other branch's
     // kernels on every CU (the Winograd work-groups take whole CUs and give 64 of them up), and a bf16 MFMA holds the vector issue
     // for 8 of its 32 cycles where the f32 MFMA blocks it for all 64
-    if (g_winograd < 0) { const char* e = getenv("BBBP_CONV_WINOGRAD"); g_winograd = e ? atoi(e) & 15 : 12; }
+    if (g_winograd < 0) { const char* e = getenv("BBBP_CONV_WINOGRAD"); g_winograd = e ? atoi(e) & 31 : 28; }
     return g_winograd;
 }
 
 }  // namespace
 
 extern "C" int bbbp_set_conv_winograd(int mask) {
-    BBBP_CHECK_ARG(mask >= 0 && mask <= 15, "set_conv_winograd: mask %d (bits 0/1 Winograd forward / data gradient, bits 2/3 split-bf16)", mask);
+    BBBP_CHECK_ARG(mask >= 0 && mask <= 31, "set_conv_winograd: mask %d (bits 0/1 Winograd forward / data gradient, bits 2/3/4 split-bf16 forward / data gradient / weight gradient)", mask);
     g_winograd = mask;
     return BBBP_OK;
 }
@@ -966,7 +968,9 @@ extern "C" int bbbp_conv3x3_relu_pool_bwd_weight(void* stream, const float* x, c
         BBBP_CHECK_ARG(workspace_bytes >= (size_t)grid * (64 * 288 + 64) * sizeof(float), "conv bwd_weight: workspace too small");
         p.groups = groups;
         p.bslab = slab + (size_t)grid * 64 * 288;
-        int rc = cin == 32 ? launch_wgrad32<64, 32, 64>(p, grid, st)
+        int rc;
+        if (cin == 32 && cout == 64 && (winograd_mask() & 16)) rc = bbbp_b3_conv2_wgrad(st, x, gy, mask, slab, p.bslab, B, grid);
+        else rc = cin == 32 ? launch_wgrad32<64, 32, 64>(p, grid, st)
                : cin == 64 ? launch_wgrad32<64, 64, 128>(p, grid, st) : launch_wgrad32<32, 128, 256>(p, grid, st);
         if (rc) return rc;
         hipLaunchKernelGGL(conv_wgrad32_reduce_kernel, dim3(cdiv(64 * 289, 64), pairs), dim3(1024), 0, st, slab, p.bslab, dw, db,

@@ -306,6 +306,194 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(B3Params p) { conv_b3_body
 template <int MODE>
 __global__ __launch_bounds__(256) void conv_b3_probe_kernel(B3Params p) { conv_b3_body<MODE, true>(p); }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same stage: dW[co][ci][tap] = sum_{b, y, x} dY[b][co][y][x] X[b][ci][y + dy][x + dx] with dY the pooled
+// gradient expanded through the arg-max mask; db[co] = sum dY.  GEMM view: M = co (2 tiles of 32), N = (tap, ci) (9 tiles of 32),
+// K = pixels, 16 per MFMA.  Both operands sit in LDS pixel-INNERMOST, split in three bf16 planes: a lane's A fragment is 8
+// consecutive pixels of its output channel (one aligned ds_read_b128); its B fragment is 8 consecutive pixels of its input channel
+// shifted by the tap: the row shift is an address, the column shift dx = -1 / +1 is 2 bytes, so the three dx fragments of a row come
+// from ONE aligned 16-byte read plus the two neighbouring words, assembled with five v_alignbit_b32.
+// A work-group = 4 waves = (m-tile, k-group) pairs; a stage is one pooled row = 2 full-resolution rows x 64 pixels of one image
+// (8 k-steps, 4 per k-group); a wave keeps the 9 tap tiles of its m-tile (144 accumulator registers) for the whole kernel.  The two
+// k-groups are summed through LDS at the end, each work-group writes one partial slab [64][288] (+ 64 bias partials) and
+// conv.hip's fixed-order slab reduce finishes (bit-reproducible, no float atomics) -- the same slab contract as conv_wgrad32_kernel.
+constexpr int DYCO = 2 * IMG + 8;              // bf16 per output channel of a stage: 2 rows x 64 px (+ 16 B: bank spread)
+constexpr int DYPLANE = 64 * DYCO;
+constexpr int XROW = IMG + 16;                 // 8 px of zero halo on both sides: pixel x sits at index x + 8 (16-byte aligned groups)
+constexpr int XCI = 4 * XROW + 8;              // 4 rows per input channel (+ 16 B)
+constexpr int WXPLANE = 32 * XCI;
+constexpr size_t WG_LDS_BYTES = (size_t)(3 * DYPLANE + 3 * WXPLANE) * 2;
+
+struct B3WgradParams {
+    const float* x;         // [B][32][64][64]
+    const float* gy;        // pooled gradient [B][64][32][32]
+    const uint8_t* mask;    // [B][64][32][32]
+    float* slab;            // [grid][64][288]
+    float* bslab;           // [grid][64]
+    int B;
+};
+
+__global__ __launch_bounds__(256) void conv_b3_wgrad_kernel(B3WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    uint16_t* DYs = smem;                       // [plane][co][row 2][px]
+    uint16_t* XsW = smem + 3 * DYPLANE;         // [plane][ci][row 4][XROW]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    const int mt = wave & 1, kg = wave >> 1;
+    const int nstrips = p.B * (IMG / 2);
+    for (int i = t * 8; i < 3 * DYPLANE + 3 * WXPLANE; i += 256 * 8) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0, 0, 0, 0};
+
+    // ---- loader: dY items (co, quad of 4 pooled px) x 2 per thread; X items (ci, row, 8 px) x 4 per thread ----
+    f32x4 gq[2]; uint32_t mq[2]; f32x4 xq[4][2];
+    float bsum[2] = {0.f, 0.f};
+    uint32_t okx = 0;
+    auto load_stage = [&](int strip) __attribute__((always_inline)) {
+        const int b = strip / (IMG / 2), ph = strip % (IMG / 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = t + i * 256, q = idx & 7, co = idx >> 3;
+            const long off = (((long)b * 64 + co) * (IMG / 2) + ph) * (IMG / 2) + q * 4;
+            gq[i] = *reinterpret_cast<const f32x4*>(p.gy + off);
+            mq[i] = *reinterpret_cast<const uint32_t*>(p.mask + off);
+        }
+        okx = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = t + i * 256, q = idx & 7, row = (idx >> 3) & 3, ci = idx >> 5;
+            const int yr = 2 * ph - 1 + row;
+            okx |= (yr >= 0 && yr < IMG ? 1u : 0u) << i;
+            const float* src = p.x + (((long)b * 32 + ci) * IMG + min(max(yr, 0), IMG - 1)) * IMG + q * 8;
+            xq[i][0] = *reinterpret_cast<const f32x4*>(src);
+            xq[i][1] = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+    };
+    auto store_stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = t + i * 256, q = idx & 7, co = idx >> 3;
+            float v0[8], v1[8];                 // full-resolution rows 2 ph and 2 ph + 1, pixels 8 q .. 8 q + 7
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t m = (mq[i] >> (8 * e)) & 0xff;
+                const float g = gq[i][e];
+                bsum[i] += m < 4 ? g : 0.f;
+                v0[2 * e] = m == 0 ? g : 0.f; v0[2 * e + 1] = m == 1 ? g : 0.f;
+                v1[2 * e] = m == 2 ? g : 0.f; v1[2 * e + 1] = m == 3 ? g : 0.f;
+            }
+            uint32_t hi[4], mid[4], lo[4];
+            uint16_t* d = DYs + co * DYCO + q * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split2(v0[2 * j], v0[2 * j + 1], hi[j], mid[j], lo[j]);
+            *reinterpret_cast<u32x4*>(d) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<u32x4*>(d + DYPLANE) = u32x4{mid[0], mid[1], mid[2], mid[3]};
+            *reinterpret_cast<u32x4*>(d + 2 * DYPLANE) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split2(v1[2 * j], v1[2 * j + 1], hi[j], mid[j], lo[j]);
+            *reinterpret_cast<u32x4*>(d + IMG) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<u32x4*>(d + IMG + DYPLANE) = u32x4{mid[0], mid[1], mid[2], mid[3]};
+            *reinterpret_cast<u32x4*>(d + IMG + 2 * DYPLANE) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = t + i * 256, q = idx & 7, row = (idx >> 3) & 3, ci = idx >> 5;
+            const bool ok = (okx >> i) & 1u;
+            uint32_t hi[4], mid[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = j < 2 ? xq[i][0][2 * j] : xq[i][1][2 * j - 4], c = j < 2 ? xq[i][0][2 * j + 1] : xq[i][1][2 * j - 3];
+                split2(ok ? a : 0.f, ok ? c : 0.f, hi[j], mid[j], lo[j]);
+            }
+            uint16_t* d = XsW + ci * XCI + row * XROW + 8 + q * 8;
+            *reinterpret_cast<u32x4*>(d) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<u32x4*>(d + WXPLANE) = u32x4{mid[0], mid[1], mid[2], mid[3]};
+            *reinterpret_cast<u32x4*>(d + 2 * WXPLANE) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+
+    int strip = xcd_adjacent(blockIdx.x, gridDim.x);
+    __syncthreads();
+    if (strip < nstrips) { load_stage(strip); store_stage(); }
+    const uint16_t* abase = DYs + (mt * 32 + r) * DYCO + 8 * h;
+    const uint16_t* bbase = XsW + r * XCI + 8 + 8 * h;
+    for (; strip < nstrips; strip += gridDim.x) {
+        const int nstrip = strip + gridDim.x;
+        __syncthreads();                                     // this stage's LDS image is complete
+        if (nstrip < nstrips) load_stage(nstrip);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {                     // this k-group's four k-steps: row rr, pixels x0 .. x0 + 15
+            const int ks = kg * 4 + s4, rr = ks >> 2, x0 = (ks & 3) * 16;
+            bf16x8 a[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(abase + pl * DYPLANE + rr * IMG + x0);
+#pragma unroll
+            for (int dyi = 0; dyi < 3; ++dyi) {
+                bf16x8 bf[3][3];                             // [dx][plane]
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const uint16_t* src = bbase + pl * WXPLANE + (rr + dyi) * XROW + x0;
+                    const u32x4 w = *reinterpret_cast<const u32x4*>(src);
+                    const uint32_t wm = *reinterpret_cast<const uint32_t*>(src - 2), wp = *reinterpret_cast<const uint32_t*>(src + 8);
+                    const uint32_t s01 = __builtin_amdgcn_alignbit(w[1], w[0], 16), s12 = __builtin_amdgcn_alignbit(w[2], w[1], 16),
+                                   s23 = __builtin_amdgcn_alignbit(w[3], w[2], 16);
+                    const u32x4 left = {__builtin_amdgcn_alignbit(w[0], wm, 16), s01, s12, s23};            // pixels x - 1 ..
+                    const u32x4 right = {s01, s12, s23, __builtin_amdgcn_alignbit(wp, w[3], 16)};           // pixels x + 1 ..
+                    bf[0][pl] = __builtin_bit_cast(bf16x8, left);
+                    bf[1][pl] = __builtin_bit_cast(bf16x8, w);
+                    bf[2][pl] = __builtin_bit_cast(bf16x8, right);
+                }
+#pragma unroll
+                for (int dxi = 0; dxi < 3; ++dxi) {
+                    const int tap = dyi * 3 + dxi;
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bf[dxi][1], acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bf[dxi][0], acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bf[dxi][2], acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bf[dxi][0], acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bf[dxi][1], acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bf[dxi][0], acc[tap], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                     // every wave is done reading this stage
+        if (nstrip < nstrips) store_stage();
+    }
+    __syncthreads();
+    // ---- the two k-groups through LDS (the staging buffers are free now), tap by tap; k-group 0 adds and keeps ----
+    float* red = reinterpret_cast<float*>(smem);             // [mt 2][16][64] floats per tap pass
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        if (kg == 1) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) red[(mt * 16 + q) * 64 + lane] = acc[tap][q];
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[tap][q] += red[(mt * 16 + q) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (kg == 0) {
+        float* sdst = p.slab + (long)blockIdx.x * 64 * 288;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sdst[(mt * 32 + mfma_row(q, lane)) * 288 + tap * 32 + r] = acc[tap][q];
+    }
+    // bias-gradient partials: the 8 threads of one channel (consecutive lanes) reduce by shuffles
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float v = bsum[i];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+        const int idx = t + i * 256;
+        if ((idx & 7) == 0) p.bslab[(long)blockIdx.x * 64 + (idx >> 3)] = v;
+    }
+}
+
 template <int MODE>
 int launch_b3(const B3Params& p, hipStream_t st) {
     static const int probe = [] { const char* e = getenv("BBBP_B3_PROBE"); return e ? atoi(e) : 0; }();
@@ -355,5 +543,23 @@ int bbbp_b3_conv2_dgrad(hipStream_t st, const float* gy, const uint8_t* gmask, c
 extern "C" int bbbp_conv_b3_phases(unsigned long long* phases4) {
     BBBP_CHECK_ARG(phases4, "conv_b3_phases: null pointer");
     BBBP_CHECK_HIP(hipMemcpyFromSymbol(phases4, HIP_SYMBOL(g_b3_phase), 4 * sizeof(unsigned long long)));
+    return BBBP_OK;
+}
+
+// grid work-groups, each writes slab[g][64][288] and bslab[g][64] (conv.hip: conv_wgrad32_reduce_kernel finishes)
+int bbbp_b3_conv2_wgrad(hipStream_t st, const float* x, const float* gy, const uint8_t* mask, float* slab, float* bslab, int B, int grid) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_b3_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)WG_LDS_BYTES);
+        if (e != hipSuccess) {
+            bbbp_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", WG_LDS_BYTES, hipGetErrorString(e));
+            return BBBP_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    B3WgradParams p{x, gy, mask, slab, bslab, B};
+    hipLaunchKernelGGL(conv_b3_wgrad_kernel, dim3(grid), dim3(256), WG_LDS_BYTES, st, p);
+    BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }

@@ -339,7 +339,7 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
     # conv2's forward / data gradient may run as Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36.  The roofline
     # line prices the kernel at the algorithmic (direct) flop count of SURVEY.md 8(d); `winograd` also gives the executed flops.
     wmask = L.bbbp_get_conv_winograd()
-    b3 = {k: bool(wmask & bit) for k, bit in (("conv2_fwd", 4), ("conv2_dgrad", 8))}          # split-bf16 form takes precedence
+    b3 = {k: bool(wmask & bit) for k, bit in (("conv2_fwd", 4), ("conv2_dgrad", 8), ("conv2_wgrad", 16))}      # split-bf16 form takes precedence
     wino = {k: bool(wmask & bit) and not b3[k] for k, bit in (("conv2_fwd", 1), ("conv2_dgrad", 2))}
     roofline = None
     if cand:

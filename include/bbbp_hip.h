@@ -84,9 +84,12 @@ size_t bbbp_conv3x3_workspace_bytes(int B, int cin, int cout, int H, int W);
 /* Measurement aid (bench.py): shader-clock cycles and 100 MHz wall ticks that work-group 0 of the most recent
  * forward / data-gradient conv launch ran for (synchronises the device). */
 int bbbp_conv_last_clock(unsigned long long* shader_cycles, unsigned long long* ticks_100mhz);
-/* Selects the algorithm of the 32->64 @ 64x64 stage (R:88-90): bit 0 = forward, bit 1 = data gradient run as Winograd
- * F(2x2,3x3) in float32 (2.25x fewer multiplies, same tensors and mask, results within 1e-6 of the direct form);
- * 0 = direct implicit GEMM everywhere.  Initial value: environment BBBP_CONV_WINOGRAD, else 3. */
+/* Selects the algorithm of the 32->64 @ 64x64 stage (R:88-90).  bit 0 = forward, bit 1 = data gradient run as Winograd
+ * F(2x2,3x3) in float32 (2.25x fewer multiplies, same tensors and mask, results within 1e-6 of the direct form).
+ * bit 2 = forward, bit 3 = data gradient, bit 4 = weight gradient run as the direct implicit GEMM on the bf16 matrix pipe with
+ * every float32 operand split into three bf16 pieces (six bf16 products per float32 product, float32 accumulate: float32
+ * accuracy, csrc/conv_b3.hip); these bits take precedence over the Winograd bits.  0 = direct implicit GEMM on the f32 MFMA
+ * everywhere.  Initial value: environment BBBP_CONV_WINOGRAD, else 28. */
 int bbbp_set_conv_winograd(int mask);
 int bbbp_get_conv_winograd(void);
 /* Measurement aid: with BBBP_WINO_PROBE=1 in the environment the Winograd kernels stamp the shader clock at phase boundaries;

@@ -324,7 +324,7 @@ def test_fused_head_backward_matches_the_launch_per_op_chain(dev, B, training):
         assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), float(b.abs().max()))
 
 
-@pytest.mark.parametrize("conv2_form", [0, 3], ids=["direct", "winograd"])
+@pytest.mark.parametrize("conv2_form", [0, 3, 28], ids=["direct", "winograd", "split-bf16"])
 def test_real_molecule_images_against_oracle(dev, conv2_form):
     """The eight depictions shipped with the reference (tests/golden/img, white background: large flat regions, i.e. exact
     ties inside pooling windows in BOTH conv stages) through the full model: output, loss and every gradient element against

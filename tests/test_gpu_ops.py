@@ -126,10 +126,11 @@ def test_conv1_3to32(dev, B):
     _conv_case(dev, B, 3, 32, 128, seed=10 + B)
 
 
-@pytest.fixture(params=[0, 3, 12], ids=["direct", "winograd", "split-bf16"])
+@pytest.fixture(params=[0, 3, 28], ids=["direct", "winograd", "split-bf16"])
 def conv2_algo(request):
     """The forms of the 32 -> 64 @ 64x64 stage (bbbp_set_conv_winograd): direct implicit GEMM on the f32 MFMA, Winograd F(2x2,3x3),
-    and the direct form on the bf16 matrix pipe with every float32 operand split into three bf16 pieces (conv_b3.hip)."""
+    and the direct form on the bf16 matrix pipe with every float32 operand split into three bf16 pieces (conv_b3.hip: forward, data
+    gradient and weight gradient)."""
     L = _lib.lib()
     old = L.bbbp_get_conv_winograd()
     _lib.check(L.bbbp_set_conv_winograd(request.param), "bbbp_set_conv_winograd")

@@ -19,10 +19,10 @@ def oracle_params(m, double=True):
             .requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in m.state_dict().items()}
 
 
-@pytest.mark.parametrize("conv2_form", [3, 0], ids=["winograd", "direct"])
+@pytest.mark.parametrize("conv2_form", [28, 3, 0], ids=["split-bf16", "winograd", "direct"])
 def test_headline_batch_fwd_bwd_against_oracle(dev, conv2_form):
-    """BASELINE config 3 exactly as bench.py runs it (B = 512, F = 167, train mode, branch overlap ON, the 192-CU Winograd
-    partition or the direct conv2 form) with dropout 0: output, loss, BatchNorm running statistics and EVERY element of
+    """BASELINE config 3 exactly as bench.py runs it (B = 512, F = 167, train mode, branch overlap ON; conv2 in its default split-bf16
+    form, as Winograd on the 192-CU partition, and in the direct f32 form) with dropout 0: output, loss, BatchNorm running statistics and EVERY element of
     every non-degenerate gradient against the float64 oracle.
 
     ReLU kinks: a step has 6.3 M hidden FFN activations, and a float32 pre-activation carries ~1e-7 of rounding, so in about

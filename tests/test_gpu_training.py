@@ -44,7 +44,7 @@ def oracle_train(state, fp, img, y, orders, batch_size, faithful, test, lrs=None
     return losses, preds
 
 
-@pytest.fixture(params=[0, 3], ids=["direct", "winograd"])
+@pytest.fixture(params=[0, 3, 28], ids=["direct", "winograd", "split-bf16"])
 def conv2_form(request):
     """Both forms of the 32 -> 64 conv stage (include/bbbp_hip.h: bbbp_set_conv_winograd)."""
     L = _lib.lib()

@@ -50,14 +50,20 @@ def main():
     bias = (0.1 * torch.randn(64, generator=g)).to(dev)
     gy = torch.randn(B, 64, 32, 32, generator=g).to(dev)
     flops = 2.0 * B * 64 * 64 * 64 * 288
-    for mask, name in ((0, "direct"), (3, "winograd"), (12, "split-bf16")):
+    ref_dw = None
+    for mask, name in ((0, "direct"), (3, "winograd"), (28, "split-bf16")):
         L.bbbp_set_conv_winograd(mask)
         y, m = ops.conv3x3_relu_pool_fwd(x, w, bias)
         tf = timed(lambda: ops.conv3x3_relu_pool_fwd(x, w, bias))
         td = timed(lambda: ops.conv3x3_relu_pool_bwd_data(gy, m, w))
+        tw = timed(lambda: ops.conv3x3_relu_pool_bwd_weight(x, gy, m))
+        dw, db = ops.conv3x3_relu_pool_bwd_weight(x, gy, m)
+        if ref_dw is None:
+            ref_dw, ref_m = dw, m
         print(f"{name:9s} B={B}: fwd {tf:.3f} ms ({flops / tf / 1e9:.1f} TFLOP/s direct-equivalent), dgrad {td:.3f} ms "
-              f"({flops / td / 1e9:.1f})", flush=True)
-        if mask == 12 and os.environ.get("BBBP_B3_PROBE") == "1":
+              f"({flops / td / 1e9:.1f}), wgrad {tw:.3f} ms ({flops / tw / 1e9:.1f}; max|dw - direct| "
+              f"{float((dw - ref_dw).abs().max()):.2e} of {float(ref_dw.abs().max()):.2e}, masks equal {bool((m == ref_m).all())})", flush=True)
+        if mask == 28 and os.environ.get("BBBP_B3_PROBE") == "1":
             import ctypes
             for nm, fn in (("fwd", lambda: ops.conv3x3_relu_pool_fwd(x, w, bias)), ("dgrad", lambda: ops.conv3x3_relu_pool_bwd_data(gy, m, w))):
                 fn(); torch.cuda.synchronize()
