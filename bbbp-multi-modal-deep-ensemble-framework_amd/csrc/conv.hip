@@ -809,14 +809,14 @@ inline int winograd_mask() {
     // the training step 0.47 / 0.42 vs 0.57 / 0.61 ms: 66 KB of LDS and 160 registers per wave leave room for the other branch's
     // kernels on every CU (the Winograd work-groups take whole CUs and give 64 of them up), and a bf16 MFMA holds the vector issue
     // for 8 of its 32 cycles where the f32 MFMA blocks it for all 64
-    if (g_winograd < 0) { const char* e = getenv("BBBP_CONV_WINOGRAD"); g_winograd = e ? atoi(e) & 31 : 28; }
+    if (g_winograd < 0) { const char* e = getenv("BBBP_CONV_WINOGRAD"); g_winograd = e ? atoi(e) & 127 : 60; }
     return g_winograd;
 }
 
 }  // namespace
 
 extern "C" int bbbp_set_conv_winograd(int mask) {
-    BBBP_CHECK_ARG(mask >= 0 && mask <= 31, "set_conv_winograd: mask %d (bits 0/1 Winograd forward / data gradient, bits 2/3/4 split-bf16 forward / data gradient / weight gradient)", mask);
+    BBBP_CHECK_ARG(mask >= 0 && mask <= 127, "set_conv_winograd: mask %d (bits 0/1 Winograd forward / data gradient, bits 2/3/4 split-bf16 forward / data gradient / weight gradient of conv2, bits 5/6 split-bf16 weight gradient / forward of conv1)", mask);
     g_winograd = mask;
     return BBBP_OK;
 }
@@ -953,10 +953,15 @@ extern "C" int bbbp_conv3x3_relu_pool_bwd_weight(void* stream, const float* x, c
         BBBP_CHECK_ARG(workspace_bytes >= (size_t)grid * (1024 + 32) * sizeof(float), "conv bwd_weight: workspace too small");
         p.groups = groups;
         p.bslab = slab + (size_t)grid * 1024;
+        if (cout == 32 && (winograd_mask() & 32)) {
+            int rc = bbbp_b3_conv1_wgrad(st, x, gy, mask, slab, p.bslab, B, grid);
+            if (rc) return rc;
+        } else {
         int rc = set_lds(conv_wgrad3_kernel<128>, lds3);
         if (rc) return rc;
         hipLaunchKernelGGL((conv_wgrad3_kernel<128>), dim3(grid), dim3(512), lds3, st, p);
         BBBP_CHECK_LAUNCH();
+        }
         hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3(33, ncob), dim3(1024), 0, st, slab, p.bslab, dw, db, groups);
         BBBP_CHECK_LAUNCH();
     } else {

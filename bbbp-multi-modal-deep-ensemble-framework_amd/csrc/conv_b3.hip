@@ -494,6 +494,183 @@ __global__ __launch_bounds__(256) void conv_b3_wgrad_kernel(B3WgradParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the FIRST conv stage (3 -> 32 channels on 128x128 images, R:85-87): M = co (32), N = (ci, kh, kw) = 27 of 32
+// columns, K = pixels.  435 MB of compulsory traffic against 14.5 GFLOP: the kernel is HBM-bound (~0.09 ms), what the split-bf16 form
+// buys here is not matrix rate but (i) a bf16 MFMA stream that leaves the vector ALU to the loader and to the other branch's kernels
+// (the f32 form took 0.21 ms alone and 0.35 ms beside the encoder's backward chain) and (ii) room for two work-groups per CU.
+// Column n of the B operand has its OWN (ci, kh, kw): every lane reads an aligned 16-byte group of its input row plus the two
+// neighbouring words and picks the kw shift with v_alignbit_b32 (shift 0 or 16) on per-lane selected word pairs.
+// A stage is one pooled row (2 full-resolution rows x 128 pixels = 16 k-steps, 4 per wave); global loads run TWO stages ahead in two
+// register sets.  Same slab contract as conv_wgrad3_kernel: slab[g][32][32] (column j = ci * 9 + kh * 3 + kw), bslab[g][32].
+constexpr int IMG1 = 128;
+constexpr int DY1CO = 2 * IMG1 + 8;             // bf16 per output channel of a stage (+16 B)
+constexpr int DY1PLANE = 32 * DY1CO;
+constexpr int X1ROW = IMG1 + 16;                // pixel x at index x + 8
+constexpr int X1CI = 4 * X1ROW + 8;
+constexpr int X1PLANE = 3 * X1CI;
+constexpr size_t WG3_LDS_BYTES = (size_t)(3 * DY1PLANE + 3 * X1PLANE) * 2;
+
+struct B3Wgrad3Params {
+    const float* x;         // [B][3][128][128]
+    const float* gy;        // pooled gradient [B][32][64][64]
+    const uint8_t* mask;    // [B][32][64][64]
+    float* slab;            // [grid][32][32]
+    float* bslab;           // [grid][32]
+    int B;
+};
+
+__global__ __launch_bounds__(256) void conv_b3_wgrad3_kernel(B3Wgrad3Params p) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    uint16_t* DYs = smem;                        // [plane][co 32][row 2][128]
+    uint16_t* X1s = smem + 3 * DY1PLANE;         // [plane][ci 3][row 4][X1ROW]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    const int nstrips = p.B * (IMG1 / 2);
+    for (int i = t * 8; i < 3 * DY1PLANE + 3 * X1PLANE; i += 256 * 8) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0, 0, 0, 0};
+
+    // ---- loader: dY items (co, quad of 4 pooled px) x 2 per thread; X items (ci, row, 8 px): 192, threads 0..191 ----
+    f32x4 gq[2][2]; uint32_t mq[2][2]; f32x4 xq[2][2];        // [register set][item]
+    uint32_t okx[2] = {0, 0};
+    float bsum[2] = {0.f, 0.f};
+    const int xi_q = t & 15, xi_row = (t >> 4) & 3, xi_ci = min(t >> 6, 2);
+    auto load_stage = [&](int strip, int set) __attribute__((always_inline)) {
+        const int b = strip / (IMG1 / 2), ph = strip % (IMG1 / 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = t + i * 256, q = idx & 15, co = idx >> 4;
+            const long off = (((long)b * 32 + co) * (IMG1 / 2) + ph) * (IMG1 / 2) + q * 4;
+            gq[set][i] = *reinterpret_cast<const f32x4*>(p.gy + off);
+            mq[set][i] = *reinterpret_cast<const uint32_t*>(p.mask + off);
+        }
+        const int yr = 2 * ph - 1 + xi_row;
+        okx[set] = (yr >= 0 && yr < IMG1 && t < 192) ? 1u : 0u;
+        const float* src = p.x + (((long)b * 3 + xi_ci) * IMG1 + min(max(yr, 0), IMG1 - 1)) * IMG1 + xi_q * 8;
+        xq[set][0] = *reinterpret_cast<const f32x4*>(src);
+        xq[set][1] = *reinterpret_cast<const f32x4*>(src + 4);
+    };
+    auto store_stage = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = t + i * 256, q = idx & 15, co = idx >> 4;
+            float v0[8], v1[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t m = (mq[set][i] >> (8 * e)) & 0xff;
+                const float g = gq[set][i][e];
+                bsum[i] += m < 4 ? g : 0.f;
+                v0[2 * e] = m == 0 ? g : 0.f; v0[2 * e + 1] = m == 1 ? g : 0.f;
+                v1[2 * e] = m == 2 ? g : 0.f; v1[2 * e + 1] = m == 3 ? g : 0.f;
+            }
+            uint32_t hi[4], mid[4], lo[4];
+            uint16_t* d = DYs + co * DY1CO + q * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split2(v0[2 * j], v0[2 * j + 1], hi[j], mid[j], lo[j]);
+            *reinterpret_cast<u32x4*>(d) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<u32x4*>(d + DY1PLANE) = u32x4{mid[0], mid[1], mid[2], mid[3]};
+            *reinterpret_cast<u32x4*>(d + 2 * DY1PLANE) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split2(v1[2 * j], v1[2 * j + 1], hi[j], mid[j], lo[j]);
+            *reinterpret_cast<u32x4*>(d + IMG1) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<u32x4*>(d + IMG1 + DY1PLANE) = u32x4{mid[0], mid[1], mid[2], mid[3]};
+            *reinterpret_cast<u32x4*>(d + IMG1 + 2 * DY1PLANE) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+        }
+        if (t < 192) {
+            const bool ok = okx[set] != 0;
+            uint32_t hi[4], mid[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = j < 2 ? xq[set][0][2 * j] : xq[set][1][2 * j - 4], c = j < 2 ? xq[set][0][2 * j + 1] : xq[set][1][2 * j - 3];
+                split2(ok ? a : 0.f, ok ? c : 0.f, hi[j], mid[j], lo[j]);
+            }
+            uint16_t* d = X1s + xi_ci * X1CI + xi_row * X1ROW + 8 + xi_q * 8;
+            *reinterpret_cast<u32x4*>(d) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<u32x4*>(d + X1PLANE) = u32x4{mid[0], mid[1], mid[2], mid[3]};
+            *reinterpret_cast<u32x4*>(d + 2 * X1PLANE) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    // column r <-> (ci, kh, kw) = (r / 9, (r % 9) / 3, r % 3) for r < 27; the other five columns compute finite garbage nobody reads
+    const int jj = r < 27 ? r : 0;
+    const int ci = jj / 9, kh = (jj % 9) / 3, kw = jj % 3;
+    const uint16_t* abase = DYs + r * DY1CO + 8 * h;
+    const uint16_t* bbase = X1s + ci * X1CI + kh * X1ROW + 8 + 8 * h;
+    const uint32_t shift = kw == 1 ? 0u : 16u;
+
+    const int stride = gridDim.x;
+    int strip = xcd_adjacent(blockIdx.x, gridDim.x);
+    __syncthreads();
+    if (strip < nstrips) { load_stage(strip, 0); store_stage(0); }
+    if (strip + stride < nstrips) load_stage(strip + stride, 1);
+    // the loop is unrolled by two so that the register-set index is a compile-time constant: stage s computes from LDS, the global
+    // loads of stage s + 2 go into the set that stage s's data left, stage s + 1's data (loaded a whole stage ago) is split and stored
+    for (; strip < nstrips; strip += 2 * stride) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int cur = strip + u * stride;
+            if (cur >= nstrips) break;
+            __syncthreads();                                 // LDS image of stage `cur` is complete
+            if (cur + 2 * stride < nstrips) load_stage(cur + 2 * stride, u);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int ks = wave * 4 + s4, rr = ks >> 3, x0 = (ks & 7) * 16;
+                bf16x8 a[3], bf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    a[pl] = *reinterpret_cast<const bf16x8*>(abase + pl * DY1PLANE + rr * IMG1 + x0);
+                    const uint16_t* src = bbase + pl * X1PLANE + rr * X1ROW + x0;
+                    const u32x4 w = *reinterpret_cast<const u32x4*>(src);
+                    const uint32_t wm = *reinterpret_cast<const uint32_t*>(src - 2), wp = *reinterpret_cast<const uint32_t*>(src + 8);
+                    // kw = 0: pixels x - 1 ..; kw = 1: x ..; kw = 2: x + 1 ..   (alignbit(hi, lo, s) = (lo >> s) | (hi << (32 - s)); s = 0 gives lo)
+                    const uint32_t l0 = kw == 0 ? wm : w[0], l1 = kw == 0 ? w[0] : w[1], l2 = kw == 0 ? w[1] : w[2], l3 = kw == 0 ? w[2] : w[3];
+                    const uint32_t u0 = kw == 0 ? w[0] : w[1], u1 = kw == 0 ? w[1] : w[2], u2 = kw == 0 ? w[2] : w[3], u3 = kw == 0 ? w[3] : wp;
+                    const uint32_t c0 = kw == 1 ? w[0] : l0, c1 = kw == 1 ? w[1] : l1, c2 = kw == 1 ? w[2] : l2, c3 = kw == 1 ? w[3] : l3;
+                    const u32x4 f = {__builtin_amdgcn_alignbit(u0, c0, shift), __builtin_amdgcn_alignbit(u1, c1, shift),
+                                     __builtin_amdgcn_alignbit(u2, c2, shift), __builtin_amdgcn_alignbit(u3, c3, shift)};
+                    bf[pl] = __builtin_bit_cast(bf16x8, f);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bf[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bf[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bf[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bf[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bf[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bf[0], acc, 0, 0, 0);
+            }
+            __syncthreads();                                 // every wave is done reading this stage
+            if (cur + stride < nstrips) store_stage(u ^ 1);
+        }
+    }
+    __syncthreads();
+    // ---- the four waves' partial tiles through LDS in wave order; wave 0 adds and writes the slab ----
+    float* red = reinterpret_cast<float*>(smem);
+    for (int g = 1; g < 4; ++g) {
+        if (wave == g) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) red[q * 64 + lane] = acc[q];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] += red[q * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        float* sdst = p.slab + (long)blockIdx.x * 1024;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sdst[mfma_row(q, lane) * 32 + r] = acc[q];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float v = bsum[i];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        const int idx = t + i * 256;
+        if ((idx & 15) == 0) p.bslab[(long)blockIdx.x * 32 + (idx >> 4)] = v;
+    }
+}
+
 template <int MODE>
 int launch_b3(const B3Params& p, hipStream_t st) {
     static const int probe = [] { const char* e = getenv("BBBP_B3_PROBE"); return e ? atoi(e) : 0; }();
@@ -560,6 +737,24 @@ int bbbp_b3_conv2_wgrad(hipStream_t st, const float* x, const float* gy, const u
     }
     B3WgradParams p{x, gy, mask, slab, bslab, B};
     hipLaunchKernelGGL(conv_b3_wgrad_kernel, dim3(grid), dim3(256), WG_LDS_BYTES, st, p);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+// 3 -> 32 @ 128x128 weight gradient: grid work-groups, each writes slab[g][32][32] and bslab[g][32] (conv.hip: conv_wgrad3_reduce_kernel)
+int bbbp_b3_conv1_wgrad(hipStream_t st, const float* x, const float* gy, const uint8_t* mask, float* slab, float* bslab, int B, int grid) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_b3_wgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)WG3_LDS_BYTES);
+        if (e != hipSuccess) {
+            bbbp_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", WG3_LDS_BYTES, hipGetErrorString(e));
+            return BBBP_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    B3Wgrad3Params p{x, gy, mask, slab, bslab, B};
+    hipLaunchKernelGGL(conv_b3_wgrad3_kernel, dim3(grid), dim3(256), WG3_LDS_BYTES, st, p);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }

@@ -354,7 +354,8 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
                              "kernels; *_isolated = same kernel, overlap off, after the timed region",
                         ms_per_launch_isolated=round(isolated.get(dom, 0.0), 4),
                         frac_isolated=round(kf / (isolated[dom] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if isolated.get(dom) else None,
-                        sections_ms={k: round(v, 4) for k, v in sections.items()})
+                        sections_ms={k: round(v, 4) for k, v in sections.items()},
+                        sections_ms_isolated={k: round(v, 4) for k, v in isolated.items()})
         roofline["algorithm"] = ("winograd F(2x2,3x3) f32" if wino.get(dom) else
                                  "direct implicit GEMM, f32 operands split into 3 bf16 pieces (6 bf16 MFMAs per f32 product, f32 accumulate)" if b3.get(dom)
                                  else "direct implicit GEMM f32") if dom.startswith("conv2") \

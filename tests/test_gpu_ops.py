@@ -121,8 +121,19 @@ def _conv_case(dev, B, cin, cout, hw, seed, uniform_patches=False):
         assert_close(dx.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol_frac=2e-5, what="conv dx")
 
 
-@pytest.mark.parametrize("B", [1, 3])
-def test_conv1_3to32(dev, B):
+@pytest.fixture(params=[0, 96], ids=["f32", "split-bf16"])
+def conv1_algo(request):
+    """The forms of the 3 -> 32 @ 128x128 stage: f32 MFMA kernels, or (bits 5/6 of bbbp_set_conv_winograd) the bf16 matrix pipe with
+    split operands (conv_b3.hip)."""
+    L = _lib.lib()
+    old = L.bbbp_get_conv_winograd()
+    _lib.check(L.bbbp_set_conv_winograd(request.param), "bbbp_set_conv_winograd")
+    yield request.param
+    L.bbbp_set_conv_winograd(old)
+
+
+@pytest.mark.parametrize("B", [1, 3, 9])
+def test_conv1_3to32(dev, B, conv1_algo):
     _conv_case(dev, B, 3, 32, 128, seed=10 + B)
 
 
