@@ -112,6 +112,27 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// Split-bf16 arithmetic (conv_b3.hip, gemm.hip): a float is the exact sum of three bf16 pieces hi + mid + lo (3 x 8 significand bits),
+// and a product of two floats is, to float32 accuracy, the sum of the six piece products hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid --
+// six v_mfma_f32_32x32x16_bf16 (f32 accumulate) in place of eight v_mfma_f32_32x32x2_f32, at 2.67x the matrix rate.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // clang vectors stay in registers; arrays of HIP's uint4 struct were demoted to scratch
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// hi / mid / lo of two floats, packed pairwise (a in the low half)
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    f32x2v v = {a, b};
+    bf16x2 h = __builtin_convertvector(v, bf16x2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    v[0] -= __builtin_bit_cast(float, hi << 16); v[1] -= __builtin_bit_cast(float, hi & 0xffff0000u);
+    bf16x2 m = __builtin_convertvector(v, bf16x2);
+    mid = __builtin_bit_cast(uint32_t, m);
+    v[0] -= __builtin_bit_cast(float, mid << 16); v[1] -= __builtin_bit_cast(float, mid & 0xffff0000u);
+    bf16x2 l = __builtin_convertvector(v, bf16x2);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+
 // Philox-4x32-10 counter RNG for dropout masks (recomputed, never stored)
 __device__ __forceinline__ uint4 philox4(uint64_t seed, uint64_t ctr) {
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);

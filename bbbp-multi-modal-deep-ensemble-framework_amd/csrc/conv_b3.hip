@@ -22,11 +22,6 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // clang vectors stay in registers; arrays of HIP's uint4 struct were demoted to scratch
-
 constexpr int B3_FWD = 0, B3_DGRAD = 1;
 constexpr int IMG = 64;
 constexpr int R = 4, ROWS = R + 2;            // output rows per strip, staged rows (halo)
@@ -46,19 +41,6 @@ struct B3Params {
     uint8_t* ymask;         // FWD
     int B;
 };
-
-// hi / mid / lo of two floats, packed pairwise
-__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-    f32x2v v = {a, b};
-    bf16x2 h = __builtin_convertvector(v, bf16x2);
-    hi = __builtin_bit_cast(uint32_t, h);
-    v[0] -= __builtin_bit_cast(float, hi << 16); v[1] -= __builtin_bit_cast(float, hi & 0xffff0000u);
-    bf16x2 m = __builtin_convertvector(v, bf16x2);
-    mid = __builtin_bit_cast(uint32_t, m);
-    v[0] -= __builtin_bit_cast(float, mid << 16); v[1] -= __builtin_bit_cast(float, mid & 0xffff0000u);
-    bf16x2 l = __builtin_convertvector(v, bf16x2);
-    lo = __builtin_bit_cast(uint32_t, l);
-}
 
 // filters -> [m-block][chunk][tap][plane][k-half][m 32][8] bf16.
 //   FWD  : m = output channel co (2 blocks of 32), k = input channel ci (2 chunks of 16), tap = kh * 3 + kw

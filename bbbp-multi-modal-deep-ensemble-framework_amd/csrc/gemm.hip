@@ -23,6 +23,9 @@
 
 #define TRY_RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // gfx950 global loads need only 4-byte alignment
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+
 namespace {
 
 // K depth of one LDS stage.  The 64x64 tile keeps 17 KB of LDS and ~32 VGPRs on purpose: the encoder's small
@@ -263,6 +266,199 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The LARGE products (128 x 128 tiles: the F = 2048 encoder's projections / FFN and their gradients, the 65536-wide image FC) on the
+// bf16 matrix pipe with split operands (common.h: split2): every float32 operand element is cut into three bf16 pieces on its way
+// into LDS and a k-step of 16 is six v_mfma_f32_32x32x16_bf16 per 32 x 32 tile -- float32 accuracy (the dropped piece products are
+// below 2^-24 of the product) at 2.67x the rate of v_mfma_f32_32x32x2_f32.  Same GemmParams, grid, split-K slabs and epilogue as
+// gemm_f32_kernel<128, 128>.
+//   * LDS: [operand 2][plane 3][row 128][32 k + 8] bf16 = 60 KB, ONE stage (the next stage waits in registers as float32), so two
+//     work-groups share a CU and one group's split + store phase runs under the other's MFMA block;
+//   * both tiles are row-major in k: the operand of lane (r, h) -- row r, k = 8h .. 8h+7 -- is one ds_read_b128, conflict-free at the
+//     80-byte row stride; a k-major global tile ([K][M]) is transposed in registers: a thread loads a 4 (k) x 4 (m) block with four
+//     16-byte loads and writes four 8-byte k-quads per plane (lane = k-quad + 8 * row-quad: conflict-free as well);
+//   * needs K % 4 == 0 (k-contiguous operand) / extent % 4 == 0 (k-major operand); anything else keeps the f32 kernel.
+constexpr int B3_BK = 32;
+constexpr int B3_LD = B3_BK + 8;
+constexpr int B3_PLANE = 128 * B3_LD;
+constexpr size_t B3_LDS = (size_t)6 * B3_PLANE * sizeof(uint16_t);
+
+template <bool KMAJ>
+struct B3Loader {
+    const float* X; int ld, extent, row0;
+    f32x4u v[4];
+    // thread (kq = t & 7, rq = t >> 3): k-contiguous: rows rq + 32 i, k = k0 + 4 kq ..+3;  k-major: k = k0 + 4 kq + j, rows 4 rq ..+3
+    __device__ __forceinline__ void load(int t, int k0, int kbeg, int kend) {
+        const int kq = t & 7, rq = t >> 3;
+        if constexpr (KMAJ) {
+            const int col = min(row0 + 4 * rq, extent - 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + 4 * kq + j;
+                v[j] = *reinterpret_cast<const f32x4u*>(X + (long)(k < kend ? k : kbeg) * ld + col);
+            }
+        } else {
+            const int k = k0 + 4 * kq;
+            const int kk = k < kend ? k : kbeg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                v[i] = *reinterpret_cast<const f32x4u*>(X + (long)min(row0 + rq + 32 * i, extent - 1) * ld + kk);
+        }
+    }
+    __device__ __forceinline__ void store(uint16_t* dst, int t, int k0, int kend) const {
+        const int kq = t & 7, rq = t >> 3;
+        if constexpr (KMAJ) {
+            bool ok[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ok[j] = k0 + 4 * kq + j < kend;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t h0, m0, l0, h1, m1, l1;
+                split2(ok[0] ? v[0][i] : 0.f, ok[1] ? v[1][i] : 0.f, h0, m0, l0);
+                split2(ok[2] ? v[2][i] : 0.f, ok[3] ? v[3][i] : 0.f, h1, m1, l1);
+                uint16_t* d = dst + (4 * rq + i) * B3_LD + 4 * kq;
+                *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(d + B3_PLANE) = u32x2{m0, m1};
+                *reinterpret_cast<u32x2*>(d + 2 * B3_PLANE) = u32x2{l0, l1};
+            }
+        } else {
+            const bool ok = k0 + 4 * kq < kend;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t h0, m0, l0, h1, m1, l1;
+                split2(ok ? v[i][0] : 0.f, ok ? v[i][1] : 0.f, h0, m0, l0);
+                split2(ok ? v[i][2] : 0.f, ok ? v[i][3] : 0.f, h1, m1, l1);
+                uint16_t* d = dst + (rq + 32 * i) * B3_LD + 4 * kq;
+                *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(d + B3_PLANE) = u32x2{m0, m1};
+                *reinterpret_cast<u32x2*>(d + 2 * B3_PLANE) = u32x2{l0, l1};
+            }
+        }
+    }
+};
+
+// phase breakdown of work-group 0 / wave 0 of the last probed launch (BBBP_GEMM_B3_PROBE=1; tools/bench_gemm_forms.py prints it): shader
+// cycles in [0] global-load issue, [1] LDS reads + MFMA block, [2] barrier after the MFMAs, [3] split + LDS writes, [4] barrier after them
+__device__ unsigned long long g_gemm_b3_phase[7];      // [5] all shader cycles of the wave, [6] the same span in 100 MHz wall ticks
+
+template <int LAYOUT, bool PROBE>
+__device__ __forceinline__ void gemm_b3_body(const GemmParams& p) {
+    BBBP_HIGH_PRIO();
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, c0 = 0;
+    const unsigned long long cyc_begin = PROBE ? __builtin_readcyclecounter() : 0, wall_begin = PROBE ? wall_clock64() : 0;
+    constexpr bool A_KMAJ = (LAYOUT == 2), B_KMAJ = (LAYOUT != 0);
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem16[];
+    uint16_t* As = smem16;
+    uint16_t* Bs = smem16 + 3 * B3_PLANE;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int batch = blockIdx.z / p.splits, split = blockIdx.z % p.splits;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int kbeg = split * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+
+    B3Loader<A_KMAJ> la{p.A + (long)batch * p.sA, p.lda, p.M, m0};
+    B3Loader<B_KMAJ> lb{p.B + (long)batch * p.sB, p.ldb, p.N, n0};
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    const int nt = (kend - kbeg + B3_BK - 1) / B3_BK;
+    if (nt > 0) {
+        la.load(t, kbeg, kbeg, kend); lb.load(t, kbeg, kbeg, kend);
+        la.store(As, t, kbeg, kend); lb.store(Bs, t, kbeg, kend);
+    }
+    __syncthreads();
+    const uint16_t* afrag = As + (wm * 64 + r) * B3_LD + 8 * h;
+    const uint16_t* bfrag = Bs + (wn * 64 + r) * B3_LD + 8 * h;
+    for (int it = 0; it < nt; ++it) {
+        const int knext = kbeg + (it + 1) * B3_BK;
+        if (PROBE) c0 = __builtin_readcyclecounter();
+        if (it + 1 < nt) { la.load(t, knext, kbeg, kend); lb.load(t, knext, kbeg, kend); }
+        if (PROBE) { const unsigned long long c = __builtin_readcyclecounter(); ph[0] += c - c0; c0 = c; }
+#pragma unroll
+        for (int kk = 0; kk < B3_BK / 16; ++kk) {
+            bf16x8 a[2][3], b[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    a[i][pl] = *reinterpret_cast<const bf16x8*>(afrag + pl * B3_PLANE + i * 32 * B3_LD + kk * 16);
+                    b[i][pl] = *reinterpret_cast<const bf16x8*>(bfrag + pl * B3_PLANE + i * 32 * B3_LD + kk * 16);
+                }
+            // smallest piece products first; the four tiles interleaved so that consecutive MFMAs are independent
+            constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+        }
+        if (PROBE) { const unsigned long long c = __builtin_readcyclecounter(); ph[1] += c - c0; c0 = c; }
+        __syncthreads();                         // every wave is done reading this stage
+        if (PROBE) { const unsigned long long c = __builtin_readcyclecounter(); ph[2] += c - c0; c0 = c; }
+        if (it + 1 < nt) { la.store(As, t, knext, kend); lb.store(Bs, t, knext, kend); }
+        if (PROBE) { const unsigned long long c = __builtin_readcyclecounter(); ph[3] += c - c0; c0 = c; }
+        __syncthreads();
+        if (PROBE) { const unsigned long long c = __builtin_readcyclecounter(); ph[4] += c - c0; c0 = c; }
+    }
+    if (PROBE && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && t == 0) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) g_gemm_b3_phase[i] = ph[i];
+        g_gemm_b3_phase[5] = __builtin_readcyclecounter() - cyc_begin;
+        g_gemm_b3_phase[6] = wall_clock64() - wall_begin;
+    }
+
+    if (p.splits > 1) {
+        float* S = p.slab + ((long)batch * p.splits + split) * (long)p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + r;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int m = m0 + wm * 64 + i * 32 + mfma_row(q, lane);
+                    if (m < p.M && n < p.N) S[(long)m * p.N + n] = acc[i][j][q];
+                }
+            }
+        return;
+    }
+    float* C = p.C + (long)batch * p.sC;
+    const float* R = p.R ? p.R + (long)batch * p.sR : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + r;
+            const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int m = m0 + wm * 64 + i * 32 + mfma_row(q, lane);
+                if (m < p.M && n < p.N) {
+                    float v = apply_act(p.alpha * acc[i][j][q] + bv, p.act);
+                    const float gsel = p.gate ? (p.gate[(long)batch * p.sG + (long)m * p.ldg + n] > 0.f ? p.gate_scale : 0.f) : 1.f;
+                    if (!p.gate_after) v *= gsel;
+                    if (R) v += R[(long)m * p.ldr + n];
+                    if (p.gate_after) v *= gsel;
+                    C[(long)m * p.ldc + n] = v;
+                }
+            }
+        }
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(256, 2) void gemm_b3_kernel(GemmParams p) { gemm_b3_body<LAYOUT, false>(p); }
+template <int LAYOUT>
+__global__ __launch_bounds__(256, 2) void gemm_b3_probe_kernel(GemmParams p) { gemm_b3_body<LAYOUT, true>(p); }
+
 // sums the split-K slabs in split order and applies the epilogue
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
     BBBP_HIGH_PRIO();
@@ -315,8 +511,6 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
 //     addresses and never stored: a column of D only depends on its own column of B, so garbage stays there;
 //   * deep K is split over the `ks` waves of the work-group (chunk c -> wave c % ks) and summed through LDS in a
 //     fixed order by wave 0 -- one launch, no slab traffic, bit-reproducible.
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 
 struct DirectParams {
     const float* A; const float* B; float* C;
@@ -643,6 +837,36 @@ void launch_tile(const GemmParams& p, int layout, dim3 grid, hipStream_t st) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+int g_gemm_b3 = -1;
+int gemm_b3_on() {
+    if (g_gemm_b3 < 0) { const char* e = getenv("BBBP_GEMM_SPLIT_BF16"); g_gemm_b3 = e ? (atoi(e) != 0) : 1; }
+    return g_gemm_b3;
+}
+// the split-bf16 form serves 128 x 128 plans whose operands can be read in aligned-extent quads
+bool b3_eligible(const GemmParams& p, int layout) {
+    if (!gemm_b3_on() || p.K < 32) return false;
+    const bool a_ok = layout == 2 ? (p.M % 4 == 0 && p.M >= 4) : (p.K % 4 == 0);
+    const bool b_ok = layout == 0 ? (p.K % 4 == 0) : (p.N % 4 == 0 && p.N >= 4);
+    return a_ok && b_ok;
+}
+template <int LAYOUT>
+int launch_b3_one(const GemmParams& p, dim3 grid, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_b3_kernel<LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_LDS);
+        if (e != hipSuccess) { bbbp_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", B3_LDS, hipGetErrorString(e)); return BBBP_ERR_HIP; }
+        attr_set = true;
+    }
+    static const bool probe = [] { const char* e = getenv("BBBP_GEMM_B3_PROBE"); return e && atoi(e) != 0; }();
+    if (probe) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_b3_probe_kernel<LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_LDS);
+        hipLaunchKernelGGL((gemm_b3_probe_kernel<LAYOUT>), grid, dim3(256), B3_LDS, st, p);
+    } else {
+        hipLaunchKernelGGL((gemm_b3_kernel<LAYOUT>), grid, dim3(256), B3_LDS, st, p);
+    }
+    return BBBP_OK;
+}
+
 }  // namespace
 
 // Split-K plan shared by the launcher and bbbp_gemm_workspace_bytes.
@@ -772,7 +996,9 @@ int gemm_run(hipStream_t st, const bbbp_gemm_desc& g, void* workspace, size_t wo
                  (long)cdiv(M, 128) * cdiv(N, 128) * batch >= (long)short_k_tiles * bbbp_num_cus()) ? 1 : 0;
     dim3 grid(cdiv(N, tile), cdiv(M, tile), batch * p.splits);
     BBBP_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
-    if (tile == 128) launch_tile<128, 128>(p, layout, grid, st);
+    if (tile == 128 && b3_eligible(p, layout)) {
+        TRY_RC(layout == 0 ? launch_b3_one<0>(p, grid, st) : layout == 1 ? launch_b3_one<1>(p, grid, st) : launch_b3_one<2>(p, grid, st));
+    } else if (tile == 128) launch_tile<128, 128>(p, layout, grid, st);
     else launch_tile<64, 64>(p, layout, grid, st);
     BBBP_CHECK_LAUNCH();
     if (p.splits > 1) {
@@ -823,5 +1049,18 @@ extern "C" int bbbp_gemm_f32_grouped(void* stream, const bbbp_gemm_desc* problem
         TRY_RC(gemm_run(st, problems[i], workspace, workspace_bytes));
         ++i;
     }
+    return BBBP_OK;
+}
+
+extern "C" int bbbp_set_gemm_split_bf16(int on) {
+    const int prev = gemm_b3_on();
+    g_gemm_b3 = on ? 1 : 0;
+    return prev;
+}
+
+extern "C" int bbbp_gemm_split_bf16_phases(unsigned long long* phases7) {
+    BBBP_CHECK_ARG(phases7 != nullptr, "gemm_split_bf16_phases: null output");
+    BBBP_CHECK_HIP(hipDeviceSynchronize());
+    BBBP_CHECK_HIP(hipMemcpyFromSymbol(phases7, HIP_SYMBOL(g_gemm_b3_phase), 7 * sizeof(unsigned long long)));
     return BBBP_OK;
 }

@@ -263,6 +263,14 @@ int bbbp_set_fused_encoder(int on);
  * registers, no [nhead, B, B] tensors (csrc/attention.hip; default on, initial value BBBP_FLASH_ATTENTION).  0 selects the batched
  * GEMM + softmax schedule.  Changes the workspace layout: set it before the forward call, not between forward and backward. */
 int bbbp_set_flash_attention(int on);
+/* Products that take the 128 x 128 tile plan (the F = 2048 encoder's GEMMs, the 65536-wide image FC): 1 (default; initial value
+ * BBBP_GEMM_SPLIT_BF16) runs them on the bf16 matrix pipe with every float32 operand split into three bf16 pieces (six MFMAs per
+ * k-step, f32 accumulate, float32 accuracy; csrc/gemm.hip: gemm_b3_kernel), 0 on the f32 MFMA.  Returns the previous setting. */
+int bbbp_set_gemm_split_bf16(int on);
+/* Debug: shader cycles of work-group 0 / wave 0 of the last split-bf16 GEMM launched with BBBP_GEMM_B3_PROBE=1 in the environment:
+ * [0] global-load issue, [1] LDS reads + MFMA block, [2] barrier after it, [3] split + LDS writes, [4] barrier after them, [5] all shader
+ * cycles of that wave's K loop and [6] the same span in 100 MHz wall ticks (their ratio is the sustained shader clock). */
+int bbbp_gemm_split_bf16_phases(unsigned long long* phases7);
 int bbbp_set_overlap(int on);   /* two/three-stream branch overlap inside bbbp_mixed_forward/backward (default on) */
 /* Data-parallel overlap: the gradient of the image-FC weight (62 % of all gradient bytes at F = 167) is final after the
  * first GEMM of the image branch's backward.  wait_bucket(stream, 0) makes `stream` wait for exactly that point of the

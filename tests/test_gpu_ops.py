@@ -22,12 +22,25 @@ GEMM_SHAPES = [(512, 501, 167), (512, 167, 167), (512, 2048, 167), (512, 167, 20
                (512, 167, 512), (512, 167, 501), (2048, 167, 512), (40, 24, 16), (40, 24, 32), (40, 24, 33), (3, 5, 700),
                (1024, 1024, 64),
                # short K over > 4 tiles per CU: the 128 x 128 tile with 16-deep stages (the image FC's input gradient)
-               (384, 49152, 128), (512, 33000, 100)]
+               (384, 49152, 128), (512, 33000, 100),
+               # 128 x 128 tiles on the bf16 pipe with split operands: full tiles, ragged M / N, K not a multiple of the 32-deep stage,
+               # split-K over a deep K; (516, 1028, 514): K % 4 != 0 keeps the f32 kernel for the k-contiguous layouts
+               (512, 2048, 2048), (500, 2044, 516), (260, 6144, 2048), (2048, 2048, 512), (516, 1028, 514)]
+
+
+@pytest.fixture(params=[1, 0], ids=["split-bf16", "f32"])
+def gemm_form(request):
+    """Large products (128 x 128 tile plans) run on the bf16 matrix pipe with operands split into three bf16 pieces
+    (bbbp_set_gemm_split_bf16, default on) or on the f32 MFMA."""
+    L = _lib.lib()
+    old = L.bbbp_set_gemm_split_bf16(request.param)
+    yield request.param
+    L.bbbp_set_gemm_split_bf16(old)
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
-def test_gemm_layouts(dev, M, N, K, layout):
+def test_gemm_layouts(dev, M, N, K, layout, gemm_form):
     a = rnd(M, K, seed=M + K); b = rnd(K, N, seed=N + 7)
     want = (a.double() @ b.double())
     scale = (a.abs().double() @ b.abs().double())
