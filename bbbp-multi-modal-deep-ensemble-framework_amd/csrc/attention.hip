@@ -15,6 +15,7 @@
 //             operand.  No atomics: every output element has one owner, results are bit-reproducible.
 #include "common.h"
 #include "bbbp_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -248,6 +249,299 @@ int head_parts(int nhead, int B) {
     return parts < 1 ? 1 : (parts > 16 ? 16 : parts);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// ONE (or a few) WIDE heads: the MACCS width F = 167 is prime, the reference's head rule gives nhead = 1, head_dim = 167 (R:71-73).
+// As separate launches the attention of a layer was QK^T -> softmax(+dropout) -> PV forward and (dV | dPd) -> softmax backward ->
+// (dQ | dK) backward: seven small launches around [B, B] tensors on a latency-bound chain.  Here it is one launch each way.
+//   * operands come STRAIGHT from global memory (L2: Q, K, V, dO of B = 512 are 342 KB each) into the MFMA register layout, as in
+//     gemm.hip's latency path: a row is read as 16-byte quads (lane (i, kq) holds X[row i][16c + 4kq + j]; MFMA j of chunk c then
+//     contracts k = 16c + 4kq + j -- a permutation of the head dimension applied to both operands alike), the transposed operands
+//     (V^T, K^T, Q^T, dO^T) as four consecutive columns of a row (column groups of 64: tile (g, u) row i <-> d = 64g + 4i + u);
+//   * forward: a work-group owns 16 queries, its 8 waves split the key tiles; every wave runs its own online softmax and the
+//     (max, sum, O^T) partials are merged through LDS.  Scores go back into the MFMA as B operand from the registers they were
+//     produced in (rows of the accumulator layout are the contraction index), as in the small-head kernel above;
+//   * backward: blockIdx.z = 0: key-owner sweep (dV^T, dK^T of 16 keys; tiles computed as S = Q K^T so that the contraction
+//     index -- the query -- is the accumulator row); blockIdx.z = 1: query-owner sweep (dQ^T of 16 queries; tiles as S^T).  P is
+//     recomputed from the saved logsumexp; delta = rowsum(dO * O) is recomputed from the operands' own quads.  4 waves per group
+//     split the other index; partials are summed through LDS in wave order.  No atomics, bit-reproducible.
+constexpr int WNC = 11;                 // 16-deep chunks of the head dimension: 160 < head_dim <= 176
+constexpr int WDG = 3;                  // 64-wide column groups: head_dim <= 192
+constexpr int WFW = 8, WBW = 4;         // waves per work-group: forward, backward
+typedef float f32x4w __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ void wide_quads(const float* row, int D, int kq, f32x4 (&v)[WNC]) {
+#pragma unroll
+    for (int c = 0; c < WNC; ++c) {
+        const int k = 16 * c + 4 * kq;
+        if (c < WNC - 1) {
+            const f32x4w x = *reinterpret_cast<const f32x4w*>(row + k);
+            v[c] = f32x4{x[0], x[1], x[2], x[3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float x = row[min(k + j, D - 1)]; v[c][j] = k + j < D ? x : 0.f; }
+        }
+    }
+}
+// columns min(64g + 4i, D - 4) .. + 3 of a row
+__device__ __forceinline__ void wide_cols(const float* row, int D, int i, f32x4 (&v)[WDG]) {
+#pragma unroll
+    for (int g = 0; g < WDG; ++g) {
+        const f32x4w x = *reinterpret_cast<const f32x4w*>(row + min(64 * g + 4 * i, D - 4));
+        v[g] = f32x4{x[0], x[1], x[2], x[3]};
+    }
+}
+// [16 rows of a] x [16 rows of b]^T over the head dimension: lane (col = b row, kq), register r <-> a row 4 kq + r
+__device__ __forceinline__ f32x4 wide_dot(const f32x4 (&a)[WNC], const f32x4 (&b)[WNC]) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < WNC; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[c][j], acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ float wide_sum_kq(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
+__device__ __forceinline__ float wide_dot_rows(const f32x4 (&a)[WNC], const f32x4 (&b)[WNC]) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < WNC; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += a[c][j] * b[c][j];
+    return wide_sum_kq(s);
+}
+// element (group g, sub-tile u, register r) of a transposed accumulator held by lane (col, kq): head-dimension index, or -1 when the
+// slot is a duplicate of a clamped quad / beyond the head dimension
+__device__ __forceinline__ int wide_d_of(int g, int u, int r, int kq, int D) {
+    const int start = 64 * g + 4 * (4 * kq + r);
+    const int d = min(start, D - 4) + u;
+    return (d >= start && d < D) ? d : -1;
+}
+
+__global__ __launch_bounds__(64 * WFW) void attn_wide_fwd_kernel(AttnParams P) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* so = smem;                                   // [WFW][48][64]
+    float* sm = so + WFW * 48 * 64;                     // [WFW][16]
+    float* sl = sm + WFW * 16;                          // [WFW][16]
+    float* sw = sl + WFW * 16;                          // [WFW][16] merge weights; [WFW * 16 ..]: logsumexp of the 16 queries
+    const int B = P.B, F = P.F, D = P.D, ld = 3 * F, h = blockIdx.x, qb = blockIdx.y;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane & 15, kq = lane >> 4;
+    const float* Qb = P.qkv + h * D; const float* Kb = Qb + F; const float* Vb = Qb + 2 * F;
+    const int query = qb * 16 + q;
+    const uint64_t seed = effective_seed(P.seed, P.seed_base);
+    const bool drop = P.p > 0.f;
+    const int ntile = (B + 15) >> 4;
+
+    f32x4 qv[WNC];
+    wide_quads(Qb + (long)min(query, B - 1) * ld, D, kq, qv);
+    float m = -INFINITY, l = 0.f;
+    f32x4 o[WDG][4];
+#pragma unroll
+    for (int g = 0; g < WDG; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o[g][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = wave; kt < ntile; kt += WFW) {
+        f32x4 kv[WNC];
+        wide_quads(Kb + (long)min(kt * 16 + q, B - 1) * ld, D, kq, kv);
+        f32x4 vc[4][WDG];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wide_cols(Vb + (long)min(kt * 16 + 4 * kq + r, B - 1) * ld, D, q, vc[r]);
+        f32x4 s = wide_dot(kv, qv);                     // S^T[key 4 kq + r][query q]
+        float cm = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + 4 * kq + r;
+            s[r] = key < B ? s[r] * P.scale : -INFINITY;
+            cm = fmaxf(cm, s[r]);
+        }
+        cm = fmaxf(cm, __shfl_xor(cm, 16)); cm = fmaxf(cm, __shfl_xor(cm, 32));
+        const float mn = fmaxf(m, cm);
+        const float corr = __expf(m - mn);
+        float ks[4] = {1.f, 1.f, 1.f, 1.f};
+        if (drop) keep4(seed, ((uint64_t)h * B + min(query, B - 1)) * B + kt * 16 + 4 * kq, P.p, P.inv_keep, ks);
+        float ps = 0.f, pd[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float pv = __expf(s[r] - mn); ps += pv; pd[r] = pv * ks[r]; }
+#pragma unroll
+        for (int g = 0; g < WDG; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[g][u] = o[g][u] * corr;
+        // O^T[d][query] += V^T[d][key] Pd^T[key][query]: step r contracts keys 4 kq + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int g = 0; g < WDG; ++g)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) o[g][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc[r][g][u], pd[r], o[g][u], 0, 0, 0);
+        l = l * corr + wide_sum_kq(ps);
+        m = mn;
+    }
+    // ---- merge the waves' partials ----
+#pragma unroll
+    for (int g = 0; g < WDG; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) so[(wave * 48 + (g * 4 + u) * 4 + r) * 64 + lane] = o[g][u][r];
+    if (kq == 0) { sm[wave * 16 + q] = m; sl[wave * 16 + q] = l; }
+    __syncthreads();
+    if (t < 16) {
+        float M = -INFINITY;
+        for (int w = 0; w < WFW; ++w) M = fmaxf(M, sm[w * 16 + t]);
+        float L = 0.f;
+        for (int w = 0; w < WFW; ++w) L += sl[w * 16 + t] * __expf(sm[w * 16 + t] - M);
+        const float inv = 1.f / L;
+        for (int w = 0; w < WFW; ++w) sw[w * 16 + t] = __expf(sm[w * 16 + t] - M) * inv;
+        if (qb * 16 + t < B) P.lse[(long)h * B + qb * 16 + t] = M + __logf(L);
+    }
+    __syncthreads();
+    for (int idx = t; idx < 48 * 64; idx += 64 * WFW) {
+        const int a = idx >> 6, ln = idx & 63, qq = ln & 15, kk = ln >> 4;
+        const int d = wide_d_of(a >> 4, (a >> 2) & 3, a & 3, kk, D);
+        const int qy = qb * 16 + qq;
+        if (d < 0 || qy >= B) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WFW; ++w) v += so[(w * 48 + a) * 64 + ln] * sw[w * 16 + qq];
+        P.ctx[(long)qy * F + h * D + d] = v;
+    }
+}
+
+__device__ __forceinline__ float keep1(uint64_t seed, uint64_t idx, float p, float inv_keep) {
+    const uint4 a = philox4(seed, idx >> 2);
+    const int off = (int)(idx & 3);
+    const uint32_t v = off == 0 ? a.x : off == 1 ? a.y : off == 2 ? a.z : a.w;
+    return ((float)(v >> 8) * (1.0f / 16777216.0f)) >= p ? inv_keep : 0.f;
+}
+
+__global__ __launch_bounds__(64 * WBW) void attn_wide_bwd_kernel(AttnParams P) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];       // [WBW][96][64]
+    const int B = P.B, F = P.F, D = P.D, ld = 3 * F, h = blockIdx.x, own = blockIdx.y;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane & 15, kq = lane >> 4;
+    const float* Qb = P.qkv + h * D; const float* Kb = Qb + F; const float* Vb = Qb + 2 * F;
+    const float* dOb = P.dctx + h * D; const float* Ob = P.ctx + h * D;
+    const uint64_t seed = effective_seed(P.seed, P.seed_base);
+    const bool drop = P.p > 0.f;
+    const int ntile = (B + 15) >> 4;
+    f32x4 acc0[WDG][4], acc1[WDG][4];
+#pragma unroll
+    for (int g = 0; g < WDG; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc0[g][u] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[g][u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    if (blockIdx.z == 0) {
+        // ---- key owner: dV^T[d][key], dK^T[d][key] of keys own * 16 .. + 15; tiles S[query 4 kq + r][key q] ----
+        const int key = own * 16 + q;
+        f32x4 kv[WNC], vv[WNC];
+        wide_quads(Kb + (long)min(key, B - 1) * ld, D, kq, kv);
+        wide_quads(Vb + (long)min(key, B - 1) * ld, D, kq, vv);
+        for (int qt = wave; qt < ntile; qt += WBW) {
+            const int qrow = min(qt * 16 + q, B - 1);
+            f32x4 qa[WNC], doa[WNC];
+            wide_quads(Qb + (long)qrow * ld, D, kq, qa);
+            wide_quads(dOb + (long)qrow * F, D, kq, doa);
+            float delta_i, lse_i;
+            {
+                f32x4 ca[WNC];
+                wide_quads(Ob + (long)qrow * F, D, kq, ca);
+                delta_i = wide_dot_rows(doa, ca);
+                lse_i = qt * 16 + q < B ? P.lse[(long)h * B + qt * 16 + q] : INFINITY;
+            }
+            const f32x4 s = wide_dot(qa, kv);
+            const f32x4 dp = wide_dot(doa, vv);
+            float pd[4], ds[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qy = qt * 16 + 4 * kq + r;
+                const float dl = __shfl(delta_i, 4 * kq + r), L = __shfl(lse_i, 4 * kq + r);
+                const float keep = drop ? keep1(seed, ((uint64_t)h * B + min(qy, B - 1)) * B + min(key, B - 1), P.p, P.inv_keep) : 1.f;
+                const float pv = key < B ? __expf(s[r] * P.scale - L) : 0.f;
+                pd[r] = pv * keep;
+                ds[r] = pv * (dp[r] * keep - dl) * P.scale;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qy = min(qt * 16 + 4 * kq + r, B - 1);
+                f32x4 doc[WDG], qc[WDG];
+                wide_cols(dOb + (long)qy * F, D, q, doc);
+                wide_cols(Qb + (long)qy * ld, D, q, qc);
+#pragma unroll
+                for (int g = 0; g < WDG; ++g)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        acc0[g][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(doc[g][u], pd[r], acc0[g][u], 0, 0, 0);
+                        acc1[g][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc[g][u], ds[r], acc1[g][u], 0, 0, 0);
+                    }
+            }
+        }
+    } else {
+        // ---- query owner: dQ^T[d][query] of queries own * 16 .. + 15; tiles S^T[key 4 kq + r][query q] ----
+        const int query = own * 16 + q;
+        const int qrow = min(query, B - 1);
+        f32x4 qv[WNC], dov[WNC];
+        wide_quads(Qb + (long)qrow * ld, D, kq, qv);
+        wide_quads(dOb + (long)qrow * F, D, kq, dov);
+        float delta;
+        {
+            f32x4 cv[WNC];
+            wide_quads(Ob + (long)qrow * F, D, kq, cv);
+            delta = wide_dot_rows(dov, cv);
+        }
+        const float L = query < B ? P.lse[(long)h * B + query] : INFINITY;
+        for (int kt = wave; kt < ntile; kt += WBW) {
+            const int krow = min(kt * 16 + q, B - 1);
+            f32x4 ka[WNC], va[WNC];
+            wide_quads(Kb + (long)krow * ld, D, kq, ka);
+            wide_quads(Vb + (long)krow * ld, D, kq, va);
+            const f32x4 s = wide_dot(ka, qv);
+            const f32x4 dp = wide_dot(va, dov);
+            float ks[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop) keep4(seed, ((uint64_t)h * B + qrow) * B + kt * 16 + 4 * kq, P.p, P.inv_keep, ks);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + 4 * kq + r;
+                const float pv = key < B ? __expf(s[r] * P.scale - L) : 0.f;
+                const float ds = pv * (dp[r] * ks[r] - delta) * P.scale;
+                f32x4 kc[WDG];
+                wide_cols(Kb + (long)min(key, B - 1) * ld, D, q, kc);
+#pragma unroll
+                for (int g = 0; g < WDG; ++g)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc0[g][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[g][u], ds, acc0[g][u], 0, 0, 0);
+            }
+        }
+    }
+    // ---- sum the waves' partials in wave order ----
+    const int nacc = blockIdx.z == 0 ? 96 : 48;
+#pragma unroll
+    for (int g = 0; g < WDG; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                smem[(wave * 96 + (g * 4 + u) * 4 + r) * 64 + lane] = acc0[g][u][r];
+                if (blockIdx.z == 0) smem[(wave * 96 + 48 + (g * 4 + u) * 4 + r) * 64 + lane] = acc1[g][u][r];
+            }
+    __syncthreads();
+    for (int idx = t; idx < nacc * 64; idx += 64 * WBW) {
+        const int a = idx >> 6, ln = idx & 63, cc = ln & 15, kk = ln >> 4, a48 = a % 48;
+        const int d = wide_d_of(a48 >> 4, (a48 >> 2) & 3, a48 & 3, kk, D);
+        const int row = own * 16 + cc;                  // key (sweep A) or query (sweep B)
+        if (d < 0 || row >= B) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WBW; ++w) v += smem[(w * 96 + a) * 64 + ln];
+        // sweep A: a < 48 -> dV (third block of dqkv), else dK (second); sweep B: dQ (first)
+        const int blk = blockIdx.z == 0 ? (a < 48 ? 2 : 1) : 0;
+        P.dqkv[(long)row * ld + blk * F + h * D + d] = v;
+    }
+}
+
+constexpr size_t WIDE_FWD_LDS = (size_t)(WFW * 48 * 64 + 4 * WFW * 16) * sizeof(float);
+constexpr size_t WIDE_BWD_LDS = (size_t)(WBW * 96 * 64) * sizeof(float);
+bool wide_supported(int B, int nhead, int head_dim) {
+    return nhead >= 1 && nhead <= 8 && head_dim > 16 * (WNC - 1) && head_dim <= 16 * WNC && B >= 1 && (B + 15) / 16 <= 65535;
+}
+
 template <class K>
 int set_dyn_lds(K kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return BBBP_OK;
@@ -258,14 +552,25 @@ int set_dyn_lds(K kernel, size_t bytes) {
 }  // namespace
 
 // The fused path serves head_dim 8 and 16 whenever one head's K, V, Q, dO fit in LDS (B <= 1024 at head_dim 8).
-bool bbbp_attn_small_supported(int B, int nhead, int head_dim) {
+static bool small_supported(int B, int nhead, int head_dim) {
     return nhead > 1 && (head_dim == 8 || head_dim == 16) && B >= 1 && bwd_lds(B, head_dim) <= LDS_MAX;
 }
+bool bbbp_attn_small_supported(int B, int nhead, int head_dim) { return small_supported(B, nhead, head_dim); }
+// ... and one (or a few) wide heads of 161 .. 176 columns (the MACCS width 167 with the reference's nhead = 1) on attn_wide_*; opt-in
+// (bbbp_set_flash_attention bit 1): measured at B = 512 the two launches take 28 / 62 us alone against ~18 / ~30 us for the seven
+// latency-path launches they replace, because 32 work-groups cannot use more than 32 CUs' matrix pipes.
+bool bbbp_attn_wide_supported(int B, int nhead, int head_dim) { return wide_supported(B, nhead, head_dim); }
 
 int bbbp_attn_small_fwd(hipStream_t st, const float* qkv, float* ctx, float* lse, int B, int F, int nhead, float scale, float p, uint64_t seed) {
     const int D = F / nhead;
-    BBBP_CHECK_ARG(bbbp_attn_small_supported(B, nhead, D), "attn_small: B=%d nhead=%d head_dim=%d not supported", B, nhead, D);
+    BBBP_CHECK_ARG(small_supported(B, nhead, D) || wide_supported(B, nhead, D), "attn_small: B=%d nhead=%d head_dim=%d not supported", B, nhead, D);
     AttnParams P{qkv, ctx, lse, nullptr, nullptr, B, F, nhead, D, scale, p, p > 0.f ? 1.f / (1.f - p) : 1.f, seed, g_bbbp_seed_base};
+    if (!small_supported(B, nhead, D)) {
+        int rc = set_dyn_lds(attn_wide_fwd_kernel, WIDE_FWD_LDS); if (rc) return rc;
+        hipLaunchKernelGGL(attn_wide_fwd_kernel, dim3(nhead, (B + 15) / 16), dim3(64 * WFW), WIDE_FWD_LDS, st, P);
+        BBBP_CHECK_LAUNCH();
+        return BBBP_OK;
+    }
     const size_t lds = fwd_lds(B, D);
     if (D == 8) { int rc = set_dyn_lds(attn_small_fwd_kernel<2>, lds); if (rc) return rc; hipLaunchKernelGGL(attn_small_fwd_kernel<2>, dim3(nhead, head_parts(nhead, B)), dim3(NTH), lds, st, P); }
     else { int rc = set_dyn_lds(attn_small_fwd_kernel<4>, lds); if (rc) return rc; hipLaunchKernelGGL(attn_small_fwd_kernel<4>, dim3(nhead, head_parts(nhead, B)), dim3(NTH), lds, st, P); }
@@ -276,9 +581,15 @@ int bbbp_attn_small_fwd(hipStream_t st, const float* qkv, float* ctx, float* lse
 int bbbp_attn_small_bwd(hipStream_t st, const float* qkv, const float* ctx, const float* lse, const float* dctx, float* dqkv, int B, int F,
                         int nhead, float scale, float p, uint64_t seed) {
     const int D = F / nhead;
-    BBBP_CHECK_ARG(bbbp_attn_small_supported(B, nhead, D), "attn_small: B=%d nhead=%d head_dim=%d not supported", B, nhead, D);
+    BBBP_CHECK_ARG(small_supported(B, nhead, D) || wide_supported(B, nhead, D), "attn_small: B=%d nhead=%d head_dim=%d not supported", B, nhead, D);
     AttnParams P{qkv, const_cast<float*>(ctx), const_cast<float*>(lse), dctx, dqkv, B, F, nhead, D, scale, p, p > 0.f ? 1.f / (1.f - p) : 1.f, seed,
                  g_bbbp_seed_base};
+    if (!small_supported(B, nhead, D)) {
+        int rc = set_dyn_lds(attn_wide_bwd_kernel, WIDE_BWD_LDS); if (rc) return rc;
+        hipLaunchKernelGGL(attn_wide_bwd_kernel, dim3(nhead, (B + 15) / 16, 2), dim3(64 * WBW), WIDE_BWD_LDS, st, P);
+        BBBP_CHECK_LAUNCH();
+        return BBBP_OK;
+    }
     const size_t lds = bwd_lds(B, D);
     if (D == 8) { int rc = set_dyn_lds(attn_small_bwd_kernel<2>, lds); if (rc) return rc; hipLaunchKernelGGL(attn_small_bwd_kernel<2>, dim3(nhead, head_parts(nhead, B)), dim3(NTH), lds, st, P); }
     else { int rc = set_dyn_lds(attn_small_bwd_kernel<4>, lds); if (rc) return rc; hipLaunchKernelGGL(attn_small_bwd_kernel<4>, dim3(nhead, head_parts(nhead, B)), dim3(NTH), lds, st, P); }

@@ -82,6 +82,7 @@ int bbbp_ln_param_grad_multi(hipStream_t st, int n, const float* const* dy, cons
                              const float* const* rstd, float* const* dgamma, float* const* dbeta, int rows, int cols);
 // attention.hip: fused (flash-style) self-attention for many heads of head_dim 8 / 16, one work-group per head
 bool bbbp_attn_small_supported(int B, int nhead, int head_dim);
+bool bbbp_attn_wide_supported(int B, int nhead, int head_dim);      // one wide head (161..176 columns): opt-in, see attention.hip
 int bbbp_attn_small_fwd(hipStream_t st, const float* qkv, float* ctx, float* lse, int B, int F, int nhead, float scale, float p, uint64_t seed);
 int bbbp_attn_small_bwd(hipStream_t st, const float* qkv, const float* ctx, const float* lse, const float* dctx, float* dqkv, int B, int F,
                         int nhead, float scale, float p, uint64_t seed);
@@ -120,15 +121,17 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // clang vectors stay in registers; arrays of HIP's uint4 struct were demoted to scratch
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-// hi / mid / lo of two floats, packed pairwise (a in the low half)
+// hi / mid / lo of two floats, packed pairwise (a in the low half).  The residuals are formed with packed-f32 subtractions.
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
     f32x2v v = {a, b};
     bf16x2 h = __builtin_convertvector(v, bf16x2);
     hi = __builtin_bit_cast(uint32_t, h);
-    v[0] -= __builtin_bit_cast(float, hi << 16); v[1] -= __builtin_bit_cast(float, hi & 0xffff0000u);
+    f32x2v hf = {__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+    v = v - hf;
     bf16x2 m = __builtin_convertvector(v, bf16x2);
     mid = __builtin_bit_cast(uint32_t, m);
-    v[0] -= __builtin_bit_cast(float, mid << 16); v[1] -= __builtin_bit_cast(float, mid & 0xffff0000u);
+    f32x2v mf = {__builtin_bit_cast(float, mid << 16), __builtin_bit_cast(float, mid & 0xffff0000u)};
+    v = v - mf;
     bf16x2 l = __builtin_convertvector(v, bf16x2);
     lo = __builtin_bit_cast(uint32_t, l);
 }

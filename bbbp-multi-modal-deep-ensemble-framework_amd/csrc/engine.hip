@@ -91,8 +91,9 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     p->B = d->batch; p->F = d->fingerprint_size; p->NH = d->nhead; p->D = p->F / p->NH; p->L = d->num_layers;
     p->DFF = d->dim_feedforward;
     p->drop = d->training && d->dropout_p > 0.f;
-    if (g_flash_attention < 0) { const char* e = getenv("BBBP_FLASH_ATTENTION"); g_flash_attention = e ? atoi(e) != 0 : 1; }
-    p->flash = g_flash_attention == 1 && p->L > 0 && bbbp_attn_small_supported(p->B, p->NH, p->D);
+    if (g_flash_attention < 0) { const char* e = getenv("BBBP_FLASH_ATTENTION"); g_flash_attention = e ? atoi(e) & 3 : 1; }
+    p->flash = p->L > 0 && (((g_flash_attention & 1) && bbbp_attn_small_supported(p->B, p->NH, p->D)) ||
+                            ((g_flash_attention & 2) && bbbp_attn_wide_supported(p->B, p->NH, p->D)));
     const size_t B = p->B, F = p->F, NH = p->NH, DFF = p->DFF;
     Bump b;
     p->seed_slot = b.take(256);
@@ -431,8 +432,9 @@ extern "C" int bbbp_set_fused_encoder(int on) {
 }
 
 extern "C" int bbbp_set_flash_attention(int on) {
-    const int prev = g_flash_attention != 0 ? 1 : 0;
-    g_flash_attention = on ? 1 : 0;
+    if (g_flash_attention < 0) { const char* e = getenv("BBBP_FLASH_ATTENTION"); g_flash_attention = e ? atoi(e) & 3 : 1; }
+    const int prev = g_flash_attention;
+    g_flash_attention = on & 3;
     return prev;
 }
 

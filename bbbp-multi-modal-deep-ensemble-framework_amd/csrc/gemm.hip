@@ -272,12 +272,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 // into LDS and a k-step of 16 is six v_mfma_f32_32x32x16_bf16 per 32 x 32 tile -- float32 accuracy (the dropped piece products are
 // below 2^-24 of the product) at 2.67x the rate of v_mfma_f32_32x32x2_f32.  Same GemmParams, grid, split-K slabs and epilogue as
 // gemm_f32_kernel<128, 128>.
-//   * LDS: [operand 2][plane 3][row 128][32 k + 8] bf16 = 60 KB, ONE stage (the next stage waits in registers as float32), so two
-//     work-groups share a CU and one group's split + store phase runs under the other's MFMA block;
+//   * LDS: [operand 2][plane 3][row 128][32 k + 8] bf16 = 60 KB, ONE stage, so two work-groups share a CU;
+//   * the global loads of stage s + 2 are issued at the top of stage s (two float32 register sets), the split of stage s + 1 into its
+//     bf16 pieces is INTERLEAVED with the MFMAs of stage s (the bf16 MFMA leaves the vector ALU free for 24 of its 32 cycles) and waits
+//     in registers; between two barriers only the 24 ds_write_b64 remain;
 //   * both tiles are row-major in k: the operand of lane (r, h) -- row r, k = 8h .. 8h+7 -- is one ds_read_b128, conflict-free at the
 //     80-byte row stride; a k-major global tile ([K][M]) is transposed in registers: a thread loads a 4 (k) x 4 (m) block with four
-//     16-byte loads and writes four 8-byte k-quads per plane (lane = k-quad + 8 * row-quad: conflict-free as well);
-//   * needs K % 4 == 0 (k-contiguous operand) / extent % 4 == 0 (k-major operand); anything else keeps the f32 kernel.
+//     16-byte loads and writes four 8-byte k-quads per plane.  The rows a half-wave writes are 4 apart (80 * 4 bytes = 16 banks): no
+//     bank conflicts on the way in either;
+//   * needs K % 32 == 0 (no K tail: no selects in the split) and extent % 4 == 0 for a k-major operand; anything else keeps the f32 kernel.
 constexpr int B3_BK = 32;
 constexpr int B3_LD = B3_BK + 8;
 constexpr int B3_PLANE = 128 * B3_LD;
@@ -285,60 +288,58 @@ constexpr size_t B3_LDS = (size_t)6 * B3_PLANE * sizeof(uint16_t);
 
 template <bool KMAJ>
 struct B3Loader {
-    const float* X; int ld, extent, row0;
-    f32x4u v[4];
-    // thread (kq = t & 7, rq = t >> 3): k-contiguous: rows rq + 32 i, k = k0 + 4 kq ..+3;  k-major: k = k0 + 4 kq + j, rows 4 rq ..+3
-    __device__ __forceinline__ void load(int t, int k0, int kbeg, int kend) {
+    const float* ptr[4];     // this thread's four 16-byte loads of the next stage to fetch
+    long step;               // pointer advance per stage
+    int soff[4];             // LDS offsets (bf16 elements) of its four k-quads
+    f32x4u raw[2][4];
+    u32x2 pk[4][3];
+    // thread (kq = t & 7, rq = t >> 3): k-contiguous operand: rows row(rq) + 32 i, k = 4 kq ..+3;  k-major: k = 4 kq + j, rows 4 rq ..+3
+    __device__ __forceinline__ void init(const float* X, int ld, int extent, int row0, int kbeg, int t) {
         const int kq = t & 7, rq = t >> 3;
         if constexpr (KMAJ) {
             const int col = min(row0 + 4 * rq, extent - 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = k0 + 4 * kq + j;
-                v[j] = *reinterpret_cast<const f32x4u*>(X + (long)(k < kend ? k : kbeg) * ld + col);
-            }
+            for (int j = 0; j < 4; ++j) { ptr[j] = X + (long)(kbeg + 4 * kq + j) * ld + col; soff[j] = (4 * rq + j) * B3_LD + 4 * kq; }
+            step = (long)B3_BK * ld;
         } else {
-            const int k = k0 + 4 * kq;
-            const int kk = k < kend ? k : kbeg;
+            const int a = rq & 3, b = rq >> 2;
+            const int row = (b >> 2) * 16 + (b & 3) + 4 * a;          // the four rows of a half-wave are 4 apart
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                v[i] = *reinterpret_cast<const f32x4u*>(X + (long)min(row0 + rq + 32 * i, extent - 1) * ld + kk);
+            for (int i = 0; i < 4; ++i) {
+                ptr[i] = X + (long)min(row0 + row + 32 * i, extent - 1) * ld + kbeg + 4 * kq;
+                soff[i] = (row + 32 * i) * B3_LD + 4 * kq;
+            }
+            step = B3_BK;
         }
     }
-    __device__ __forceinline__ void store(uint16_t* dst, int t, int k0, int kend) const {
-        const int kq = t & 7, rq = t >> 3;
-        if constexpr (KMAJ) {
-            bool ok[4];
+    __device__ __forceinline__ void load(int set) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ok[j] = k0 + 4 * kq + j < kend;
+        for (int i = 0; i < 4; ++i) { raw[set][i] = *reinterpret_cast<const f32x4u*>(ptr[i]); ptr[i] += step; }
+    }
+    __device__ __forceinline__ void split(int set) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint32_t h0, m0, l0, h1, m1, l1;
-                split2(ok[0] ? v[0][i] : 0.f, ok[1] ? v[1][i] : 0.f, h0, m0, l0);
-                split2(ok[2] ? v[2][i] : 0.f, ok[3] ? v[3][i] : 0.f, h1, m1, l1);
-                uint16_t* d = dst + (4 * rq + i) * B3_LD + 4 * kq;
-                *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
-                *reinterpret_cast<u32x2*>(d + B3_PLANE) = u32x2{m0, m1};
-                *reinterpret_cast<u32x2*>(d + 2 * B3_PLANE) = u32x2{l0, l1};
+        for (int i = 0; i < 4; ++i) {
+            uint32_t h0, m0, l0, h1, m1, l1;
+            if constexpr (KMAJ) {
+                split2(raw[set][0][i], raw[set][1][i], h0, m0, l0);
+                split2(raw[set][2][i], raw[set][3][i], h1, m1, l1);
+            } else {
+                split2(raw[set][i][0], raw[set][i][1], h0, m0, l0);
+                split2(raw[set][i][2], raw[set][i][3], h1, m1, l1);
             }
-        } else {
-            const bool ok = k0 + 4 * kq < kend;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint32_t h0, m0, l0, h1, m1, l1;
-                split2(ok ? v[i][0] : 0.f, ok ? v[i][1] : 0.f, h0, m0, l0);
-                split2(ok ? v[i][2] : 0.f, ok ? v[i][3] : 0.f, h1, m1, l1);
-                uint16_t* d = dst + (rq + 32 * i) * B3_LD + 4 * kq;
-                *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
-                *reinterpret_cast<u32x2*>(d + B3_PLANE) = u32x2{m0, m1};
-                *reinterpret_cast<u32x2*>(d + 2 * B3_PLANE) = u32x2{l0, l1};
-            }
+            pk[i][0] = u32x2{h0, h1}; pk[i][1] = u32x2{m0, m1}; pk[i][2] = u32x2{l0, l1};
         }
+    }
+    __device__ __forceinline__ void store(uint16_t* dst) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x2*>(dst + soff[i] + pl * B3_PLANE) = pk[i][pl];
     }
 };
 
 // phase breakdown of work-group 0 / wave 0 of the last probed launch (BBBP_GEMM_B3_PROBE=1; tools/bench_gemm_forms.py prints it): shader
-// cycles in [0] global-load issue, [1] LDS reads + MFMA block, [2] barrier after the MFMAs, [3] split + LDS writes, [4] barrier after them
+// cycles in [0] global-load issue, [1] LDS reads + MFMA block + split, [2] barrier after it, [3] LDS writes, [4] barrier after them
 __device__ unsigned long long g_gemm_b3_phase[7];      // [5] all shader cycles of the wave, [6] the same span in 100 MHz wall ticks
 
 template <int LAYOUT, bool PROBE>
@@ -356,9 +357,12 @@ __device__ __forceinline__ void gemm_b3_body(const GemmParams& p) {
     const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
     const int kbeg = split * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
+    const int nt = (kend - kbeg) / B3_BK;                 // K % 32 == 0 and kchunk % 32 == 0: whole stages only
 
-    B3Loader<A_KMAJ> la{p.A + (long)batch * p.sA, p.lda, p.M, m0};
-    B3Loader<B_KMAJ> lb{p.B + (long)batch * p.sB, p.ldb, p.N, n0};
+    B3Loader<A_KMAJ> la;
+    B3Loader<B_KMAJ> lb;
+    la.init(p.A + (long)batch * p.sA, p.lda, p.M, m0, kbeg, t);
+    lb.init(p.B + (long)batch * p.sB, p.ldb, p.N, n0, kbeg, t);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -368,46 +372,60 @@ __device__ __forceinline__ void gemm_b3_body(const GemmParams& p) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    const int nt = (kend - kbeg + B3_BK - 1) / B3_BK;
     if (nt > 0) {
-        la.load(t, kbeg, kbeg, kend); lb.load(t, kbeg, kbeg, kend);
-        la.store(As, t, kbeg, kend); lb.store(Bs, t, kbeg, kend);
+        la.load(0); lb.load(0);
+        if (nt > 1) { la.load(1); lb.load(1); }
+        la.split(0); lb.split(0);
+        la.store(As); lb.store(Bs);
     }
     __syncthreads();
     const uint16_t* afrag = As + (wm * 64 + r) * B3_LD + 8 * h;
     const uint16_t* bfrag = Bs + (wn * 64 + r) * B3_LD + 8 * h;
-    for (int it = 0; it < nt; ++it) {
-        const int knext = kbeg + (it + 1) * B3_BK;
-        if (PROBE) c0 = __builtin_readcyclecounter();
-        if (it + 1 < nt) { la.load(t, knext, kbeg, kend); lb.load(t, knext, kbeg, kend); }
-        if (PROBE) { const unsigned long long c = __builtin_readcyclecounter(); ph[0] += c - c0; c0 = c; }
+    for (int it = 0; it < nt; it += 2) {
 #pragma unroll
-        for (int kk = 0; kk < B3_BK / 16; ++kk) {
-            bf16x8 a[2][3], b[2][3];
+        for (int u = 0; u < 2; ++u) {
+            const int cur = it + u;
+            if (cur >= nt) break;
+            if (PROBE) c0 = __builtin_readcyclecounter();
+            // float32 set u held stage `cur` (split one stage ago): refill it with stage cur + 2
+            if (cur + 2 < nt) { la.load(u); lb.load(u); }
+            if (PROBE) { const unsigned long long c = __builtin_readcyclecounter(); ph[0] += c - c0; c0 = c; }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    a[i][pl] = *reinterpret_cast<const bf16x8*>(afrag + pl * B3_PLANE + i * 32 * B3_LD + kk * 16);
-                    b[i][pl] = *reinterpret_cast<const bf16x8*>(bfrag + pl * B3_PLANE + i * 32 * B3_LD + kk * 16);
-                }
-            // smallest piece products first; the four tiles interleaved so that consecutive MFMAs are independent
-            constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
+            for (int kk = 0; kk < B3_BK / 16; ++kk) {
+                bf16x8 a[2][3], b[2][3];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+                    for (int pl = 0; pl < 3; ++pl) {
+                        a[i][pl] = *reinterpret_cast<const bf16x8*>(afrag + pl * B3_PLANE + i * 32 * B3_LD + kk * 16);
+                        b[i][pl] = *reinterpret_cast<const bf16x8*>(bfrag + pl * B3_PLANE + i * 32 * B3_LD + kk * 16);
+                    }
+                // smallest piece products first; the four tiles interleaved so that consecutive MFMAs are independent
+                constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+            }
+            // stage cur + 1 (float32 set u ^ 1, loaded a whole stage ago) -> bf16 pieces, in registers; unconditional so that it stays in
+            // the MFMAs' basic block (after the last stage it chews on stale registers)
+            la.split(u ^ 1); lb.split(u ^ 1);
+#pragma unroll
+            for (int g = 0; g < 48; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA ...
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // ... three VALU instructions of the split under it
+            }
+            if (PROBE) { const unsigned long long c = __builtin_readcyclecounter(); ph[1] += c - c0; c0 = c; }
+            __syncthreads();                         // every wave is done reading this stage
+            if (PROBE) { const unsigned long long c = __builtin_readcyclecounter(); ph[2] += c - c0; c0 = c; }
+            if (cur + 1 < nt) { la.store(As); lb.store(Bs); }
+            if (PROBE) { const unsigned long long c = __builtin_readcyclecounter(); ph[3] += c - c0; c0 = c; }
+            __syncthreads();
+            if (PROBE) { const unsigned long long c = __builtin_readcyclecounter(); ph[4] += c - c0; c0 = c; }
         }
-        if (PROBE) { const unsigned long long c = __builtin_readcyclecounter(); ph[1] += c - c0; c0 = c; }
-        __syncthreads();                         // every wave is done reading this stage
-        if (PROBE) { const unsigned long long c = __builtin_readcyclecounter(); ph[2] += c - c0; c0 = c; }
-        if (it + 1 < nt) { la.store(As, t, knext, kend); lb.store(Bs, t, knext, kend); }
-        if (PROBE) { const unsigned long long c = __builtin_readcyclecounter(); ph[3] += c - c0; c0 = c; }
-        __syncthreads();
-        if (PROBE) { const unsigned long long c = __builtin_readcyclecounter(); ph[4] += c - c0; c0 = c; }
     }
     if (PROBE && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && t == 0) {
 #pragma unroll
@@ -844,9 +862,9 @@ int gemm_b3_on() {
 }
 // the split-bf16 form serves 128 x 128 plans whose operands can be read in aligned-extent quads
 bool b3_eligible(const GemmParams& p, int layout) {
-    if (!gemm_b3_on() || p.K < 32) return false;
-    const bool a_ok = layout == 2 ? (p.M % 4 == 0 && p.M >= 4) : (p.K % 4 == 0);
-    const bool b_ok = layout == 0 ? (p.K % 4 == 0) : (p.N % 4 == 0 && p.N >= 4);
+    if (!gemm_b3_on() || p.K < 32 || p.K % 32 != 0) return false;
+    const bool a_ok = layout != 2 || (p.M % 4 == 0 && p.M >= 4);
+    const bool b_ok = layout == 0 || (p.N % 4 == 0 && p.N >= 4);
     return a_ok && b_ok;
 }
 template <int LAYOUT>

@@ -259,9 +259,12 @@ int bbbp_set_fused_head_bwd(int on);
  * out_proj input gradient backward) as ONE launch each (csrc/encoder.hip) instead of 6 + 6, for d_model <= 192 (default OFF:
  * measured slower, see csrc/engine.hip; initial value BBBP_FUSED_ENCODER).  Returns the previous setting.  Both schedules fill the same workspace. */
 int bbbp_set_fused_encoder(int on);
-/* Many heads of head_dim 8 / 16 (F = 2048: 256 x 8): fused flash-style self-attention, one work-group per head, scores in
- * registers, no [nhead, B, B] tensors (csrc/attention.hip; default on, initial value BBBP_FLASH_ATTENTION).  0 selects the batched
- * GEMM + softmax schedule.  Changes the workspace layout: set it before the forward call, not between forward and backward. */
+/* Fused flash-style self-attention (csrc/attention.hip), a bit mask (default 1, initial value BBBP_FLASH_ATTENTION):
+ * bit 0: many heads of head_dim 8 / 16 (F = 2048: 256 x 8), one work-group per head, scores in registers, no [nhead, B, B] tensors;
+ * bit 1: one wide head of 161 .. 176 columns (F = 167, nhead = 1), operands straight from global memory -- correct but measured
+ *        slower than the batched-GEMM + softmax schedule at B = 512, hence opt-in.
+ * 0 selects the batched GEMM + softmax schedule everywhere.  Returns the previous mask.  Changes the workspace layout: set it
+ * before the forward call, not between forward and backward. */
 int bbbp_set_flash_attention(int on);
 /* Products that take the 128 x 128 tile plan (the F = 2048 encoder's GEMMs, the 65536-wide image FC): 1 (default; initial value
  * BBBP_GEMM_SPLIT_BF16) runs them on the bf16 matrix pipe with every float32 operand split into three bf16 pieces (six MFMAs per

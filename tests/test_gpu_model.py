@@ -404,9 +404,11 @@ def test_fused_encoder_rows_match_the_launch_per_op_schedule(dev, F, B, training
             assert rel <= 2e-3 and float((g0[k] - g1[k]).abs().max()) <= 5e-2 * float(g0[k].abs().max()), (k, rel)
 
 
-@pytest.mark.parametrize("F,B,training", [(64, 37, True), (128, 16, True), (64, 512, True), (2048, 24, True), (128, 33, False)])
+@pytest.mark.parametrize("F,B,training", [(64, 37, True), (128, 16, True), (64, 512, True), (2048, 24, True), (128, 33, False),
+                                          (167, 37, True), (167, 7, True), (167, 512, True), (167, 130, False)])
 def test_fused_small_head_attention_matches_materialised_attention(dev, F, B, training):
-    """csrc/attention.hip (one work-group per head, scores in registers, logsumexp saved, P recomputed in backward) against the
+    """csrc/attention.hip (one work-group per head, scores in registers, logsumexp saved, P recomputed in backward; F = 167: the single
+    167-wide head of the MACCS encoder on the attn_wide kernels, operands straight from global memory) against the
     batched-GEMM + softmax schedule with materialised probabilities that round 1 validated, dropout ON: both draw the attention
     dropout mask from the same Philox stream, so outputs and all gradients agree to rounding (ragged last tile, nhead 8 / 16 /
     256, eval-mode BatchNorm)."""
@@ -415,7 +417,7 @@ def test_fused_small_head_attention_matches_materialised_attention(dev, F, B, tr
     fp, img, y = synth_inputs(700 + B, B, F, 49152)
     m = build(F, 29, dev).train(training)
     res = []
-    for flash in (0, 1):
+    for flash in (0, 3):                # 3: small-head kernels and the opt-in wide-head kernels
         old = L.bbbp_set_flash_attention(flash)
         try:
             m.zero_grad(set_to_none=True)
