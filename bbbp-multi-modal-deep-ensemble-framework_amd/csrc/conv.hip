@@ -830,7 +830,7 @@ extern "C" int bbbp_conv_winograd_phases(unsigned long long* phases4) {
 // workspace: prepped weights (fwd / dgrad) or partial slabs (wgrad)
 extern "C" int bbbp_conv_last_clock(unsigned long long* shader_cycles, unsigned long long* ticks_100mhz) {
     BBBP_CHECK_ARG(shader_cycles && ticks_100mhz, "conv_last_clock: null pointer");
-    if (g_last_clock_wino == 2) { *shader_cycles = 0; *ticks_100mhz = 0; return BBBP_OK; }
+    if (g_last_clock_wino == 2) return bbbp_b3_last_clock(shader_cycles, ticks_100mhz);
     if (g_last_clock_wino) return bbbp_wino_last_clock(shader_cycles, ticks_100mhz);
     unsigned long long h[2] = {0, 0};
     BBBP_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_conv_clock), sizeof(h)));
@@ -862,7 +862,7 @@ extern "C" int bbbp_conv3x3_relu_pool_fwd(void* stream, const float* x, const fl
     g_last_clock_wino = 0;
     if (cin == 32 && cout == 64 && (winograd_mask() & 4)) {
         BBBP_CHECK_ARG(workspace_bytes >= bbbp_b3_workspace_bytes(), "conv fwd: workspace too small");
-        g_last_clock_wino = 2;               // no clock stamps in the split-bf16 kernels
+        g_last_clock_wino = 2;               // split-bf16 kernel: its own stamps (conv_b3.hip)
         return bbbp_b3_conv2_fwd(st, x, w, bias, y, mask, B, workspace);
     }
     if (cin == 32 && cout == 64 && (winograd_mask() & 1)) {

@@ -74,6 +74,9 @@ __global__ void b3_prep_kernel(const float* __restrict__ w, uint16_t* __restrict
 // phase breakdown of work-group 0 / wave 0 (BBBP_B3_PROBE=1 selects the stamping instantiation; tools/bench_conv2.py prints it): shader
 // cycles in [0] global-load issue, [1] MFMA block of a stage, [2] split + LDS writes + barriers, [3] epilogue
 __device__ unsigned long long g_b3_phase[4];
+// shader cycles and 100 MHz wall ticks work-group 0 of the last forward / data-gradient launch spent (bbbp_conv_last_clock): their
+// ratio is the clock the chip sustains under this kernel -- ~1.9 GHz for bf16 MFMA loops on real data, not the 2.4 GHz of the spec
+__device__ unsigned long long g_b3_clock[2];
 
 template <int MODE, bool PROBE>
 __device__ __forceinline__ void conv_b3_body(const B3Params& p) {
@@ -85,6 +88,7 @@ __device__ __forceinline__ void conv_b3_body(const B3Params& p) {
     uint16_t* Xs = smem;                                     // [plane 3][row][px][16]
     uint16_t* Ws = smem + XBUF;                              // [WSTAGE]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    const unsigned long long clk_begin = __builtin_readcyclecounter(), wall_begin = wall_clock64();
 
     // the produced-channel block is fixed per work-group; blocks of one strip sit on one XCD (ids w and w + 8: common.h)
     const bool pairs = NMB == 2 && (gridDim.x & 15) == 0;
@@ -281,6 +285,7 @@ __device__ __forceinline__ void conv_b3_body(const B3Params& p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) g_b3_phase[k] = ph[k];
     }
+    if (blockIdx.x == 0 && t == 0) { g_b3_clock[0] = __builtin_readcyclecounter() - clk_begin; g_b3_clock[1] = wall_clock64() - wall_begin; }
 }
 
 template <int MODE>
@@ -738,5 +743,12 @@ int bbbp_b3_conv1_wgrad(hipStream_t st, const float* x, const float* gy, const u
     B3Wgrad3Params p{x, gy, mask, slab, bslab, B};
     hipLaunchKernelGGL(conv_b3_wgrad3_kernel, dim3(grid), dim3(256), WG3_LDS_BYTES, st, p);
     BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+int bbbp_b3_last_clock(unsigned long long* shader_cycles, unsigned long long* ticks_100mhz) {
+    unsigned long long h[2] = {0, 0};
+    BBBP_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_b3_clock), sizeof(h)));
+    *shader_cycles = h[0]; *ticks_100mhz = h[1];
     return BBBP_OK;
 }

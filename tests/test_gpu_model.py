@@ -190,13 +190,15 @@ def test_headline_batch_properties(dev):
     assert_close(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol_frac=2e-5, what="sub-batch vs oracle")
 
 
-def test_morgan_width_2048_against_oracle(dev):
-    """BASELINE config 4 width: F = 2048 => nhead 256, head_dim 8 (batched K = 8 attention GEMMs), 160 M parameters."""
+@pytest.mark.parametrize("B", [6, 64])
+def test_morgan_width_2048_against_oracle(dev, B):
+    """BASELINE config 4 width: F = 2048 => nhead 256, head_dim 8 (fused small-head attention), 160 M parameters.  B = 64 is the
+    per-GPU shape of the 8-GPU strong-scaling run of config 4; its weight-gradient GEMMs (2048 x 2048 and 6144 x 2048 outputs) take
+    the 128 x 128 tile plan on the bf16 pipe with split operands."""
     m = build(2048, 7, dev)
     assert m.nhead == 256 and sum(p.numel() for p in m.parameters()) == 160_027_845
     zero_dropout(m)
     m.train()
-    B = 6
     fp, img, y = synth_inputs(2048, B, 2048, 49152)
     out = m(fp.to(dev), img.to(dev))
     torch.nn.MSELoss()(out.squeeze(), y.to(dev)).backward()

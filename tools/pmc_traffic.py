@@ -18,16 +18,16 @@ def sources_sha():
     h = hashlib.sha256()
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bbbp-multi-modal-deep-ensemble-framework_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
+        if f.startswith("conv") or f == "common.h":          # the sources of the kernels whose traffic is quoted (conv*.hip)
             h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
-KERNELS = {            # a section maps to whichever of its kernels ran (direct or Winograd form of conv2)
-    "conv2_fwd": ("conv3x3_kernel<32, 64, 64, 0>", "wino_conv_kernel<0>"),
-    "conv2_dgrad": ("conv3x3_kernel<64, 32, 64, 1>", "wino_conv_kernel<1>"),
-    "conv2_wgrad": "conv_wgrad32_kernel<64, 64, 32, 64>",
+KERNELS = {            # a section maps to whichever of its kernels ran (direct f32, Winograd or split-bf16 form)
+    "conv2_fwd": ("conv3x3_kernel<32, 64, 64, 0>", "wino_conv_kernel<0>", "conv_b3_kernel<0>"),
+    "conv2_dgrad": ("conv3x3_kernel<64, 32, 64, 1>", "wino_conv_kernel<1>", "conv_b3_kernel<1>"),
+    "conv2_wgrad": ("conv_wgrad32_kernel<64, 64, 32, 64>", "conv_b3_wgrad_kernel"),
     "conv1_fwd": "conv3x3_kernel<3, 32, 128, 0>",
-    "conv1_wgrad": "conv_wgrad3_kernel<128>",
+    "conv1_wgrad": ("conv_wgrad3_kernel<128>", "conv_b3_wgrad3_kernel"),
 }
 
 
