@@ -3,7 +3,8 @@ FengDushuo/BBBP-Multi-Modal-Deep-Ensemble-Framework (import it as ``bbbp_amd``).
 
 Layout:  csrc/ (HIP kernels + the C ABI of include/bbbp_hip.h), _lib.py (ctypes binding), ops.py (tensor
 front end), models.py (the reference's nn.Module interface), optim.py (fused AdamW), ensemble.py (stacked
-predict surface), distributed.py (one process per GPU, RCCL gradient all-reduce).
+predict surface), trees.py / boosters.py (random-forest and XGBoost prediction), distributed.py (one process per GPU, RCCL
+gradient all-reduce).
 """
 from .models import (ConcatMixedInputModel, MixedDataset, MixedInputModel, MSELoss, TwoBranchConcatModel,
                      MultiHeadAttentionFusion, flatten_parameters, reference_nhead)  # noqa: F401

@@ -1,0 +1,204 @@
+"""GPU prediction for the gradient-boosted base learner of the reference's stacked ensemble.
+
+Reference: ``Models/multi_input_data_regression_opt_transformer_cnn_20250108.py:186-189`` (``XGBRegressor(n_estimators=300,
+learning_rate=0.01, max_depth=30, tree_method="hist")`` fitted on ``hstack([fingerprints, images])``) and the fitted model the
+repository ships, ``Models/xgb_model_maccs.pkl``.  Fitting stays with XGBoost (third-party CPU/GPU code, as in the reference);
+prediction over screening-scale libraries runs here.
+
+The pickle holds the booster's raw model buffer (``Booster.save_raw``: UBJSON).  ``lift_raw_from_pickle`` takes that byte string
+out of the pickle stream with ``pickletools`` -- nothing is unpickled, no xgboost import -- and ``parse_ubjson`` /
+``XGBTrees.from_raw`` read the documented model schema (``learner.gradient_booster.model.trees[*]``: left_children,
+right_children, split_indices, split_conditions, default_left; ``learner.learner_model_param.base_score``).
+
+PARITY UNPINNED: the xgboost package is not installed in the build image, so outputs cannot be compared with the library's own
+``predict``; the predict rule is XGBoost's published one (csrc/forest.hip) and the tests check the GPU path against the numpy
+restatement in ``oracle/reference_cpu.py`` only.
+"""
+from __future__ import annotations
+
+import pickletools
+import struct
+from typing import Any, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+_INT = {"i": (">b", 1), "U": (">B", 1), "I": (">h", 2), "l": (">i", 4), "L": (">q", 8)}
+_NUM = dict(_INT, d=(">f", 4), D=(">d", 8))
+_NP = {"i": ">i1", "U": ">u1", "I": ">i2", "l": ">i4", "L": ">i8", "d": ">f4", "D": ">f8"}
+
+
+def parse_ubjson(buf: bytes) -> Any:
+    """Universal Binary JSON (ubjson.org, draft 12) -> Python objects; strongly typed arrays come back as numpy arrays."""
+    mv = memoryview(buf)
+
+    def integer(pos, tag=None):
+        if tag is None:
+            tag = chr(mv[pos]); pos += 1
+        if tag not in _INT:
+            raise ValueError(f"UBJSON: integer expected at byte {pos - 1}, found {tag!r}")
+        fmt, n = _INT[tag]
+        return struct.unpack_from(fmt, mv, pos)[0], pos + n
+
+    def value(pos, tag=None):
+        if tag is None:
+            tag = chr(mv[pos]); pos += 1
+            while tag == "N":
+                tag = chr(mv[pos]); pos += 1
+        if tag == "Z":
+            return None, pos
+        if tag == "T":
+            return True, pos
+        if tag == "F":
+            return False, pos
+        if tag in _NUM:
+            fmt, n = _NUM[tag]
+            return struct.unpack_from(fmt, mv, pos)[0], pos + n
+        if tag == "C":
+            return chr(mv[pos]), pos + 1
+        if tag in ("S", "H"):
+            n, pos = integer(pos)
+            return bytes(mv[pos:pos + n]).decode("utf-8"), pos + n
+        if tag == "[":
+            etype, count = None, None
+            if chr(mv[pos]) == "$":
+                etype = chr(mv[pos + 1]); pos += 2
+                if chr(mv[pos]) != "#":
+                    raise ValueError("UBJSON: a typed container needs a count")
+            if chr(mv[pos]) == "#":
+                count, pos = integer(pos + 1)
+            if etype is not None and etype in _NP:
+                n = count * np.dtype(_NP[etype]).itemsize
+                return np.frombuffer(mv[pos:pos + n], dtype=_NP[etype]).astype(_NP[etype][1:]), pos + n
+            out = []
+            if count is not None:
+                for _ in range(count):
+                    v, pos = value(pos, etype)
+                    out.append(v)
+                return out, pos
+            while chr(mv[pos]) != "]":
+                v, pos = value(pos)
+                out.append(v)
+            return out, pos + 1
+        if tag == "{":
+            etype, count = None, None
+            if chr(mv[pos]) == "$":
+                etype = chr(mv[pos + 1]); pos += 2
+            if chr(mv[pos]) == "#":
+                count, pos = integer(pos + 1)
+            out = {}
+            k = 0
+            while (count is None and chr(mv[pos]) != "}") or (count is not None and k < count):
+                n, pos = integer(pos)
+                key = bytes(mv[pos:pos + n]).decode("utf-8"); pos += n
+                out[key], pos = value(pos, etype)
+                k += 1
+            return out, (pos + 1 if count is None else pos)
+        raise ValueError(f"UBJSON: unknown type marker {tag!r} at byte {pos - 1}")
+
+    obj, end = value(0)
+    return obj
+
+
+def lift_raw_from_pickle(path: str) -> bytes:
+    """The largest bytes / bytearray literal of a pickle stream (an XGBoost estimator's pickle: the booster's raw model buffer),
+    read with pickletools.genops: no object of the pickle is constructed."""
+    best = b""
+    with open(path, "rb") as f:
+        for op, arg, _ in pickletools.genops(f.read()):
+            if isinstance(arg, (bytes, bytearray)) and len(arg) > len(best):
+                best = bytes(arg)
+    if not best:
+        raise ValueError(f"{path}: no byte string in the pickle stream")
+    return best
+
+
+class XGBTrees:
+    """Flattened regression trees of a gbtree booster + GPU ``predict``."""
+
+    def __init__(self, left, right, feature, cond, default_left, root, n_features: int, base_score: float, device="cuda"):
+        self.arrays = dict(left=np.ascontiguousarray(left, np.int32), right=np.ascontiguousarray(right, np.int32),
+                           feature=np.ascontiguousarray(feature, np.int32), cond=np.ascontiguousarray(cond, np.float32),
+                           default_left=np.ascontiguousarray(default_left, np.uint8), root=np.ascontiguousarray(root, np.int32))
+        self.n_trees, self.n_features, self.base_score = len(root) - 1, int(n_features), float(np.float32(base_score))
+        self.device = torch.device(device) if device is not None else None
+        self._dev = None
+
+    # ---- construction -------------------------------------------------------------------------------------------------
+    @staticmethod
+    def flatten(model: dict) -> Tuple:
+        """(left, right, feature, cond, default_left, root, n_features, base_score) from a parsed XGBoost model document
+        (JSON / UBJSON schema of XGBoost >= 1.0; a top-level {"Config", "Model"} pair as written into pickles is accepted)."""
+        if "learner" not in model and "Model" in model:
+            model = model["Model"]
+        learner = model["learner"]
+        gb = learner["gradient_booster"]
+        if gb.get("name", "gbtree") not in ("gbtree",):
+            raise ValueError(f"booster {gb.get('name')!r} is not supported (gbtree only)")
+        objective = learner.get("objective", {}).get("name", "reg:squarederror")
+        if objective not in ("reg:squarederror", "reg:linear"):
+            raise ValueError(f"objective {objective!r} is not supported (the reference fits reg:squarederror)")
+        lmp = learner["learner_model_param"]
+        if int(lmp.get("num_class", "0")) > 1 or int(lmp.get("num_target", "1")) > 1:
+            raise ValueError("single-output regression only")
+        base = lmp["base_score"]
+        base = float(base.strip("[]")) if isinstance(base, str) else float(np.asarray(base).reshape(-1)[0])
+        left, right, feature, cond, dleft, root = [], [], [], [], [], [0]
+        for tree in gb["model"]["trees"]:
+            cl = np.asarray(tree["left_children"], np.int64); cr = np.asarray(tree["right_children"], np.int64)
+            if "split_type" in tree and np.any(np.asarray(tree["split_type"]) != 0):
+                raise ValueError("categorical splits are not supported")
+            off = root[-1]
+            left.append(np.where(cl >= 0, cl + off, -1)); right.append(np.where(cr >= 0, cr + off, -1))
+            feature.append(np.asarray(tree["split_indices"], np.int64)); cond.append(np.asarray(tree["split_conditions"], np.float32))
+            dleft.append(np.asarray(tree["default_left"], np.uint8))
+            root.append(off + len(cl))
+        if root[-1] >= 2 ** 31:
+            raise ValueError("model too large for 32-bit node indices")
+        return (np.concatenate(left), np.concatenate(right), np.concatenate(feature), np.concatenate(cond), np.concatenate(dleft),
+                np.asarray(root), int(lmp["num_feature"]), base)
+
+    @classmethod
+    def from_raw(cls, raw: bytes, device="cuda") -> "XGBTrees":
+        """From ``Booster.save_raw("ubj")`` bytes (what an XGBoost estimator's pickle holds) or a JSON model document."""
+        if raw[:1] == b"{" and raw[1:2] in (b'"', b" ", b"\n"):
+            import json
+            doc = json.loads(raw.decode("utf-8"))
+        else:
+            doc = parse_ubjson(raw)
+        return cls(*cls.flatten(doc), device=device)
+
+    @classmethod
+    def from_pickle(cls, path: str, device="cuda") -> "XGBTrees":
+        return cls.from_raw(lift_raw_from_pickle(path), device=device)
+
+    # ---- prediction ---------------------------------------------------------------------------------------------------
+    def _on_device(self):
+        if self.device is None or self.device.type != "cuda":
+            raise RuntimeError("XGBTrees.predict needs a GPU (no CPU fallback; oracle/reference_cpu.py holds the checker)")
+        if self._dev is None:
+            self._dev = {k: torch.from_numpy(v).to(self.device) for k, v in self.arrays.items()}
+        return self._dev
+
+    def predict_device(self, X, rows_per_call: int = 1 << 16) -> torch.Tensor:
+        """``X``: [n, n_features] float32 (numpy or CUDA tensor; NaN = missing).  Returns float32 predictions on the GPU."""
+        d = self._on_device()
+        Xd = X.to(self.device, torch.float32).contiguous() if isinstance(X, torch.Tensor) else \
+            torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).to(self.device)
+        if Xd.dim() != 2 or Xd.shape[1] != self.n_features:
+            raise ValueError(f"X must be [n, {self.n_features}]")
+        n = Xd.shape[0]
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        L = _lib.lib()
+        scratch = torch.empty(self.n_trees * min(max(n, 1), rows_per_call), dtype=torch.float32, device=self.device)
+        for lo in range(0, n, rows_per_call):
+            m = min(rows_per_call, n - lo)
+            _lib.check(L.bbbp_gbt_predict(ops._stream(), Xd[lo:lo + m].data_ptr(), m, self.n_features, d["left"].data_ptr(), d["right"].data_ptr(),
+                                          d["feature"].data_ptr(), d["cond"].data_ptr(), d["default_left"].data_ptr(), d["root"].data_ptr(),
+                                          self.n_trees, self.base_score, scratch.data_ptr(), out[lo:lo + m].data_ptr()), "bbbp_gbt_predict")
+        return out
+
+    def predict(self, X) -> np.ndarray:
+        return self.predict_device(X).cpu().numpy()

@@ -62,3 +62,55 @@ extern "C" int bbbp_forest_predict(void* stream, const float* X, long n, int n_f
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Gradient-boosted regression trees, prediction only (the xgb base learner of the stack: XGBRegressor(300 trees, max_depth 30,
+// tree_method="hist") over hstack([fingerprint, image]), Models/multi_input_data_regression_opt_transformer_cnn_20250108.py:186-189;
+// its fitted form ships as Models/xgb_model_maccs.pkl).  XGBoost's published predict rule (src/predictor/cpu_predictor.cc, RegTree::
+// GetNext), restated: a node sends a row to its left child when x[split_index] < split_condition (float32 compare), to the default
+// child (default_left) when the feature is missing (NaN); a leaf's value sits in split_conditions[leaf]; the margin is
+// base_score + (((l_0 + l_1) + l_2) + ...) summed in float32 in tree order; reg:squarederror returns the margin.
+// The xgboost package is absent from this image: parity of this path is UNPINNED (oracle = the same rule restated in numpy).
+// Kernel 1 walks every (tree, row) pair in parallel into leaf[tree][row]; kernel 2 adds a row's leaves in tree order.
+namespace {
+__global__ __launch_bounds__(256) void gbt_walk_kernel(const float* X, long n, int n_features, const int* left, const int* right,
+                                                      const int* feature, const float* cond, const uint8_t* default_left, const int* root,
+                                                      float* leaf) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.y;
+    if (i >= n) return;
+    const float* x = X + i * (long)n_features;
+    int node = root[t];
+    int l = left[node];
+    while (l >= 0) {
+        const float v = x[feature[node]];
+        node = (v != v) ? (default_left[node] ? l : right[node]) : (v < cond[node] ? l : right[node]);
+        l = left[node];
+    }
+    leaf[(long)t * n + i] = cond[node];
+}
+__global__ __launch_bounds__(256) void gbt_sum_kernel(const float* leaf, long n, int n_trees, float base_score, float* out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int t = 0; t < n_trees; ++t) s += leaf[(long)t * n + i];
+    out[i] = base_score + s;
+}
+}  // namespace
+
+extern "C" int bbbp_gbt_predict(void* stream, const float* X, long n, int n_features, const int* left, const int* right, const int* feature,
+                                const float* split_condition, const uint8_t* default_left, const int* root, int n_trees, float base_score,
+                                float* leaf_scratch, float* out) {
+    BBBP_CHECK_ARG(n >= 0 && n_features >= 1 && n_trees >= 1 && n_trees <= 65535, "gbt_predict: bad sizes (n_trees 1..65535)");
+    if (n == 0) return BBBP_OK;
+    BBBP_CHECK_ARG(X && left && right && feature && split_condition && default_left && root && leaf_scratch && out, "gbt_predict: null pointer");
+    const long blocks = (n + 255) / 256;
+    BBBP_CHECK_ARG(blocks <= 0x7fffffffL, "gbt_predict: too many rows");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(gbt_walk_kernel, dim3((unsigned)blocks, n_trees), dim3(256), 0, st, X, n, n_features, left, right, feature,
+                       split_condition, default_left, root, leaf_scratch);
+    BBBP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gbt_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, leaf_scratch, n, n_trees, base_score, out);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}

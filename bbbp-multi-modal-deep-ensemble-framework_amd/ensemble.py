@@ -128,10 +128,12 @@ class StackingRegressor:
         return self.final_estimator_.predict(self.transform(X))
 
 
-def screen(model, forest, stack, fingerprints, images, extra_columns=(), batch_size: int = 4096):
+def screen(model, forest, stack, fingerprints, images, extra_columns=(), batch_size: int = 4096, boosters=()):
     """Stacked prediction over a library (BASELINE config 5; ``Descriptors/virtualscreening.py`` + ...20250113.py:394-403):
-    per batch, the multi-modal network in eval mode, the random forest on ``hstack([fingerprint, image])`` (``trees.ForestGPU``)
-    and any precomputed columns (XGBoost / CatBoost predictions) go through the linear meta-learner, all on the GPU.
+    per batch, the multi-modal network in eval mode, the random forest on ``hstack([fingerprint, image])`` (``trees.ForestGPU``),
+    fitted gradient-boosted learners (``boosters``: ``boosters.XGBTrees``, the xgb column of ...20250108.py:186-207, on the same
+    hstack) and any precomputed columns (CatBoost predictions) go through the linear meta-learner, all on the GPU.  Column order:
+    nn, rf, boosters..., extra_columns...
     Returns float64 predictions on the device.  Like the reference, the network attends ACROSS the batch, so its
     column depends on ``batch_size`` and on the order of the library."""
     import torch
@@ -149,6 +151,7 @@ def screen(model, forest, stack, fingerprints, images, extra_columns=(), batch_s
                 cols = []
                 if forest is not None:
                     cols.append(forest.predict_device(torch.cat([fp, im], dim=1)))
+                cols += [bst.predict_device(torch.cat([fp, im], dim=1)).double() for bst in boosters]
                 cols += [torch.as_tensor(c[i:i + batch_size], device=nn_col.device) for c in extra_columns]
                 out.append(stack.predict_device(nn_col, *cols))
     finally:

@@ -4,8 +4,9 @@ Reference: ``Models/multi_input_data_regression_opt_transformer_cnn_20250113.py:
 n_estimators=300, max_depth=30, random_state=42)`` fitted on ``hstack([fingerprints, images])``) and ``:394-403`` (the same
 learner inside ``StackingRegressor``).  Fitting stays with scikit-learn (CPU, a few thousand molecules); prediction over
 screening-scale libraries (ZINC) is what needs the GPU: ``ForestGPU.from_sklearn(rf).predict(X)`` reproduces
-``rf.predict(X)`` (float32 features, float64 thresholds/values, mean over trees in float64).  XGBoost / CatBoost learners
-cannot be pinned here (packages absent) and stay precomputed input columns of ``ensemble.StackedEnsemble``.
+``rf.predict(X)`` (float32 features, float64 thresholds/values, mean over trees in float64).  The XGBoost learner predicts
+through ``boosters.XGBTrees`` (parity unpinned: package absent); CatBoost stays a precomputed input column of
+``ensemble.StackedEnsemble``.
 """
 from __future__ import annotations
 

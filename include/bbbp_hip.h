@@ -249,6 +249,14 @@ int bbbp_forest_predict(void* stream, const float* X, long n, int n_features, co
                         const int* feature, const double* threshold, const double* value, const int* root, int n_trees,
                         double* partial, double* out);
 
+/* ---- gradient-boosted regression trees, prediction (the xgb base learner of the stack, ...20250108.py:186-189; fitted model
+ * Models/xgb_model_maccs.pkl) -- XGBoost's predict rule: left when x[feature] < split_condition (float32), the default child when
+ * the feature is NaN, leaf value in split_condition[leaf], out = base_score + float32 sum of the leaves in tree order.  Node arrays
+ * concatenated over trees (child indices rebased, -1 = leaf), root[t] = first node of tree t; leaf_scratch: n_trees * n floats. */
+int bbbp_gbt_predict(void* stream, const float* X, long n, int n_features, const int* left, const int* right, const int* feature,
+                     const float* split_condition, const uint8_t* default_left, const int* root, int n_trees, float base_score,
+                     float* leaf_scratch, float* out);
+
 /* ---- optional per-section timing (HIP events on the launch stream; used by bench.py's roofline leg) ----
  * enable(1), run steps, synchronise the stream, collect(ms_sum[n], count[n]) with n = num_sections(). */
 int bbbp_set_partition(int reserved_cus, size_t small_lds_pad);   /* CU partition knob, see csrc/common.h */

@@ -327,3 +327,27 @@ STACKED_KNOWN = {
     "stacked_model_rdkit.pkl": ((0.15119656041952942, 0.8976983917102106, 0.20171374717530366), 0.02521309973011923),
     "stacked_model_maccs_multiattention.pkl": ((0.2134672413252459, 0.6878011884620018, 0.27686389616560697), 0.016440310778525757),
 }
+
+
+def xgb_predict(left, right, feature, cond, default_left, root, base_score, X):
+    """XGBoost's gbtree predict rule for reg:squarederror, restated (src/predictor/cpu_predictor.cc: PredValue; include/xgboost/
+    tree_model.h: RegTree::GetNext / GetLeafIndex): float32 rows, missing = NaN takes the default child, otherwise left when
+    x[split_index] < split_condition; a leaf's weight is split_conditions[leaf]; margin = base_score + float32 sum of the leaf
+    weights in tree order.  The package is absent from the build image: this restatement is the only checker (parity unpinned)."""
+    import numpy as np
+    X = np.asarray(X, np.float32)
+    n = X.shape[0]
+    psum = np.zeros(n, np.float32)
+    rows = np.arange(n)
+    for t in range(len(root) - 1):
+        node = np.full(n, root[t], np.int64)
+        while True:
+            l = left[node]
+            active = l >= 0
+            if not active.any():
+                break
+            v = X[rows, np.where(active, feature[node], 0)]
+            go_left = np.where(np.isnan(v), default_left[node] != 0, v < cond[node])
+            node = np.where(active, np.where(go_left, l, right[node]), node)
+        psum = (psum + cond[node]).astype(np.float32)
+    return (np.float32(base_score) + psum).astype(np.float32)

@@ -61,3 +61,33 @@ def test_screening_pipeline_matches_columnwise_reference(dev):
     want = stack.predict(np.stack([nn_col, rf.predict(feats), xgb_col], axis=1))
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-10, atol=1e-10)
 
+
+
+def test_screening_pipeline_with_a_gradient_boosted_column(dev):
+    """ensemble.screen with the xgb column computed on the GPU (boosters.XGBTrees) == the same columns assembled by hand with the
+    oracle's restatement of XGBoost's predict rule (column order nn, rf, xgb, extra)."""
+    import torch
+    import bbbp_amd
+    from bbbp_amd.boosters import XGBTrees
+    from bbbp_amd.ensemble import StackedEnsemble, screen
+    from oracle import reference_cpu as oracle
+    from test_boosters import random_model, ubj
+    rs = np.random.RandomState(6)
+    n, F = 24, 167
+    fp = torch.from_numpy((rs.rand(n, F) > 0.7).astype(np.float32))
+    img = torch.from_numpy(rs.rand(n, 49152).astype(np.float32))
+    feats = np.hstack([fp.numpy(), img.numpy()])
+    rf = ens.RandomForestRegressor(n_estimators=5, max_depth=4, random_state=1).fit(feats, rs.randn(n))
+    bst = XGBTrees.from_raw(ubj(random_model(21, n_trees=30, n_features=F + 49152, depth=8)), device=dev)
+    torch.manual_seed(1)
+    model = bbbp_amd.MixedInputModel(F, 128).to(dev)
+    cat_col = rs.randn(n)
+    stack = StackedEnsemble.from_coefficients([0.2, 0.5, 0.2, 0.1], -0.01)
+    got = screen(model, ForestGPU.from_sklearn(rf, device=dev), stack, fp.to(dev), img.to(dev), extra_columns=(cat_col,), batch_size=16, boosters=(bst,))
+    model.eval()
+    with torch.no_grad():
+        nn_col = torch.cat([model(fp[i:i + 16].to(dev), img[i:i + 16].to(dev)).reshape(-1) for i in range(0, n, 16)]).double().cpu().numpy()
+    a = bst.arrays
+    xgb_col = oracle.xgb_predict(a["left"], a["right"], a["feature"], a["cond"], a["default_left"], a["root"], bst.base_score, feats).astype(np.float64)
+    want = stack.predict(np.stack([nn_col, rf.predict(feats), xgb_col, cat_col], axis=1))
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-10, atol=1e-10)

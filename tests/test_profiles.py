@@ -42,7 +42,12 @@ def test_bench_lines_have_the_contract_fields(config):
     assert d["vs_baseline"] is None and d["n_gpus"] == 1 and "workload" in d["config"] and d["config"]["baseline_config"] == config
     assert d["dtype"] == ("f64" if config == 1 else "f32") and d["scaling"] == "weak" and d["data"] == "synthetic"
     r = d["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["peak"] == 157.3
+    # configs 2-5: the dominant kernel runs in the split-bf16 form, priced against the bf16 pipe's ceiling (2500 / 6 TFLOP/s of float32
+    # products); config 1's float64 MLP grid against the f32 MFMA peak as before
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["peak"] == (157.3 if config == 1 else 416.7)
+    if config != 1:
+        assert abs(r["frac_of_f32_mfma_peak"] - r["achieved"] / 157.3) < 1e-3 and abs(r["executed_bf16_tflops"] - 6 * r["achieved"]) < 0.1
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     if config != 1:
@@ -60,11 +65,14 @@ def test_rocprof_kernel_table_agrees_with_the_bench_line(config):
     launch in the table is an in-step one), and the PMC traffic quoted in the line is the committed pass of that configuration."""
     d = bench(config)
     r = d["roofline"]
-    pattern = {"conv2_wgrad": "conv_wgrad32_kernel", "conv2_fwd": "wino_conv_kernel<0>", "conv2_dgrad": "wino_conv_kernel<1>"}[r["kernel"]]
+    pattern = {"conv2_wgrad": "conv_b3_wgrad_kernel", "conv2_fwd": "conv_b3_kernel<0>", "conv2_dgrad": "conv_b3_kernel<1>"}[r["kernel"]]
     rows = [x for x in csv.DictReader(open(os.path.join(PROF, f"{ROUND}_kernel_stats_config{config}.csv"))) if pattern in x["Name"]]
     assert len(rows) == 1
     avg_ms = float(rows[0]["AverageNs"]) * 1e-6
-    assert abs(avg_ms - r["ms_per_launch"]) <= 0.05 * r["ms_per_launch"], (avg_ms, r["ms_per_launch"])
+    # config 5 (B = 4096 inference): 13 launches of 3.2 .. 5.6 ms depending on what the encoder stream runs beside them -- two short
+    # runs' averages agree to ~15 %; the training configurations (tens of launches of one repeating step) to 5 %
+    tol = 0.15 if config == 5 else 0.05
+    assert abs(avg_ms - r["ms_per_launch"]) <= tol * r["ms_per_launch"], (avg_ms, r["ms_per_launch"])
     t = json.load(open(os.path.join(PROF, f"{ROUND}_pmc_traffic_config{config}.json")))
     assert r["traffic_source"] == f"{ROUND}_pmc_traffic_config{config}.json" and t["config"] == config
     assert abs(t[r["kernel"]] - r["traffic"]) <= 1e-6 * r["traffic"]
@@ -78,6 +86,7 @@ def test_config4_line_is_the_ffn_gemm_and_improved_over_round_1():
     d = bench(4)
     r = d["roofline"]
     assert r["kernel"] == "ffn1_fwd" and r["flops_per_launch"] == 2 * 512 * 2048 * 2048 and r["traffic"] is None
-    assert d["ms_per_step"] < 13.0           # round 1: 19.5 ms (tools/time_configs.py); the fused small-head attention removed ~6.5 ms
+    # round 1: 19.5 ms (tools/time_configs.py); the fused small-head attention removed ~6.5 ms, the split-bf16 GEMMs another ~2
+    assert d["ms_per_step"] < 10.0 and r["frac_of_f32_mfma_peak"] >= 0.5
     rows = [x for x in csv.DictReader(open(os.path.join(PROF, f"{ROUND}_kernel_stats_config4.csv"))) if "attn_small" in x["Name"]]
     assert len(rows) == 2, "the fused attention kernels ran in the profiled command"

@@ -213,6 +213,36 @@ def case_ops():
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
 
 
+def case_xgb_head(n_keep=6):
+    """The first trees of the XGBoost model the reference ships (Models/xgb_model_maccs.pkl: XGBRegressor, 300 trees, 49 319
+    features, reg:squarederror), lifted out of the pickle stream without unpickling: node arrays, base_score, and the raw UBJSON
+    bytes of a document cut down to those trees (so that the parser is checked on the library's own byte layout).  No expected
+    predictions: xgboost is not installed, the predict rule is pinned only by its published description (parity unpinned)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bbbp_amd import boosters
+    raw = boosters.lift_raw_from_pickle(os.path.join(REF, "Models", "xgb_model_maccs.pkl"))
+    doc = boosters.parse_ubjson(raw)
+    model = doc["Model"]
+    trees = model["learner"]["gradient_booster"]["model"]["trees"]
+    left, right, feature, cond, dleft, root, nfeat, base = boosters.XGBTrees.flatten(doc)
+    hi = int(root[n_keep])
+    out = dict(left=left[:hi].astype(np.int32), right=right[:hi].astype(np.int32), feature=feature[:hi].astype(np.int32), cond=cond[:hi],
+               default_left=dleft[:hi], root=root[:n_keep + 1].astype(np.int32), n_features=np.int64(nfeat), base_score=np.float32(base),
+               n_trees_total=np.int64(len(trees)), n_nodes_total=np.int64(root[-1]),
+               checksum_all=np.array([float(cond.astype(np.float64).sum()), float(np.abs(cond.astype(np.float64)).sum()),
+                                      float(feature.astype(np.float64).sum())]))
+    # the byte layout of the library's writer: the span of the first tree object inside the raw buffer (tree objects open with the
+    # key "base_weights")
+    mark = b"{L" + (12).to_bytes(8, "big") + b"base_weights"
+    start = raw.index(mark)
+    nxt = raw.index(mark, start + 1)
+    probe = boosters.parse_ubjson(raw[start:nxt])
+    assert np.array_equal(probe["left_children"], trees[0]["left_children"]) and np.array_equal(probe["split_conditions"], trees[0]["split_conditions"])
+    out["tree0_ubjson"] = np.frombuffer(raw[start:nxt], dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "xgb_maccs_head.npz"), **out)
+    print("xgb_maccs_head:", hi, "nodes of", int(root[-1]), "| tree 0 bytes", nxt - start)
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
@@ -256,6 +286,8 @@ def main():
     case_model("rdkit_pca", M + "multi_input_data_regression_opt_transformer_cnn_rdkit.py",
                128, 256, 256, Bs=(1, 9), init_seed=3, train_Bs=(6,))
     case_ops()
+    if not only or "xgb_head" in only:
+        case_xgb_head()
 
 
 if __name__ == "__main__":
