@@ -91,9 +91,12 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     p->B = d->batch; p->F = d->fingerprint_size; p->NH = d->nhead; p->D = p->F / p->NH; p->L = d->num_layers;
     p->DFF = d->dim_feedforward;
     p->drop = d->training && d->dropout_p > 0.f;
-    if (g_flash_attention < 0) { const char* e = getenv("BBBP_FLASH_ATTENTION"); g_flash_attention = e ? atoi(e) & 3 : 1; }
+    if (g_flash_attention < 0) { const char* e = getenv("BBBP_FLASH_ATTENTION"); g_flash_attention = e ? atoi(e) & 7 : 5; }
+    // bit 2: the wide-head kernel where it wins -- forward-only plans of 2048 rows and more (256+ work-groups fill the chip and the
+    // [B, B] probability tensor, 67 MB per layer at B = 4096, is never written): config 5 8.28 -> 7.84 ms per 4096 molecules
+    const bool wide = (g_flash_attention & 2) || ((g_flash_attention & 4) && p->inference && p->B >= 2048);
     p->flash = p->L > 0 && (((g_flash_attention & 1) && bbbp_attn_small_supported(p->B, p->NH, p->D)) ||
-                            ((g_flash_attention & 2) && bbbp_attn_wide_supported(p->B, p->NH, p->D)));
+                            (wide && bbbp_attn_wide_supported(p->B, p->NH, p->D)));
     const size_t B = p->B, F = p->F, NH = p->NH, DFF = p->DFF;
     Bump b;
     p->seed_slot = b.take(256);
@@ -432,9 +435,9 @@ extern "C" int bbbp_set_fused_encoder(int on) {
 }
 
 extern "C" int bbbp_set_flash_attention(int on) {
-    if (g_flash_attention < 0) { const char* e = getenv("BBBP_FLASH_ATTENTION"); g_flash_attention = e ? atoi(e) & 3 : 1; }
+    if (g_flash_attention < 0) { const char* e = getenv("BBBP_FLASH_ATTENTION"); g_flash_attention = e ? atoi(e) & 7 : 5; }
     const int prev = g_flash_attention;
-    g_flash_attention = on & 3;
+    g_flash_attention = on & 7;
     return prev;
 }
 

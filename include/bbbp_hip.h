@@ -267,10 +267,11 @@ int bbbp_set_fused_head_bwd(int on);
  * out_proj input gradient backward) as ONE launch each (csrc/encoder.hip) instead of 6 + 6, for d_model <= 192 (default OFF:
  * measured slower, see csrc/engine.hip; initial value BBBP_FUSED_ENCODER).  Returns the previous setting.  Both schedules fill the same workspace. */
 int bbbp_set_fused_encoder(int on);
-/* Fused flash-style self-attention (csrc/attention.hip), a bit mask (default 1, initial value BBBP_FLASH_ATTENTION):
+/* Fused flash-style self-attention (csrc/attention.hip), a bit mask (default 5, initial value BBBP_FLASH_ATTENTION):
  * bit 0: many heads of head_dim 8 / 16 (F = 2048: 256 x 8), one work-group per head, scores in registers, no [nhead, B, B] tensors;
- * bit 1: one wide head of 161 .. 176 columns (F = 167, nhead = 1), operands straight from global memory -- correct but measured
- *        slower than the batched-GEMM + softmax schedule at B = 512, hence opt-in.
+ * bit 1: one wide head of 161 .. 176 columns (F = 167, nhead = 1), operands straight from global memory, everywhere -- correct but
+ *        measured slower than the batched-GEMM + softmax schedule in the B = 512 .. 2048 training steps, hence opt-in;
+ * bit 2: that kernel only where it is faster: forward-only (inference) plans of 2048 rows and more (screening batches).
  * 0 selects the batched GEMM + softmax schedule everywhere.  Returns the previous mask.  Changes the workspace layout: set it
  * before the forward call, not between forward and backward. */
 int bbbp_set_flash_attention(int on);
