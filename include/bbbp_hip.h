@@ -88,8 +88,9 @@ int bbbp_conv_last_clock(unsigned long long* shader_cycles, unsigned long long* 
  * F(2x2,3x3) in float32 (2.25x fewer multiplies, same tensors and mask, results within 1e-6 of the direct form).
  * bit 2 = forward, bit 3 = data gradient, bit 4 = weight gradient run as the direct implicit GEMM on the bf16 matrix pipe with
  * every float32 operand split into three bf16 pieces (six bf16 products per float32 product, float32 accumulate: float32
- * accuracy, csrc/conv_b3.hip); these bits take precedence over the Winograd bits.  0 = direct implicit GEMM on the f32 MFMA
- * everywhere.  Initial value: environment BBBP_CONV_WINOGRAD, else 28. */
+ * accuracy, csrc/conv_b3.hip); these bits take precedence over the Winograd bits.  bit 5 = the weight gradient of the 3->32 @
+ * 128x128 stage (R:85-87) in the same split-bf16 form.  0 = direct implicit GEMM on the f32 MFMA everywhere.  Initial value:
+ * environment BBBP_CONV_WINOGRAD, else 60. */
 int bbbp_set_conv_winograd(int mask);
 int bbbp_get_conv_winograd(void);
 /* Measurement aid: with BBBP_WINO_PROBE=1 in the environment the Winograd kernels stamp the shader clock at phase boundaries;

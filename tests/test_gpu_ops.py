@@ -134,10 +134,11 @@ def _conv_case(dev, B, cin, cout, hw, seed, uniform_patches=False):
         assert_close(dx.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol_frac=2e-5, what="conv dx")
 
 
-@pytest.fixture(params=[0, 96], ids=["f32", "split-bf16"])
+@pytest.fixture(params=[0, 32], ids=["f32", "split-bf16"])
 def conv1_algo(request):
-    """The forms of the 3 -> 32 @ 128x128 stage: f32 MFMA kernels, or (bits 5/6 of bbbp_set_conv_winograd) the bf16 matrix pipe with
-    split operands (conv_b3.hip)."""
+    """The forms of the 3 -> 32 @ 128x128 stage: f32 MFMA kernels, or (bit 5 of bbbp_set_conv_winograd) the weight gradient on the
+    bf16 matrix pipe with split operands (conv_b3.hip); the forward stays on the f32 MFMA (a split-bf16 forward was built and
+    measured slower: 0.283 vs 0.267 ms, its per-lane operand assembly and pooling epilogue outweigh the cheaper MFMAs)."""
     L = _lib.lib()
     old = L.bbbp_get_conv_winograd()
     _lib.check(L.bbbp_set_conv_winograd(request.param), "bbbp_set_conv_winograd")

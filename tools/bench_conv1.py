@@ -23,7 +23,7 @@ def main():
     gy = torch.randn(B, 32, 64, 64, generator=g).to(dev)
     ref = None
     old = L.bbbp_get_conv_winograd()
-    for mask, name in ((0, "f32"), (96, "split-bf16")):
+    for mask, name in ((0, "f32"), (32, "split-bf16 weight gradient")):
         L.bbbp_set_conv_winograd(mask)
         y, m = ops.conv3x3_relu_pool_fwd(x, w, bias)
         dw, db = ops.conv3x3_relu_pool_bwd_weight(x, gy, m)
