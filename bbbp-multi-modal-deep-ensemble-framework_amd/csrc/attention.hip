@@ -545,8 +545,7 @@ bool wide_supported(int B, int nhead, int head_dim) {
 template <class K>
 int set_dyn_lds(K kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return BBBP_OK;
-    BBBP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return BBBP_OK;
+    return bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(kernel), bytes);
 }
 
 }  // namespace

@@ -40,14 +40,15 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 int bbbp_num_cus();   // cached multiProcessorCount of the current device
+int bbbp_ensure_dyn_lds(const void* kernel, size_t bytes);   // hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device)
 
 // CU partitioning for the two-branch overlap (engine.hip).  A persistent conv work-group takes >= 120 KB of a CU's
 // 160 KB LDS, so exactly one fits per CU; with `reserved_cus` > 0 the conv grids shrink to (CUs - reserved) and the
 // small side-stream kernels request `small_lds_pad` bytes (> 40 KB) so that they can ONLY land on the CUs the conv
 // grids left free.  Measured without it: a 5 us kernel sharing CUs with a conv kernel takes 35-85 us.
-extern int g_bbbp_reserved_cus;
-extern size_t g_bbbp_small_lds_pad;
-extern int g_bbbp_wino_side_cus;      // CUs the Winograd conv grids leave free while the engine overlaps its branches
+extern thread_local int g_bbbp_reserved_cus;
+extern thread_local size_t g_bbbp_small_lds_pad;
+extern thread_local int g_bbbp_wino_side_cus;      // CUs the Winograd conv grids leave free while the engine overlaps its branches
 // head.hip: fused fusion-block + regression-head forward (two launches); `partial`: ceil(B/16) * 2 * 256 floats
 int bbbp_head_forward_fused(hipStream_t st, const float* comb, const float* const* fw1, const float* const* fb1,
                             const float* const* fw2, const float* const* fb2, const float* w0, const float* b0, const float* gamma,
@@ -157,7 +158,7 @@ __device__ __forceinline__ uint4 philox4(uint64_t seed, uint64_t ctr) {
 // The engine keeps the per-call dropout seed in DEVICE memory (a slot of the forward workspace, written by a one-thread
 // kernel) so that the enqueued work does not depend on it and can be replayed as a HIP graph; kernels then receive the
 // slot's address in `base` and a per-site salt in `seed`.  The op-level C entry points pass base = nullptr.
-extern const unsigned long long* g_bbbp_seed_base;
+extern thread_local const unsigned long long* g_bbbp_seed_base;
 __device__ __forceinline__ uint64_t effective_seed(uint64_t seed, const unsigned long long* base) {
     return base ? (uint64_t)(*base) * 0x9E3779B97F4A7C15ull + seed : seed;
 }

@@ -753,15 +753,7 @@ __global__ __launch_bounds__(1024) void conv_wgrad3_reduce_kernel(const float* s
 }
 
 template <typename K>
-int set_lds(K kernel, size_t bytes) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) {
-        bbbp_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", bytes, hipGetErrorString(e));
-        return BBBP_ERR_HIP;
-    }
-    return BBBP_OK;
-}
+int set_lds(K kernel, size_t bytes) { return bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(kernel), bytes); }
 
 template <int CIN, int COUT, int W, int MODE>
 int launch_conv(const ConvParams& p, hipStream_t st) {

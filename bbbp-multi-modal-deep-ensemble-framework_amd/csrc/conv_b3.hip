@@ -662,16 +662,7 @@ template <int MODE>
 int launch_b3(const B3Params& p, hipStream_t st) {
     static const int probe = [] { const char* e = getenv("BBBP_B3_PROBE"); return e ? atoi(e) : 0; }();
     auto kernel = probe ? conv_b3_probe_kernel<MODE> : conv_b3_kernel<MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)LDS_BYTES);
-        if (e != hipSuccess) {
-            bbbp_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", LDS_BYTES, hipGetErrorString(e));
-            return BBBP_ERR_HIP;
-        }
-        attr_set = true;
-    }
+    { int rc_ = bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(kernel), (size_t)LDS_BYTES); if (rc_) return rc_; }
     constexpr int NMB = MODE == B3_FWD ? 2 : 1;
     const int nwork = p.B * (IMG / R) * NMB;
     static const int per_cu = [] { const char* e = getenv("BBBP_B3_PER_CU"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 2 ? 2 : v); }();
@@ -712,16 +703,7 @@ extern "C" int bbbp_conv_b3_phases(unsigned long long* phases4) {
 
 // grid work-groups, each writes slab[g][64][288] and bslab[g][64] (conv.hip: conv_wgrad32_reduce_kernel finishes)
 int bbbp_b3_conv2_wgrad(hipStream_t st, const float* x, const float* gy, const uint8_t* mask, float* slab, float* bslab, int B, int grid) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_b3_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)WG_LDS_BYTES);
-        if (e != hipSuccess) {
-            bbbp_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", WG_LDS_BYTES, hipGetErrorString(e));
-            return BBBP_ERR_HIP;
-        }
-        attr_set = true;
-    }
+    { int rc_ = bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(conv_b3_wgrad_kernel), (size_t)WG_LDS_BYTES); if (rc_) return rc_; }
     B3WgradParams p{x, gy, mask, slab, bslab, B};
     hipLaunchKernelGGL(conv_b3_wgrad_kernel, dim3(grid), dim3(256), WG_LDS_BYTES, st, p);
     BBBP_CHECK_LAUNCH();
@@ -730,16 +712,7 @@ int bbbp_b3_conv2_wgrad(hipStream_t st, const float* x, const float* gy, const u
 
 // 3 -> 32 @ 128x128 weight gradient: grid work-groups, each writes slab[g][32][32] and bslab[g][32] (conv.hip: conv_wgrad3_reduce_kernel)
 int bbbp_b3_conv1_wgrad(hipStream_t st, const float* x, const float* gy, const uint8_t* mask, float* slab, float* bslab, int B, int grid) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_b3_wgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)WG3_LDS_BYTES);
-        if (e != hipSuccess) {
-            bbbp_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", WG3_LDS_BYTES, hipGetErrorString(e));
-            return BBBP_ERR_HIP;
-        }
-        attr_set = true;
-    }
+    { int rc_ = bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(conv_b3_wgrad3_kernel), (size_t)WG3_LDS_BYTES); if (rc_) return rc_; }
     B3Wgrad3Params p{x, gy, mask, slab, bslab, B};
     hipLaunchKernelGGL(conv_b3_wgrad3_kernel, dim3(grid), dim3(256), WG3_LDS_BYTES, st, p);
     BBBP_CHECK_LAUNCH();

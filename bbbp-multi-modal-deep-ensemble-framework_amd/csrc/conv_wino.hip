@@ -300,16 +300,7 @@ int launch_wino(const WinoParams& p, hipStream_t st) {
     }();
     static const int probe = [] { const char* e = getenv("BBBP_WINO_PROBE"); return e ? atoi(e) : 0; }();
     auto kernel = probe ? wino_conv_probe_kernel<MODE> : wino_conv_kernel<MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)C::LDS_BYTES);
-        if (e != hipSuccess) {
-            bbbp_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", (size_t)C::LDS_BYTES, hipGetErrorString(e));
-            return BBBP_ERR_HIP;
-        }
-        attr_set = true;
-    }
+    { int rc_ = bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(kernel), (size_t)C::LDS_BYTES); if (rc_) return rc_; }
     const int nwork = p.B * (IMG / 8) * C::NCB;
     int grid = bbbp_num_cus();
     if (cu_cap > 0 && cu_cap < grid) grid = cu_cap;

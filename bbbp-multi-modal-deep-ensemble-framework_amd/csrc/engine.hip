@@ -8,6 +8,7 @@
 #include "common.h"
 #include <optional>
 #include "bbbp_hip.h"
+#include <mutex>
 #include <stdlib.h>
 
 namespace {
@@ -1051,9 +1052,14 @@ extern "C" int bbbp_graph_stats(long* captures, long* replays) {
     return BBBP_OK;
 }
 
+// The engine's side streams, events, profiling slots and graph cache are per-process state: enqueueing a forward or backward call is
+// serialised (two host threads driving two models take turns ENQUEUEING, ~1 ms each; the GPU work itself overlaps as the streams allow).
+static std::mutex g_engine_mutex;
+
 extern "C" int bbbp_mixed_forward(void* stream, const bbbp_mixed_desc* d, const float* const* P, float* const* bn_running,
                                   const float* fingerprint, const float* image, float* out, void* workspace,
                                   size_t workspace_bytes) {
+    std::lock_guard<std::mutex> engine_lock(g_engine_mutex);
     Plan plan;
     TRY(make_plan(d, &plan));
     BBBP_CHECK_ARG(P && fingerprint && image && out && workspace && bn_running, "mixed_forward: null pointer");
@@ -1080,6 +1086,7 @@ extern "C" int bbbp_mixed_forward(void* stream, const bbbp_mixed_desc* d, const 
 extern "C" int bbbp_mixed_backward(void* stream, const bbbp_mixed_desc* d, const float* const* P, float* const* G,
                                    const float* fingerprint, const float* image, const float* dout, void* workspace,
                                    size_t workspace_bytes) {
+    std::lock_guard<std::mutex> engine_lock(g_engine_mutex);
     Plan plan;
     TRY(make_plan(d, &plan));
     BBBP_CHECK_ARG(P && G && fingerprint && image && dout && workspace, "mixed_backward: null pointer");

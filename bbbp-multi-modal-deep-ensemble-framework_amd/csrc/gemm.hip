@@ -830,12 +830,8 @@ template <int BM, int BN, int LAYOUT, bool VEC, int BKT = 0>
 void launch_one(const GemmParams& p, dim3 grid, hipStream_t st) {
     constexpr int BK = BKT ? BKT : bk_of(BM);
     constexpr size_t lds = (size_t)2 * BK * ((BM + (LAYOUT == 2 ? 4 : 1)) + (BN + (LAYOUT != 0 ? 4 : 1))) * sizeof(float);
-    static bool attr_set = false;        // > 64 KB of dynamic LDS needs the opt-in once per kernel
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, LAYOUT, VEC, BKT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    // a refused opt-in makes the launch itself fail, which BBBP_CHECK_LAUNCH reports
+    if (lds > 64 * 1024) (void)bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, LAYOUT, VEC, BKT>), lds);
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, LAYOUT, VEC, BKT>), grid, dim3(256), lds > g_bbbp_small_lds_pad ? lds : g_bbbp_small_lds_pad, st, p);
 }
 
@@ -869,12 +865,7 @@ bool b3_eligible(const GemmParams& p, int layout) {
 }
 template <int LAYOUT>
 int launch_b3_one(const GemmParams& p, dim3 grid, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_b3_kernel<LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_LDS);
-        if (e != hipSuccess) { bbbp_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", B3_LDS, hipGetErrorString(e)); return BBBP_ERR_HIP; }
-        attr_set = true;
-    }
+    { int rc_ = bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_b3_kernel<LAYOUT>), (size_t)B3_LDS); if (rc_) return rc_; }
     static const bool probe = [] { const char* e = getenv("BBBP_GEMM_B3_PROBE"); return e && atoi(e) != 0; }();
     if (probe) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_b3_probe_kernel<LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_LDS);

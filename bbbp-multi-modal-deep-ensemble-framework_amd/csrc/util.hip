@@ -2,12 +2,36 @@
 #include "common.h"
 #include "bbbp_hip.h"
 #include <stdarg.h>
+#include <mutex>
+#include <set>
+#include <utility>
 
 static thread_local char g_err[512] = "";
-int g_bbbp_reserved_cus = 0;
-size_t g_bbbp_small_lds_pad = 0;
-int g_bbbp_wino_side_cus = 0;
-const unsigned long long* g_bbbp_seed_base = nullptr;
+// Per-call scopes of the engine (common.h): set by the host thread that enqueues a forward / backward call and read by the launchers
+// that thread reaches -- thread-local, so that two host threads driving two models do not see each other's scopes.
+thread_local int g_bbbp_reserved_cus = 0;
+thread_local size_t g_bbbp_small_lds_pad = 0;
+thread_local int g_bbbp_wino_side_cus = 0;
+thread_local const unsigned long long* g_bbbp_seed_base = nullptr;
+
+// More than 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, DEVICE): code objects are loaded
+// per device, so a process-wide flag is not enough when one process touches two GPUs.
+int bbbp_ensure_dyn_lds(const void* kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    BBBP_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(dev, kernel);
+    if (done.count(key)) return BBBP_OK;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        bbbp_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", bytes, hipGetErrorString(e));
+        return BBBP_ERR_HIP;
+    }
+    done.insert(key);
+    return BBBP_OK;
+}
 
 void bbbp_set_error(const char* fmt, ...) {
     va_list ap;
@@ -19,15 +43,15 @@ void bbbp_set_error(const char* fmt, ...) {
 extern "C" const char* bbbp_last_error(void) { return g_err; }
 
 int bbbp_num_cus() {
-    static int cached = 0;
-    if (cached == 0) {
-        int dev = 0;
+    static int cached[64] = {0};                  // per device (benign race: every thread computes the same value)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cached = prop.multiProcessorCount;
-        if (cached <= 0) cached = 256;
+        int n = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+        cached[dev] = n > 0 ? n : 256;
     }
-    return cached;
+    return cached[dev];
 }
 
 extern "C" int bbbp_abi_version(void) { return 1; }

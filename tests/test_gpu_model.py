@@ -442,3 +442,60 @@ def test_fused_small_head_attention_matches_materialised_attention(dev, F, B, tr
         else:                       # B = 512: an occasional ReLU / dropout gate at a pre-activation within rounding of zero (see above)
             rel = float((g0[k] - g1[k]).norm() / g0[k].norm().clamp_min(1e-30))
             assert rel <= 2e-3 and float((g0[k] - g1[k]).abs().max()) <= 5e-2 * float(g0[k].abs().max()), (k, rel)
+
+
+def test_two_host_threads_drive_two_models(dev):
+    """The library's per-call scopes are thread-local and the engine serialises ENQUEUEING: two host threads, each training its own
+    model on its own stream at the same time, get bit for bit what they get one after the other.  (Models and inputs are built on
+    the main thread: torch's global RNG is not per thread.)"""
+    import copy
+    import threading
+
+    def make(seed):
+        m = build(167, seed, dev)
+        zero_dropout(m)
+        m.train()
+        fp, img, y = synth_inputs(seed, 24, 167, 49152)
+        return m, fp.to(dev), img.to(dev), y.to(dev)
+
+    def run(seed, job, out, concurrent_barrier=None):
+        m, fp, img, y = job
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        if concurrent_barrier is not None:
+            concurrent_barrier.wait()
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                m.zero_grad(set_to_none=True)
+                o = m(fp, img)
+                bbbp_amd.MSELoss()(o.squeeze(), y).backward()
+            s.synchronize()
+        out[seed] = (o.detach().cpu(), {k: p.grad.detach().cpu() for k, p in m.named_parameters()})
+
+    jobs = {seed: make(seed) for seed in (11, 12)}
+    states = {seed: copy.deepcopy(jobs[seed][0].state_dict()) for seed in jobs}
+    serial, parallel = {}, {}
+    for seed in jobs:
+        run(seed, jobs[seed], serial)
+    for seed in jobs:                        # same starting point (BatchNorm running statistics moved during the serial pass)
+        jobs[seed][0].load_state_dict(states[seed])
+    torch.cuda.synchronize()
+    bar = threading.Barrier(2)
+    errors = []
+
+    def guarded(seed):
+        try:
+            run(seed, jobs[seed], parallel, bar)
+        except Exception as e:       # noqa: BLE001 -- surfaced below
+            errors.append(e)
+
+    ts = [threading.Thread(target=guarded, args=(seed,)) for seed in jobs]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not errors and all(not t.is_alive() for t in ts), errors
+    for seed in jobs:
+        assert torch.equal(serial[seed][0], parallel[seed][0])
+        for k, g in serial[seed][1].items():
+            assert torch.equal(g, parallel[seed][1][k]), k

@@ -111,7 +111,7 @@ def test_adamw_three_steps():
 @pytest.mark.parametrize("name,pth_F,pth_I", [("pca_mlp_maccs_pth", 64, 128), ("pca_mlp_pth", 128, 256)])
 def test_pca_mlp_shipped_weights(name, pth_F, pth_I):
     """The shipped best_nn_model*.pth run through the oracle reproduce the reference class's outputs.  The
-    weights themselves are not committed; the golden holds per-tensor checksums and the outputs."""
+    golden holds per-tensor checksums and the outputs (the two .pth files, the reference's data, sit beside it under tests/golden/)."""
     g = golden(name)
     keys, shapes = list(g["meta/keys"]), list(g["meta/shapes"])
     assert len(keys) == 26 and keys[0] == "fingerprint_fc.0.weight" and "image_fc.0.weight" in keys
