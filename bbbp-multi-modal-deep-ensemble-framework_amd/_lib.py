@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes
 import os
 import re
-from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_long, c_size_t, c_uint8, c_uint64, c_void_p)
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_uint8, c_uint64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BBBP_LIB", os.path.join(_HERE, "libbbbp_hip.so"))    # BBBP_LIB: A/B another build
@@ -68,6 +68,8 @@ _SIGNATURES = {
     "bbbp_gemm_split_bf16_phases": (c_int, [POINTER(c_uint64)]),
     "bbbp_gbt_predict": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                          c_void_p, c_void_p]),
+    "bbbp_oblivious_predict": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                               c_double, c_double, c_void_p, c_void_p]),
     "bbbp_forest_groups": (c_int, [c_int]),
     "bbbp_forest_predict": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_void_p]),

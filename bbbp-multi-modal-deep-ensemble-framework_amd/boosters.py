@@ -10,7 +10,10 @@ out of the pickle stream with ``pickletools`` -- nothing is unpickled, no xgboos
 ``XGBTrees.from_raw`` read the documented model schema (``learner.gradient_booster.model.trees[*]``: left_children,
 right_children, split_indices, split_conditions, default_left; ``learner.learner_model_param.base_score``).
 
-PARITY UNPINNED: the xgboost package is not installed in the build image, so outputs cannot be compared with the library's own
+``CatBoostTrees`` does the same for the cat learner (``CatBoostRegressor(iterations=300, depth=10)``, ...20250108.py:192-195) from
+CatBoost's JSON export (``model.save_model(path, format="json")``): oblivious trees over float features.
+
+PARITY UNPINNED: neither xgboost nor catboost is installed in the build image (and the reference ships no fitted CatBoost model), so outputs cannot be compared with the library's own
 ``predict``; the predict rule is XGBoost's published one (csrc/forest.hip) and the tests check the GPU path against the numpy
 restatement in ``oracle/reference_cpu.py`` only.
 """
@@ -198,6 +201,90 @@ class XGBTrees:
             _lib.check(L.bbbp_gbt_predict(ops._stream(), Xd[lo:lo + m].data_ptr(), m, self.n_features, d["left"].data_ptr(), d["right"].data_ptr(),
                                           d["feature"].data_ptr(), d["cond"].data_ptr(), d["default_left"].data_ptr(), d["root"].data_ptr(),
                                           self.n_trees, self.base_score, scratch.data_ptr(), out[lo:lo + m].data_ptr()), "bbbp_gbt_predict")
+        return out
+
+    def predict(self, X) -> np.ndarray:
+        return self.predict_device(X).cpu().numpy()
+
+
+class CatBoostTrees:
+    """Oblivious trees of a CatBoost model exported as JSON + GPU ``predict`` (float features only, single-dimensional output)."""
+
+    def __init__(self, split_feature, split_border, nan_true, tree_first_split, tree_first_leaf, leaf_values, n_features: int,
+                 scale: float = 1.0, bias: float = 0.0, device="cuda"):
+        self.arrays = dict(split_feature=np.ascontiguousarray(split_feature, np.int32), split_border=np.ascontiguousarray(split_border, np.float32),
+                           nan_true=np.ascontiguousarray(nan_true, np.uint8), tree_first_split=np.ascontiguousarray(tree_first_split, np.int32),
+                           tree_first_leaf=np.ascontiguousarray(tree_first_leaf, np.int64), leaf_values=np.ascontiguousarray(leaf_values, np.float64))
+        self.n_trees, self.n_features, self.scale, self.bias = len(tree_first_split) - 1, int(n_features), float(scale), float(bias)
+        self.device = torch.device(device) if device is not None else None
+        self._dev = None
+
+    @staticmethod
+    def flatten(doc: dict, n_features: int | None = None) -> Tuple:
+        """(split_feature, split_border, nan_true, tree_first_split, tree_first_leaf, leaf_values, n_features, scale, bias) from the
+        JSON export's "oblivious_trees" / "features_info" / "scale_and_bias".  Feature indices are positions in the flat feature
+        vector (``flat_feature_index``)."""
+        feats = doc.get("features_info", {})
+        if feats.get("categorical_features") or feats.get("text_features") or feats.get("embedding_features"):
+            raise ValueError("float features only")
+        ff = feats.get("float_features", [])
+        flat = {int(f.get("feature_index", i)): int(f.get("flat_feature_index", f.get("feature_index", i))) for i, f in enumerate(ff)}
+        nf = n_features if n_features is not None else (max(flat.values()) + 1 if flat else 0)
+        nan_true = np.zeros(max(nf, 1), np.uint8)
+        for i, f in enumerate(ff):
+            if f.get("nan_value_treatment", "AsIs") == "AsTrue":
+                nan_true[flat[int(f.get("feature_index", i))]] = 1
+        sf, sb, first_split, first_leaf, leaves = [], [], [0], [0], []
+        for tree in doc["oblivious_trees"]:
+            splits = tree.get("splits", [])
+            if len(splits) > 31:
+                raise ValueError("trees deeper than 31 levels are not supported")
+            for sp in splits:
+                if sp.get("split_type", "FloatFeature") != "FloatFeature":
+                    raise ValueError("float-feature splits only")
+                fi = int(sp["float_feature_index"])
+                sf.append(flat.get(fi, fi)); sb.append(float(sp["border"]))
+            lv = np.asarray(tree["leaf_values"], np.float64)
+            if lv.size != 1 << len(splits):
+                raise ValueError("single-dimensional leaf values expected (2^depth per tree)")
+            leaves.append(lv)
+            first_split.append(len(sf)); first_leaf.append(first_leaf[-1] + lv.size)
+        sab = doc.get("scale_and_bias", [1.0, [0.0]])
+        bias = sab[1][0] if isinstance(sab[1], (list, tuple)) else sab[1]
+        if sf and max(sf) >= nf:
+            nf = max(sf) + 1
+            nan_true = np.concatenate([nan_true, np.zeros(nf - len(nan_true), np.uint8)])
+        return (np.asarray(sf, np.int32), np.asarray(sb, np.float32), nan_true[:max(nf, 1)], np.asarray(first_split, np.int32),
+                np.asarray(first_leaf[:-1], np.int64), np.concatenate(leaves) if leaves else np.zeros(0), nf,
+                float(sab[0]), float(bias))
+
+    @classmethod
+    def from_json(cls, text_or_doc, n_features: int | None = None, device="cuda") -> "CatBoostTrees":
+        import json
+        doc = json.loads(text_or_doc) if isinstance(text_or_doc, (str, bytes)) else text_or_doc
+        return cls(*cls.flatten(doc, n_features), device=device)
+
+    def predict_device(self, X, rows_per_call: int = 1 << 16) -> torch.Tensor:
+        """``X``: [n, n_features] float32 (numpy or CUDA tensor; NaN = missing).  Returns float64 predictions on the GPU."""
+        if self.device is None or self.device.type != "cuda":
+            raise RuntimeError("CatBoostTrees.predict needs a GPU (no CPU fallback; oracle/reference_cpu.py holds the checker)")
+        if self._dev is None:
+            self._dev = {k: torch.from_numpy(v).to(self.device) for k, v in self.arrays.items()}
+        d = self._dev
+        Xd = X.to(self.device, torch.float32).contiguous() if isinstance(X, torch.Tensor) else \
+            torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).to(self.device)
+        if Xd.dim() != 2 or Xd.shape[1] != self.n_features:
+            raise ValueError(f"X must be [n, {self.n_features}]")
+        n = Xd.shape[0]
+        out = torch.empty(n, dtype=torch.float64, device=self.device)
+        scratch = torch.empty(self.n_trees * min(max(n, 1), rows_per_call), dtype=torch.float64, device=self.device)
+        L = _lib.lib()
+        for lo in range(0, n, rows_per_call):
+            m = min(rows_per_call, n - lo)
+            _lib.check(L.bbbp_oblivious_predict(ops._stream(), Xd[lo:lo + m].data_ptr(), m, self.n_features, d["split_feature"].data_ptr(),
+                                                d["split_border"].data_ptr(), d["nan_true"].data_ptr(), d["tree_first_split"].data_ptr(),
+                                                d["tree_first_leaf"].data_ptr(), d["leaf_values"].data_ptr(), self.n_trees, self.scale, self.bias,
+                                                scratch.data_ptr(), out[lo:lo + m].data_ptr()), "bbbp_oblivious_predict")
         return out
 
     def predict(self, X) -> np.ndarray:

@@ -114,3 +114,59 @@ extern "C" int bbbp_gbt_predict(void* stream, const float* X, long n, int n_feat
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Oblivious (symmetric) trees, prediction only: the cat base learner of the stack (CatBoostRegressor(iterations=300, depth=10),
+// Models/multi_input_data_regression_opt_transformer_cnn_20250108.py:192-195).  CatBoost's published rule for float features
+// (catboost/libs/model: the JSON export's "oblivious_trees"): level i of a tree compares ONE (feature, border) pair for every row,
+// bit i of the leaf index is x[feature] > border (a NaN compares false, or true for features whose nan_value_treatment is "AsTrue"),
+// the tree adds leaf_values[index]; the prediction is scale * (sum over trees, float64, tree order) + bias.
+// The catboost package is absent from this image and the reference ships no fitted CatBoost model: parity UNPINNED.
+namespace {
+__global__ __launch_bounds__(256) void obl_walk_kernel(const float* X, long n, int n_features, const int* split_feature, const float* split_border,
+                                                      const uint8_t* nan_true, const int* tree_first_split, const long* tree_first_leaf,
+                                                      const double* leaf_values, double* leaf) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.y;
+    if (i >= n) return;
+    const float* x = X + i * (long)n_features;
+    const int s0 = tree_first_split[t], s1 = tree_first_split[t + 1];
+    unsigned idx = 0;
+    for (int s = s0; s < s1; ++s) {
+        const int f = split_feature[s];
+        const float v = x[f];
+        const bool bit = (v != v) ? (nan_true[f] != 0) : (v > split_border[s]);
+        idx |= (bit ? 1u : 0u) << (s - s0);
+    }
+    leaf[(long)t * n + i] = leaf_values[tree_first_leaf[t] + idx];
+}
+__global__ __launch_bounds__(256) void obl_sum_kernel(const double* leaf, long n, int n_trees, double scale, double bias, double* out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int t = 0; t < n_trees; ++t) s += leaf[(long)t * n + i];
+    {
+#pragma clang fp contract(off)                               // two roundings, as the host-side rule (no fused multiply-add)
+        const double prod = scale * s;
+        out[i] = prod + bias;
+    }
+}
+}  // namespace
+
+extern "C" int bbbp_oblivious_predict(void* stream, const float* X, long n, int n_features, const int* split_feature, const float* split_border,
+                                      const uint8_t* nan_true, const int* tree_first_split, const long* tree_first_leaf, const double* leaf_values,
+                                      int n_trees, double scale, double bias, double* leaf_scratch, double* out) {
+    BBBP_CHECK_ARG(n >= 0 && n_features >= 1 && n_trees >= 1 && n_trees <= 65535, "oblivious_predict: bad sizes (n_trees 1..65535)");
+    if (n == 0) return BBBP_OK;
+    BBBP_CHECK_ARG(X && split_feature && split_border && nan_true && tree_first_split && tree_first_leaf && leaf_values && leaf_scratch && out,
+                   "oblivious_predict: null pointer");
+    const long blocks = (n + 255) / 256;
+    BBBP_CHECK_ARG(blocks <= 0x7fffffffL, "oblivious_predict: too many rows");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(obl_walk_kernel, dim3((unsigned)blocks, n_trees), dim3(256), 0, st, X, n, n_features, split_feature, split_border, nan_true,
+                       tree_first_split, tree_first_leaf, leaf_values, leaf_scratch);
+    BBBP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(obl_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, leaf_scratch, n, n_trees, scale, bias, out);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}

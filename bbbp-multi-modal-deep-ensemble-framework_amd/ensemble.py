@@ -131,8 +131,8 @@ class StackingRegressor:
 def screen(model, forest, stack, fingerprints, images, extra_columns=(), batch_size: int = 4096, boosters=()):
     """Stacked prediction over a library (BASELINE config 5; ``Descriptors/virtualscreening.py`` + ...20250113.py:394-403):
     per batch, the multi-modal network in eval mode, the random forest on ``hstack([fingerprint, image])`` (``trees.ForestGPU``),
-    fitted gradient-boosted learners (``boosters``: ``boosters.XGBTrees``, the xgb column of ...20250108.py:186-207, on the same
-    hstack) and any precomputed columns (CatBoost predictions) go through the linear meta-learner, all on the GPU.  Column order:
+    fitted gradient-boosted learners (``boosters``: ``boosters.XGBTrees`` / ``boosters.CatBoostTrees``, the xgb and cat columns of
+    ...20250108.py:186-207, on the same hstack) and any precomputed columns go through the linear meta-learner, all on the GPU.  Column order:
     nn, rf, boosters..., extra_columns...
     Returns float64 predictions on the device.  Like the reference, the network attends ACROSS the batch, so its
     column depends on ``batch_size`` and on the order of the library."""

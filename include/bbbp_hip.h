@@ -258,6 +258,14 @@ int bbbp_gbt_predict(void* stream, const float* X, long n, int n_features, const
                      const float* split_condition, const uint8_t* default_left, const int* root, int n_trees, float base_score,
                      float* leaf_scratch, float* out);
 
+/* ---- oblivious (symmetric) trees, prediction (the cat base learner of the stack, ...20250108.py:192-195) -- CatBoost's rule for float
+ * features: bit i of a tree's leaf index is x[split_feature] > split_border of its level i (NaN: false, or true where nan_true[feature]),
+ * out = scale * (float64 sum of leaf_values[tree_first_leaf[t] + index] in tree order) + bias.  Splits concatenated over trees
+ * (tree_first_split: n_trees + 1 entries, at most 31 levels per tree); leaf_scratch: n_trees * n doubles. */
+int bbbp_oblivious_predict(void* stream, const float* X, long n, int n_features, const int* split_feature, const float* split_border,
+                           const uint8_t* nan_true, const int* tree_first_split, const long* tree_first_leaf, const double* leaf_values,
+                           int n_trees, double scale, double bias, double* leaf_scratch, double* out);
+
 /* ---- optional per-section timing (HIP events on the launch stream; used by bench.py's roofline leg) ----
  * enable(1), run steps, synchronise the stream, collect(ms_sum[n], count[n]) with n = num_sections(). */
 int bbbp_set_partition(int reserved_cus, size_t small_lds_pad);   /* CU partition knob, see csrc/common.h */

@@ -351,3 +351,22 @@ def xgb_predict(left, right, feature, cond, default_left, root, base_score, X):
             node = np.where(active, np.where(go_left, l, right[node]), node)
         psum = (psum + cond[node]).astype(np.float32)
     return (np.float32(base_score) + psum).astype(np.float32)
+
+
+def catboost_predict(split_feature, split_border, nan_true, tree_first_split, tree_first_leaf, leaf_values, scale, bias, X):
+    """CatBoost's oblivious-tree rule for float features, restated from the model format's documentation (JSON export:
+    "oblivious_trees"[t]["splits"][i] = {float_feature_index, border}, "leaf_values", "scale_and_bias"): bit i of a tree's leaf index
+    is x[feature_i] > border_i (NaN: false, or true for nan_value_treatment "AsTrue"); prediction = scale * sum_t leaf_values[t][index_t]
+    + bias in float64.  Package absent, no fitted model in the reference: this restatement is the only checker (parity unpinned)."""
+    import numpy as np
+    X = np.asarray(X, np.float32)
+    n = X.shape[0]
+    acc = np.zeros(n, np.float64)
+    for t in range(len(tree_first_split) - 1):
+        idx = np.zeros(n, np.int64)
+        for lvl, s in enumerate(range(tree_first_split[t], tree_first_split[t + 1])):
+            v = X[:, split_feature[s]]
+            bit = np.where(np.isnan(v), nan_true[split_feature[s]] != 0, v > split_border[s])
+            idx |= bit.astype(np.int64) << lvl
+        acc += leaf_values[tree_first_leaf[t] + idx]
+    return scale * acc + bias

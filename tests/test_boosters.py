@@ -165,3 +165,57 @@ def test_gpu_predict_on_the_shipped_models_first_trees():
     X = rng.random((333, m.n_features), dtype=np.float32)          # standardised MACCS bits + pixels live around [0, 1]
     want = oracle.xgb_predict(g["left"], g["right"], g["feature"], g["cond"], g["default_left"], g["root"], float(g["base_score"]), X)
     assert np.array_equal(m.predict(X), want) and len(np.unique(want)) > 50
+
+
+# ---- CatBoost (oblivious trees, JSON export) -------------------------------------------------------------------------------------
+def random_catboost_doc(seed, n_trees, n_features, depth, nan_true_every=7):
+    rng = np.random.default_rng(seed)
+    feats = [dict(feature_index=i, flat_feature_index=i, borders=[], has_nans=bool(i % 3 == 0),
+                  nan_value_treatment="AsTrue" if i % nan_true_every == 0 else ("AsFalse" if i % 2 else "AsIs")) for i in range(n_features)]
+    trees = []
+    for t in range(n_trees):
+        d = int(rng.integers(1, depth + 1)) if t else depth
+        splits = [dict(float_feature_index=int(rng.integers(0, n_features)), split_index=int(i), split_type="FloatFeature",
+                       border=float(np.float32(rng.normal()))) for i in range(d)]
+        trees.append(dict(splits=splits, leaf_values=[float(v) for v in 0.1 * rng.normal(size=1 << d)], leaf_weights=[1.0] * (1 << d)))
+    return dict(model_info={}, features_info=dict(float_features=feats), oblivious_trees=trees, scale_and_bias=[0.75, [-0.3]])
+
+
+def test_catboost_flatten_and_oracle_rule():
+    import json
+    doc = random_catboost_doc(1, n_trees=4, n_features=12, depth=5)
+    sf, sb, nt, fs, fl, lv, nf, scale, bias = boosters.CatBoostTrees.flatten(json.loads(json.dumps(doc)))
+    assert nf == 12 and scale == 0.75 and bias == -0.3 and len(fs) == 5 and fs[1] == 5 and len(fl) == 4 and lv.size == sum(1 << (fs[i + 1] - fs[i]) for i in range(4))
+    assert nt[0] == 1 and nt[7] == 1 and nt[1] == 0
+    # hand case: one tree of depth 2 over features 0 and 1; bit 0 = x0 > 0.5, bit 1 = x1 > -1
+    hand = dict(features_info=dict(float_features=[dict(feature_index=0, flat_feature_index=0), dict(feature_index=1, flat_feature_index=1, nan_value_treatment="AsTrue")]),
+                oblivious_trees=[dict(splits=[dict(float_feature_index=0, border=0.5), dict(float_feature_index=1, border=-1.0)], leaf_values=[1.0, 2.0, 4.0, 8.0])],
+                scale_and_bias=[2.0, [0.5]])
+    f = boosters.CatBoostTrees.flatten(hand)
+    X = np.array([[0.4, -2.0], [0.6, -2.0], [0.5, 0.0], [np.nan, np.nan]], np.float32)
+    got = oracle.catboost_predict(*f[:6], f[7], f[8], X)
+    assert np.array_equal(got, 2.0 * np.array([1.0, 2.0, 4.0, 4.0]) + 0.5)       # equality is not '>', NaN: false on x0, true on x1
+    bad = json.loads(json.dumps(doc)); bad["oblivious_trees"][0]["splits"][0]["split_type"] = "OneHotFeature"
+    with pytest.raises(ValueError):
+        boosters.CatBoostTrees.flatten(bad)
+    with pytest.raises(RuntimeError):
+        boosters.CatBoostTrees(*f, device="cpu").predict(X)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,n_trees,depth", [(1, 2, 3), (777, 50, 6), (4000, 300, 10)])
+def test_gpu_catboost_predict_is_bit_exact_against_the_oracle(n, n_trees, depth):
+    doc = random_catboost_doc(n, n_trees, 96, depth)
+    m = boosters.CatBoostTrees.from_json(doc)
+    rng = np.random.default_rng(n + 1)
+    X = rng.normal(size=(n, 96)).astype(np.float32)
+    X[rng.random(X.shape) < 0.05] = np.nan
+    a = m.arrays
+    for i in range(min(n, 40)):                      # rows sitting exactly on a border: '>' is false
+        s = i % len(a["split_feature"])
+        X[i, a["split_feature"][s]] = a["split_border"][s]
+    want = oracle.catboost_predict(a["split_feature"], a["split_border"], a["nan_true"], a["tree_first_split"], a["tree_first_leaf"], a["leaf_values"],
+                                   m.scale, m.bias, X)
+    got = m.predict(X)
+    assert got.dtype == np.float64 and np.array_equal(got, want)
+    assert np.array_equal(m.predict_device(torch.from_numpy(X), rows_per_call=301).cpu().numpy(), want)
