@@ -31,7 +31,7 @@ class GemmDesc(Structure):
                 ("bias", c_void_p), ("residual", c_void_p), ("ldr", c_int), ("act", c_int),
                 ("gate", c_void_p), ("ldg", c_int), ("gate_scale", c_float), ("batch", c_int),
                 ("strideA", c_long), ("strideB", c_long), ("strideC", c_long), ("strideR", c_long), ("strideG", c_long),
-                ("gate_after_residual", c_int), ("asum", c_void_p)]
+                ("gate_after_residual", c_int), ("asum", c_void_p), ("drop_p", c_float), ("drop_seed", c_uint64)]
 
 
 class MlpModel(Structure):

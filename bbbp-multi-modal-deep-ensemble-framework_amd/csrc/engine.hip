@@ -342,7 +342,7 @@ bbbp_gemm_desc gemm_desc(int transA, int transB, int M, int N, int K, float alph
     g.transA = transA; g.transB = transB; g.M = M; g.N = N; g.K = K; g.alpha = alpha;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.bias = nullptr; g.residual = nullptr; g.ldr = 0; g.act = 0; g.gate = nullptr; g.ldg = 0; g.gate_scale = 1.f;
-    g.gate_after_residual = 0; g.asum = nullptr;
+    g.gate_after_residual = 0; g.asum = nullptr; g.drop_p = 0.f; g.drop_seed = 0;
     g.batch = batch; g.strideA = sA; g.strideB = sB; g.strideC = sC; g.strideR = 0; g.strideG = 0;
     return g;
 }
@@ -587,11 +587,19 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         TRY(bbbp_layernorm_fwd(ce.st, z1, x, y1, P[ix.layer(l, L_N1W)], P[ix.layer(l, L_N1B)], c.f(o.mean1), c.f(o.rstd1), B, F,
                                1e-5f, p_drop, site_seed(d->seed, l, 1)));
         float* hff = c.f(o.hff); float* z2 = c.f(o.z2); float* y2 = c.f(o.y2);
+        // linear1 + ReLU (+ the FFN dropout in the same epilogue when the product takes the small-GEMM path: same Philox elements as bbbp_dropout)
+        const bool drop_in_gemm = plan.drop && bbbp_gemm_folds_asum(B, DFF, F, 1);
         {
             Section sf(ce.st, SEC_FFN1_FWD);
-            TRY(linear_fwd(ce, y1, F, P[ix.layer(l, L_W1)], P[ix.layer(l, L_B1)], hff, DFF, B, DFF, F, BBBP_ACT_RELU));
+            if (drop_in_gemm) {
+                bbbp_gemm_desc g = gemm_desc(0, 1, B, DFF, F, 1.f, y1, F, P[ix.layer(l, L_W1)], F, hff, DFF, 1, 0, 0, 0);
+                g.bias = P[ix.layer(l, L_B1)]; g.act = BBBP_ACT_RELU; g.drop_p = p_drop; g.drop_seed = site_seed(d->seed, l, 2);
+                TRY(bbbp_gemm_f32_grouped(ce.st, &g, 1, ce.scratch(), ce.scratch_bytes()));
+            } else {
+                TRY(linear_fwd(ce, y1, F, P[ix.layer(l, L_W1)], P[ix.layer(l, L_B1)], hff, DFF, B, DFF, F, BBBP_ACT_RELU));
+            }
         }
-        if (plan.drop) TRY(bbbp_dropout(ce.st, hff, hff, (long)B * DFF, p_drop, site_seed(d->seed, l, 2)));
+        if (plan.drop && !drop_in_gemm) TRY(bbbp_dropout(ce.st, hff, hff, (long)B * DFF, p_drop, site_seed(d->seed, l, 2)));
         {
             Section sf(ce.st, SEC_FFN2_FWD);
             TRY(linear_fwd(ce, hff, DFF, P[ix.layer(l, L_W2)], P[ix.layer(l, L_B2)], z2, F, B, F, DFF, 0));

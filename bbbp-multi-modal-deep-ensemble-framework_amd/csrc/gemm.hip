@@ -542,6 +542,7 @@ struct DirectParams {
     int wsm, wsn, ks;        // waves of a work-group: wsm x wsn output tiles, each computed by ks K-slices
     int batch, gx, gy;       // grid extent of THIS problem (a grouped launch covers the largest)
     float* asum;             // LAYOUT 2 only: asum[m] = sum_k A[k][m] through a virtual all-ones column N of B
+    float drop_p, drop_inv_keep; unsigned long long drop_seed; const unsigned long long* seed_base;      // output dropout (after act)
 };
 
 template <int T>
@@ -716,6 +717,8 @@ __device__ __forceinline__ void gemm_direct_body(const DirectParams& p, int batc
                 }
                 if (m < p.M && n < p.N) {
                     float v = apply_act(p.alpha * acc[um][un][r] + bv, p.act);
+                    if (p.drop_p > 0.f)
+                        v *= dropout_scale(effective_seed(p.drop_seed, p.seed_base), ((uint64_t)batch * p.M + m) * p.N + n, p.drop_p, p.drop_inv_keep);
                     const float gsel = p.gate ? (p.gate[(long)batch * p.sG + (long)m * p.ldg + n] > 0.f ? p.gate_scale : 0.f) : 1.f;
                     if (!p.gate_after) v *= gsel;
                     if (R) v += R[(long)m * p.ldr + n];
@@ -942,6 +945,7 @@ int gemm_validate(const bbbp_gemm_desc& g) {
     BBBP_CHECK_ARG(g.ldb >= (g.transB ? g.K : g.N), "gemm: ldb %d too small", g.ldb);
     BBBP_CHECK_ARG(g.ldc >= g.N, "gemm: ldc %d too small", g.ldc);
     BBBP_CHECK_ARG(!g.gate || g.ldg >= g.N, "gemm: ldg %d too small", g.ldg);
+    BBBP_CHECK_ARG(g.drop_p >= 0.f && g.drop_p < 1.f, "gemm: drop_p %g outside [0, 1)", (double)g.drop_p);
     return BBBP_OK;
 }
 
@@ -958,6 +962,7 @@ bool direct_params(const bbbp_gemm_desc& g, DirectParams* d, int* t) {
     d->gate = g.gate; d->ldg = g.ldg; d->sG = g.strideG; d->gate_scale = g.gate_scale; d->gate_after = g.gate_after_residual;
     d->wsm = dp.wsm; d->wsn = dp.wsn; d->ks = dp.ks;
     d->asum = (g.transA && !g.transB) ? g.asum : nullptr;
+    d->drop_p = g.drop_p; d->drop_inv_keep = g.drop_p > 0.f ? 1.f / (1.f - g.drop_p) : 1.f; d->drop_seed = g.drop_seed; d->seed_base = g_bbbp_seed_base;
     d->batch = g.batch; d->gx = cdiv(g.N + (d->asum ? 1 : 0), 16 * dp.t * dp.wsn); d->gy = cdiv(g.M, 16 * dp.t * dp.wsm);
     *t = dp.t;
     return true;
@@ -974,6 +979,7 @@ int gemm_run(hipStream_t st, const bbbp_gemm_desc& g, void* workspace, size_t wo
         return BBBP_OK;
     }
     BBBP_CHECK_ARG(!g.asum, "gemm: asum is only produced by the small-product path (bbbp_gemm_folds_asum(%d, %d, %d, %d) == 0)", g.M, g.N, g.K, g.batch);
+    BBBP_CHECK_ARG(!(g.drop_p > 0.f), "gemm: output dropout is only applied by the small-product path (bbbp_gemm_folds_asum(%d, %d, %d, %d) == 0)", g.M, g.N, g.K, g.batch);
     const int M = g.M, N = g.N, K = g.K, batch = g.batch;
     GemmParams p;
     p.A = g.A; p.B = g.B; p.C = g.C; p.bias = g.bias; p.R = g.residual;
@@ -1031,7 +1037,7 @@ extern "C" int bbbp_gemm_f32(void* stream, int transA, int transB, int M, int N,
     g.transA = transA; g.transB = transB; g.M = M; g.N = N; g.K = K; g.alpha = alpha;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
-    g.gate = nullptr; g.ldg = 0; g.gate_scale = 1.f; g.gate_after_residual = 0; g.asum = nullptr;
+    g.gate = nullptr; g.ldg = 0; g.gate_scale = 1.f; g.gate_after_residual = 0; g.asum = nullptr; g.drop_p = 0.f; g.drop_seed = 0;
     g.batch = batch; g.strideA = strideA; g.strideB = strideB; g.strideC = strideC; g.strideR = strideR; g.strideG = 0;
     return gemm_run(static_cast<hipStream_t>(stream), g, workspace, workspace_bytes);
 }

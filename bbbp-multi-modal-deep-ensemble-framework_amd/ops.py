@@ -41,7 +41,8 @@ def _rowmajor_2d(t: torch.Tensor, name: str) -> Tuple[int, int, int]:
     return t.shape[0], t.shape[1], ld
 
 
-def _gemm_desc(a, b, trans_a, trans_b, alpha, bias, residual, act, out, gate, gate_scale, gate_after_residual=False):
+def _gemm_desc(a, b, trans_a, trans_b, alpha, bias, residual, act, out, gate, gate_scale, gate_after_residual=False, dropout_p=0.0,
+               dropout_seed=0):
     """Validate one product and describe it as a bbbp_gemm_desc; returns (desc, out, split-K workspace bytes)."""
     _chk(a, "a"); _chk(b, "b")
     batched = a.dim() == 3
@@ -85,7 +86,7 @@ def _gemm_desc(a, b, trans_a, trans_b, alpha, bias, residual, act, out, gate, ga
             raise RuntimeError(f"gemm: bias has {bias.numel()} elements, expected {N}")
     d = _lib.GemmDesc(int(trans_a), int(trans_b), M, N, K, float(alpha), a.data_ptr(), lda, b.data_ptr(), ldb,
                       out.data_ptr(), ldc, _p(bias), _p(residual), ldr, ACT[act], _p(gate), ldg, float(gate_scale), nb,
-                      sa, sb, sc, sr, sg, int(bool(gate_after_residual)))
+                      sa, sb, sc, sr, sg, int(bool(gate_after_residual)), None, float(dropout_p), int(dropout_seed))
     return d, out, _lib.lib().bbbp_gemm_workspace_bytes(M, N, K, nb)
 
 
@@ -110,14 +111,16 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bo
 
 def gemm_grouped(problems) -> list:
     """Independent products (dicts of gemm()'s arguments); neighbours that are small enough share one launch."""
-    keys = ("trans_a", "trans_b", "alpha", "bias", "residual", "act", "out", "gate", "gate_scale", "gate_after_residual")
+    keys = ("trans_a", "trans_b", "alpha", "bias", "residual", "act", "out", "gate", "gate_scale", "gate_after_residual", "dropout_p",
+            "dropout_seed")
     defaults = dict(trans_a=False, trans_b=False, alpha=1.0, bias=None, residual=None, act=None, out=None, gate=None,
-                    gate_scale=1.0, gate_after_residual=False)
+                    gate_scale=1.0, gate_after_residual=False, dropout_p=0.0, dropout_seed=0)
     descs, outs, wsb = [], [], 0
     for pr in problems:
         kw = {k: pr.get(k, defaults[k]) for k in keys}
         d, out, w = _gemm_desc(pr["a"], pr["b"], kw["trans_a"], kw["trans_b"], kw["alpha"], kw["bias"], kw["residual"],
-                               kw["act"], kw["out"], kw["gate"], kw["gate_scale"], kw["gate_after_residual"])
+                               kw["act"], kw["out"], kw["gate"], kw["gate_scale"], kw["gate_after_residual"], kw["dropout_p"],
+                               kw["dropout_seed"])
         descs.append(d); outs.append(out); wsb = max(wsb, w)
     if not descs:
         return []

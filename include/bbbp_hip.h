@@ -67,6 +67,11 @@ typedef struct bbbp_gemm_desc {
     float* asum;                  /* optional, layout A^T B only (a Linear's weight gradient dW = dY^T X): asum[m] = sum_k A[k][m], the
                                      matching bias gradient, produced by the same MFMAs through a virtual all-ones column N of B.
                                      Honoured by the small-product path only: ask bbbp_gemm_folds_asum first. */
+    float drop_p;                 /* optional dropout of the OUTPUT, applied after bias/act (before gate/residual): element (m, n) is
+                                     scaled by the keep-scale of element m * N + n of Philox stream drop_seed -- the stream bbbp_dropout
+                                     draws for a contiguous [M][N] tensor, so act + dropout of linear1 (R:75-78, train mode) is one launch.
+                                     0 = off.  Small-product path only (bbbp_gemm_folds_asum(M, N, K, batch) == 1). */
+    unsigned long long drop_seed;
 } bbbp_gemm_desc;
 /* 1 when a product of this shape (layout A^T B) takes the path that honours bbbp_gemm_desc.asum. */
 int bbbp_gemm_folds_asum(int M, int N, int K, int batch);

@@ -97,6 +97,21 @@ def test_gemm_grouped_pairs_and_gate(dev, B, D, NH):
     assert ops.gemm_grouped([]) == []
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 2048, 167), (37, 300, 64), (16, 16, 16)])
+def test_gemm_output_dropout_draws_the_dropout_kernels_stream(dev, M, N, K):
+    """bbbp_gemm_desc.drop_p: linear1 + ReLU + dropout as ONE launch == the GEMM followed by bbbp_dropout with the same seed, bit for bit
+    (element (m, n) takes the keep-scale of element m * N + n of the stream); the large-product path refuses it."""
+    a, w, bias = rnd(M, K, seed=21).to(dev), rnd(N, K, seed=22).to(dev), rnd(N, seed=23).to(dev)
+    two = ops.dropout(ops.gemm(a, w, trans_b=True, bias=bias, act="relu"), 0.1, 987654321)
+    one = ops.gemm_grouped([dict(a=a, b=w, trans_b=True, bias=bias, act="relu", dropout_p=0.1, dropout_seed=987654321)])[0]
+    assert torch.equal(one, two)
+    kept = float((one != 0).float().mean()) / max(float((ops.gemm(a, w, trans_b=True, bias=bias, act="relu") != 0).float().mean()), 1e-9)
+    assert 0.8 < kept < 0.97 or M * N < 1000
+    big_a, big_w = torch.zeros(4096, 512, device=dev), torch.zeros(2048, 512, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.gemm_grouped([dict(a=big_a, b=big_w, trans_b=True, dropout_p=0.1, dropout_seed=1)])
+
+
 def test_gemm_errors(dev):
     with pytest.raises(RuntimeError):
         ops.gemm(torch.zeros(4, 5), torch.zeros(5, 6))                    # CPU tensors: no fallback
