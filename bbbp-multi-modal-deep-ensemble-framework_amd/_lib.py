@@ -70,6 +70,9 @@ _SIGNATURES = {
                          c_void_p, c_void_p]),
     "bbbp_oblivious_predict": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                c_double, c_double, c_void_p, c_void_p]),
+    "bbbp_linear_layernorm_supported": (c_int, [c_int, c_int, c_int]),
+    "bbbp_linear_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_uint64]),
     "bbbp_forest_groups": (c_int, [c_int]),
     "bbbp_forest_predict": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_void_p]),

@@ -583,9 +583,20 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
                           D, D, 0, ce.scratch(), ce.scratch_bytes()));
         }
         float* z1 = c.f(o.z1); float* y1 = c.f(o.y1);
+        // out_proj -> (dropout) + residual -> norm1: one launch when the output is narrow (gemm.hip: gemm_direct_ln_kernel)
+        // OPT-IN (BBBP_FUSED_LINEAR_LN=1), measured slower at B = 512: the 11-wave work-groups need three wave slots on three SIMDs of a CU
+        // beside the resident conv work-groups (encoder forward 0.98 -> 1.15 ms in the step, 0.58 -> 0.60 alone); linear2 -> norm2 is never
+        // fused (one wave per tile walking K = 2048 alone: 90 us against 22 + 4)
+        static const bool ln_opt_in = [] { const char* e = getenv("BBBP_FUSED_LINEAR_LN"); return e && atoi(e) != 0; }();
+        const bool ln_fused = ln_opt_in && bbbp_linear_layernorm_supported(B, F, F) && F <= 512;
+        if (ln_fused) {
+            TRY(bbbp_linear_layernorm_fwd(ce.st, ctx, F, P[ix.layer(l, L_OUTW)], P[ix.layer(l, L_OUTB)], x, F, z1, F, y1, F, P[ix.layer(l, L_N1W)],
+                                          P[ix.layer(l, L_N1B)], c.f(o.mean1), c.f(o.rstd1), B, F, F, 1e-5f, p_drop, site_seed(d->seed, l, 1)));
+        } else {
         TRY(linear_fwd(ce, ctx, F, P[ix.layer(l, L_OUTW)], P[ix.layer(l, L_OUTB)], z1, F, B, F, F, 0));
         TRY(bbbp_layernorm_fwd(ce.st, z1, x, y1, P[ix.layer(l, L_N1W)], P[ix.layer(l, L_N1B)], c.f(o.mean1), c.f(o.rstd1), B, F,
                                1e-5f, p_drop, site_seed(d->seed, l, 1)));
+        }
         float* hff = c.f(o.hff); float* z2 = c.f(o.z2); float* y2 = c.f(o.y2);
         // linear1 + ReLU (+ the FFN dropout in the same epilogue when the product takes the small-GEMM path: same Philox elements as bbbp_dropout)
         const bool drop_in_gemm = plan.drop && bbbp_gemm_folds_asum(B, DFF, F, 1);

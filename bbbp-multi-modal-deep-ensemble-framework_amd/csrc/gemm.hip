@@ -736,6 +736,105 @@ __global__ __launch_bounds__(1024) void gemm_direct_kernel(DirectParams p) {
     gemm_direct_body<LAYOUT, TM, TN>(p, blockIdx.z, red);
 }
 
+// Linear + dropout + residual + LayerNorm as ONE launch for a narrow output (N <= 256: the encoder's out_proj -> norm1 and linear2 ->
+// norm2 at F = 167, R:75-78): a work-group owns 16 rows and ALL their columns, one 16 x 16 wave tile per wave (same operand path as
+// gemm_direct_kernel), so the row statistics are two LDS exchanges away from the accumulators.
+//   z = dropout(x W^T + b) + residual   (written: backward needs it)      y = (z - mean) * rstd * gamma + beta
+// The dropout draws element m * N + n of `seed`, exactly what bbbp_layernorm_fwd draws for the same tensor.
+struct LnFuse {
+    const float* gamma; const float* beta;
+    float* y; int ldy;
+    float* mean; float* rstd;
+    float eps;
+};
+
+__global__ __launch_bounds__(1024, 2) void gemm_direct_ln_kernel(DirectParams p, LnFuse f) {
+    BBBP_HIGH_PRIO();
+    __shared__ float part[2][16][16];                     // [pass][wave][row]
+    constexpr int D = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int q = lane & 15, kq = lane >> 4;
+    DirectOperand<1, false> opa, opb;
+    opa.init(p.A, p.lda, p.M, blockIdx.y * 16, lane);
+    opb.init(p.B, p.ldb, p.N, wave * 16, lane);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto mfma_chunk = [&](const float (&a)[4][1], const float (&b)[4][1]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][0], b[j][0], acc, 0, 0, 0);
+    };
+    const int nch = (p.K + 15) / 16;
+    const int nfast = nch - 1;
+    if (nfast > 0) {
+        float ra[D][4][1], rb[D][4][1];
+#pragma unroll
+        for (int d = 0; d < D; ++d) { const int c = min(d, nfast - 1); opa.fetch(c, ra[d]); opb.fetch(c, rb[d]); }
+        for (int i0 = 0; i0 < nfast; i0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (i0 + d < nfast) mfma_chunk(ra[d], rb[d]);
+                const int c = min(i0 + d + D, nfast - 1);
+                opa.fetch(c, ra[d]); opb.fetch(c, rb[d]);
+            }
+        }
+    }
+    if (nch > 0) {
+        float ta[4][1], tb[4][1];
+        opa.fetch_tail(nch - 1, p.K, ta); opb.fetch_tail(nch - 1, p.K, tb);
+        mfma_chunk(ta, tb);
+    }
+    // lane (q, kq): column n, rows m0 + 4 kq + r
+    const int n = wave * 16 + q, m0 = blockIdx.y * 16 + 4 * kq;
+    const bool coln = n < p.N;
+    const float bv = (p.bias && coln) ? p.bias[n] : 0.f;
+    const uint64_t seed = effective_seed(p.drop_seed, p.seed_base);
+    float z[4], s[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = min(m0 + r, p.M - 1);
+        float v = p.alpha * acc[r] + bv;
+        if (p.drop_p > 0.f) v *= dropout_scale(seed, (uint64_t)m * p.N + min(n, p.N - 1), p.drop_p, p.drop_inv_keep);
+        if (p.R && coln) v += p.R[(long)m * p.ldr + n];
+        z[r] = coln ? v : 0.f;
+        if (coln && m0 + r < p.M) p.C[(long)m * p.ldc + n] = v;
+        s[r] = z[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s[r] += __shfl_xor(s[r], 1); s[r] += __shfl_xor(s[r], 2); s[r] += __shfl_xor(s[r], 4); s[r] += __shfl_xor(s[r], 8); }
+    if (q == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[0][wave][4 * kq + r] = s[r];
+    }
+    __syncthreads();
+    float mean[4], d2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t = 0.f;
+        for (int w = 0; w < nw; ++w) t += part[0][w][4 * kq + r];
+        mean[r] = t / p.N;
+        const float d = coln ? z[r] - mean[r] : 0.f;
+        d2[r] = d * d;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { d2[r] += __shfl_xor(d2[r], 1); d2[r] += __shfl_xor(d2[r], 2); d2[r] += __shfl_xor(d2[r], 4); d2[r] += __shfl_xor(d2[r], 8); }
+    if (q == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[1][wave][4 * kq + r] = d2[r];
+    }
+    __syncthreads();
+    const float gam = coln ? f.gamma[n] : 0.f, bet = coln ? f.beta[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t = 0.f;
+        for (int w = 0; w < nw; ++w) t += part[1][w][4 * kq + r];
+        const float rstd = rsqrtf(t / p.N + f.eps);
+        const int m = m0 + r;
+        if (m < p.M) {
+            if (coln) f.y[(long)m * f.ldy + n] = (z[r] - mean[r]) * rstd * gam + bet;
+            if (wave == 0 && q == 0) { f.mean[m] = mean[r]; f.rstd[m] = rstd; }
+        }
+    }
+}
+
 // Two independent products in one launch (dV | dP and dQ | dK of the attention backward, which become ready together):
 // the chain of small launches is bound by per-launch latency, not by work, so halving the launches halves the time.
 // blockIdx.z < p0.batch -> problem 0, else problem 1; work-groups outside a problem's own grid exit at once.
@@ -1077,5 +1176,29 @@ extern "C" int bbbp_gemm_split_bf16_phases(unsigned long long* phases7) {
     BBBP_CHECK_ARG(phases7 != nullptr, "gemm_split_bf16_phases: null output");
     BBBP_CHECK_HIP(hipDeviceSynchronize());
     BBBP_CHECK_HIP(hipMemcpyFromSymbol(phases7, HIP_SYMBOL(g_gemm_b3_phase), 7 * sizeof(unsigned long long)));
+    return BBBP_OK;
+}
+
+// Linear + dropout + residual + LayerNorm in one launch (gemm_direct_ln_kernel): narrow outputs only
+extern "C" int bbbp_linear_layernorm_supported(int M, int N, int K) {
+    return (M >= 1 && N >= 1 && N <= 256 && K >= 1 && K <= 8192 && (M + 15) / 16 <= 65535) ? 1 : 0;
+}
+
+extern "C" int bbbp_linear_layernorm_fwd(void* stream, const float* x, int ldx, const float* W, const float* bias, const float* residual, int ldr,
+                                         float* z, int ldz, float* y, int ldy, const float* gamma, const float* beta, float* mean, float* rstd,
+                                         int M, int N, int K, float eps, float dropout_p, uint64_t seed) {
+    BBBP_CHECK_ARG(bbbp_linear_layernorm_supported(M, N, K), "linear_layernorm: M=%d N=%d K=%d not supported (N <= 256, K <= 8192)", M, N, K);
+    BBBP_CHECK_ARG(x && W && z && y && gamma && beta && mean && rstd, "linear_layernorm: null pointer");
+    BBBP_CHECK_ARG(ldx >= K && ldz >= N && ldy >= N && (!residual || ldr >= N), "linear_layernorm: leading dimension too small");
+    BBBP_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "linear_layernorm: bad dropout %f", (double)dropout_p);
+    DirectParams d;
+    memset(&d, 0, sizeof(d));
+    d.A = x; d.B = W; d.C = z; d.bias = bias; d.R = residual;
+    d.M = M; d.N = N; d.K = K; d.lda = ldx; d.ldb = K; d.ldc = ldz; d.ldr = ldr;
+    d.alpha = 1.f; d.wsm = 1; d.wsn = cdiv(N, 16); d.ks = 1; d.batch = 1; d.gx = 1; d.gy = cdiv(M, 16);
+    d.drop_p = dropout_p; d.drop_inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f; d.drop_seed = seed; d.seed_base = g_bbbp_seed_base;
+    LnFuse f{gamma, beta, y, ldy, mean, rstd, eps};
+    hipLaunchKernelGGL(gemm_direct_ln_kernel, dim3(1, d.gy), dim3(64 * d.wsn), g_bbbp_small_lds_pad, static_cast<hipStream_t>(stream), d, f);
+    BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }

@@ -218,6 +218,27 @@ def layernorm_fwd(x: torch.Tensor, residual: Optional[torch.Tensor], gamma: torc
     return y, z, mean, rstd
 
 
+def linear_layernorm_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor],
+                         gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, dropout_p: float = 0.0, seed: int = 0):
+    """y = LayerNorm(dropout(x @ weight.T + bias) + residual) in ONE launch (narrow outputs: weight [N <= 256, K]).
+    Returns (y, z, mean, rstd) like ``layernorm_fwd``."""
+    _chk(x, "x"); _chk(weight, "weight")
+    x = x.contiguous(); weight = weight.contiguous()
+    M, K = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K:
+        raise RuntimeError("linear_layernorm_fwd: inner dimensions differ")
+    z = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    y = torch.empty_like(z)
+    mean = torch.empty(M, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    res = residual.contiguous() if residual is not None else None
+    _lib.check(_lib.lib().bbbp_linear_layernorm_fwd(_stream(), x.data_ptr(), K, weight.data_ptr(), _p(bias), _p(res), N, z.data_ptr(), N,
+                                                    y.data_ptr(), N, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                    M, N, K, eps, dropout_p, seed), "bbbp_linear_layernorm_fwd")
+    return y, z, mean, rstd
+
+
 def layernorm_bwd(dy, z, gamma, mean, rstd, dropout_p: float = 0.0, seed: int = 0):
     """Returns (dz, dx, dgamma, dbeta); dx is dz when dropout_p == 0."""
     rows, cols = z.shape

@@ -119,6 +119,14 @@ int bbbp_conv3x3_relu_pool_bwd_weight(void* stream, const float* x, const float*
 int bbbp_layernorm_fwd(void* stream, float* x_inout_z, const float* residual, float* y, const float* gamma,
                        const float* beta, float* mean, float* rstd, int rows, int cols, float eps,
                        float dropout_p, uint64_t seed);
+/* Linear + dropout + residual + LayerNorm as ONE launch for narrow outputs (the encoder's out_proj -> norm1 and linear2 -> norm2 at
+ * F = 167, R:75-78): z = dropout(x W^T + bias) + residual (written, kept for backward), y = LayerNorm(z), mean / rstd per row.  The
+ * dropout draws the elements bbbp_layernorm_fwd draws.  bbbp_linear_layernorm_supported: N <= 256, K <= 8192.  The engine uses it for
+ * out_proj -> norm1 only with BBBP_FUSED_LINEAR_LN=1 in the environment (measured slower inside the B = 512 step). */
+int bbbp_linear_layernorm_supported(int M, int N, int K);
+int bbbp_linear_layernorm_fwd(void* stream, const float* x, int ldx, const float* W, const float* bias, const float* residual, int ldr,
+                              float* z, int ldz, float* y, int ldy, const float* gamma, const float* beta, float* mean, float* rstd,
+                              int M, int N, int K, float eps, float dropout_p, uint64_t seed);
 int bbbp_layernorm_bwd(void* stream, const float* dy, const float* z, const float* gamma, const float* mean,
                        const float* rstd, float* dz, float* dx, float* dgamma, float* dbeta, int rows, int cols,
                        float dropout_p, uint64_t seed);

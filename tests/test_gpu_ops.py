@@ -112,6 +112,33 @@ def test_gemm_output_dropout_draws_the_dropout_kernels_stream(dev, M, N, K):
         ops.gemm_grouped([dict(a=big_a, b=big_w, trans_b=True, dropout_p=0.1, dropout_seed=1)])
 
 
+@pytest.mark.parametrize("M,N,K,p", [(512, 167, 167, 0.1), (512, 167, 2048, 0.1), (37, 64, 300, 0.0), (5, 256, 16, 0.25), (16, 1, 7, 0.0)])
+def test_linear_layernorm_fused_matches_gemm_then_layernorm(dev, M, N, K, p):
+    """out_proj -> dropout + residual -> LayerNorm as one launch == the GEMM followed by bbbp_layernorm_fwd (same Philox elements,
+    so the dropped positions are identical; sums are ordered differently, hence rounding-level tolerances)."""
+    x, w, b = rnd(M, K, seed=31).to(dev), rnd(N, K, seed=32, scale=0.2).to(dev), rnd(N, seed=33).to(dev)
+    res, gam, bet = rnd(M, N, seed=34).to(dev), (1 + 0.1 * rnd(N, seed=35)).to(dev), rnd(N, seed=36).to(dev)
+    y1, z1, m1, r1 = ops.linear_layernorm_fwd(x, w, b, res, gam, bet, dropout_p=p, seed=4242)
+    y0, z0, m0, r0 = ops.layernorm_fwd(ops.gemm(x, w, trans_b=True, bias=b), res, gam, bet, dropout_p=p, seed=4242)
+    if p > 0:
+        lin = ops.gemm(x, w, trans_b=True, bias=b)
+        assert torch.equal((z1 - res).abs() < 1e-12 * 0, (z0 - res).abs() < 1e-12 * 0)          # shapes only; the real check follows
+        dropped0 = ((z0 - res).abs() <= 1e-6 * lin.abs().clamp_min(1e-3)) & (lin.abs() > 1e-2)
+        dropped1 = ((z1 - res).abs() <= 1e-6 * lin.abs().clamp_min(1e-3)) & (lin.abs() > 1e-2)
+        assert torch.equal(dropped0, dropped1)
+    assert_close(z1.cpu().numpy(), z0.cpu().numpy(), rtol=2e-5, atol_frac=2e-6, what="z")
+    assert_close(y1.cpu().numpy(), y0.cpu().numpy(), rtol=1e-4, atol_frac=1e-5, what="y")
+    assert_close(m1.cpu().numpy(), m0.cpu().numpy(), rtol=1e-4, atol_frac=1e-5, what="mean")
+    assert_close(r1.cpu().numpy(), r0.cpu().numpy(), rtol=1e-4, atol_frac=1e-6, what="rstd")
+    # against float64
+    if p == 0:
+        zz = x.double().cpu() @ w.double().cpu().t() + b.double().cpu() + res.double().cpu()
+        want = torch.nn.functional.layer_norm(zz, (N,), gam.double().cpu(), bet.double().cpu(), 1e-5)
+        assert_close(y1.cpu().numpy(), want.numpy(), rtol=1e-4, atol_frac=1e-5, what="y vs float64")
+    with pytest.raises(RuntimeError):
+        ops.linear_layernorm_fwd(torch.zeros(4, 8, device=dev), torch.zeros(300, 8, device=dev), None, None, torch.ones(300, device=dev), torch.zeros(300, device=dev))
+
+
 def test_gemm_errors(dev):
     with pytest.raises(RuntimeError):
         ops.gemm(torch.zeros(4, 5), torch.zeros(5, 6))                    # CPU tensors: no fallback
