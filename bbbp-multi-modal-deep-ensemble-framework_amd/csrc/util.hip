@@ -2,6 +2,7 @@
 #include "common.h"
 #include "bbbp_hip.h"
 #include <stdarg.h>
+#include <stdlib.h>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -44,12 +45,17 @@ extern "C" const char* bbbp_last_error(void) { return g_err; }
 
 int bbbp_num_cus() {
     static int cached[64] = {0};                  // per device (benign race: every thread computes the same value)
+    // BBBP_COMM_CUS=n keeps n CUs out of every persistent grid (they are all sized from this count): room for RCCL's ring kernels
+    // beside the conv work-groups in a multi-GPU run.  Default 0; never measured on a multi-GPU node (none was available).
+    static const int comm_cus = [] { const char* e = getenv("BBBP_COMM_CUS"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : v; }();
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
     if (cached[dev] == 0) {
         hipDeviceProp_t prop;
         int n = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
-        cached[dev] = n > 0 ? n : 256;
+        n = n > 0 ? n : 256;
+        if (comm_cus > 0 && n - comm_cus >= 64) n -= comm_cus;
+        cached[dev] = n;
     }
     return cached[dev];
 }
