@@ -106,7 +106,7 @@ def cpu_baseline_model(cfg, fp, img, y, state):
     kw = dict(num_layers=cfg["layers"], fusion="attention" if cfg["fusion"] else "concat")
     fp, img, y = fp.cpu(), img.cpu(), y.cpu()
     B = fp.shape[0]
-    iters = 3 if cfg["F"] <= 256 and B <= 512 else 1
+    iters = 5 if cfg["F"] <= 256 and B <= 512 else 2          # ~10 s of CPU work per configuration
     if not cfg["train"]:
         p = {k: v.detach().cpu() for k, v in state.items()}
         times = []
