@@ -190,11 +190,12 @@ def test_headline_batch_properties(dev):
     assert_close(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol_frac=2e-5, what="sub-batch vs oracle")
 
 
-@pytest.mark.parametrize("B", [6, 64])
+@pytest.mark.parametrize("B", [6, 64, 256])
 def test_morgan_width_2048_against_oracle(dev, B):
     """BASELINE config 4 width: F = 2048 => nhead 256, head_dim 8 (fused small-head attention), 160 M parameters.  B = 64 is the
     per-GPU shape of the 8-GPU strong-scaling run of config 4; its weight-gradient GEMMs (2048 x 2048 and 6144 x 2048 outputs) take
-    the 128 x 128 tile plan on the bf16 pipe with split operands."""
+    the 128 x 128 tile plan on the bf16 pipe with split operands.  From B = 256 on the forward and input-gradient GEMMs (M = B) take
+    that plan as well, as in the benchmarked B = 512 step."""
     m = build(2048, 7, dev)
     assert m.nhead == 256 and sum(p.numel() for p in m.parameters()) == 160_027_845
     zero_dropout(m)
