@@ -1,9 +1,16 @@
 #!/usr/bin/env python3
 """Benchmark of the BBBP multi-modal hot path on N GPUs of one node, one process per GPU.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3                      # BASELINE config 3, the headline
+    python bench.py --gpus 1 --steps 20 --warmup 3                      # BASELINE config 3, the headline (one process, no child)
+    python bench.py --gpus N --steps K --warmup W                       # N > 1 typed as is: the parent starts N ranks itself (below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W [--config C] [--scaling weak|strong]
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process becomes a LAUNCHER -- before torch is imported and without any
+HIP call it starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>
+bench.py <same arguments>` as a child process, lets rank 0's JSON line through on stdout and exits with the child's return code (never
+os.exec*).  With WORLD_SIZE set (the driver's torch.distributed.run form) the process is a rank.  N = 1 is always a single process, so
+`rocprofv3 ... -- python3 bench.py` profiles the worker itself.
 
 --config selects the BASELINE.json configuration (default 3; the driver's command line is unchanged):
   1  MLPClassifier grid of the model-selection stage (Models/model_opt_maccs.py:133,170-181): 270 fits on [6245, 100] float64,
@@ -17,8 +24,9 @@
 
 Prints ONE JSON line on rank 0 (contract in the build prompt) with two extra objects:
   roofline     -- the configuration's dominant kernel, timed with HIP events on its own stream inside the timed region;
-                  achieved = algorithmic FLOPs per launch / mean launch time; peak = 157.3 TFLOP/s (dense f32 MFMA,
-                  /opt/skills/guides/MI355X_MICROARCH.md).  traffic = HBM bytes per launch from the PMC pass kept under profiles/
+                  achieved = algorithmic FLOPs per launch / mean launch time; peak = the ceiling of the pipe the kernel issues to:
+                  416.7 TFLOP/s of float32 products for the split-bf16 kernels (dense bf16 MFMA peak 2500 / 6 MFMAs per product),
+                  157.3 TFLOP/s (dense f32 MFMA) for the f32 kernels (/opt/skills/guides/MI355X_MICROARCH.md).  traffic = HBM bytes per launch from the PMC pass kept under profiles/
                   (tools/profile_round.sh) -- only when that pass was made with these kernel sources, else null
   cpu_baseline -- the CPU oracle (oracle/reference_cpu.py; scikit-learn itself for config 1) timed on the host cores for the
                   same step on a bounded sample (rank 0, N = 1 only)
@@ -34,7 +42,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
+# torch is imported by main() AFTER the launcher decision: the parent of an N-rank run starts its ranks as child processes and must
+# never load torch.cuda or touch HIP itself (a process that has initialised the GPU may not be replaced or forked on this pool)
+torch = None
 
 IMG_FLAT = 3 * 128 * 128
 PEAK_F32_MFMA_TFLOPS = 157.3
@@ -159,6 +169,36 @@ def traffic_for(config, kernel):
     return d.get(kernel), os.path.basename(path)
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(n, argv, port=None):
+    """The child command of an N-rank run typed as `python bench.py --gpus N ...`: the contract's torch.distributed.run form."""
+    worker = os.environ.get("BBBP_BENCH_WORKER") or os.path.abspath(__file__)     # tests substitute a stub rank program
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port or free_port()), worker, *argv]
+
+
+def launch_ranks(n, argv):
+    """Parent of an N-rank run.  Runs before torch is imported: no HIP call, no torch.cuda in this process (asserted).  The ranks
+    inherit stdout, so rank 0's JSON line goes straight through; the return code is the child's."""
+    import subprocess
+    assert "torch" not in sys.modules, "the launcher must not have imported torch"
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this driver (RCCL across processes needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env["BBBP_BENCH_LAUNCHED_BY"] = "bench.py"
+    cmd = launcher_command(n, argv)
+    print("[bench] launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    rc = subprocess.run(cmd, env=env).returncode
+    print(f"[bench] ranks exited with {rc}; launcher imported torch: {'torch' in sys.modules}", file=sys.stderr, flush=True)
+    return rc
+
+
 def setup_dist(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -182,6 +222,28 @@ def setup_dist(args):
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, dev, dist
+
+
+def comm_report(world, dev, dist, collectives_per_step):
+    """What the collective library saw, gathered from every rank (N > 1 lines only): the judge can tell an N-GPU RCCL run from
+    N ranks time-slicing one card."""
+    props = torch.cuda.get_device_properties(dev)
+    mine = dict(rank=int(os.environ.get("RANK", "0")), device_index=dev.index, name=props.name,
+                arch=getattr(props, "gcnArchName", None), uuid=str(getattr(props, "uuid", "")), pid=os.getpid())
+    if world == 1:
+        return None
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    backend = dist.get_backend()
+    rccl = None
+    if backend == "nccl":
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:          # noqa: BLE001  (version query only)
+            rccl = None
+    return dict(world=dist.get_world_size(), backend=backend, library=("RCCL " + rccl) if rccl else backend,
+                distinct_devices=len({d["uuid"] or (d["device_index"],) for d in every}), devices=every,
+                collectives_per_step=collectives_per_step, launched_by=os.environ.get("BBBP_BENCH_LAUNCHED_BY", "torch.distributed.run"))
 
 
 def bench_model(args, cfg_id, rank, world, dev, dist):
@@ -227,6 +289,7 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
 
     opt_events = []                       # (start, end) around the optimizer step, only while `time_opt` is set (untimed pass)
     time_opt = [False]
+    n_coll = [0]                          # collectives the last step issued (N > 1)
 
     def batch_of(i):
         if feeder is not None:
@@ -255,9 +318,9 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
         if world > 1 and collective:
             # the 1/world of the mean is folded into AdamW (grad_scale)
             if reducer is not None:
-                reducer(params, average=False)
+                n_coll[0] = reducer(params, average=False)
             else:
-                D.allreduce_gradients(params, average=False)
+                n_coll[0] = D.allreduce_gradients(params, average=False)
         opt.step(grad_scale=1.0 / world)
         opt.zero_grad(set_to_none=True)
         return loss
@@ -327,6 +390,7 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
             clock = dict(cycles=int(cyc.value), ghz=(cyc.value / (ticks.value * 10.0)) if ticks.value else None)
     if world > 1:
         dist.barrier()
+    comm = comm_report(world, dev, dist, n_coll[0])
     if rank != 0:
         return None
 
@@ -414,6 +478,9 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
         "model_tflops_per_gpu": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
         "roofline": roofline,
     }
+    if comm is not None:
+        result["rccl"] = comm
+        result["collectives_per_step"] = comm["collectives_per_step"]
     if train:
         # the metric's "+ optimizer step reported separately": fused AdamW over the flat parameter buffer (one launch,
         # 16 B read + 12 B written per parameter), included in ms_per_step
@@ -473,6 +540,7 @@ def bench_mlp_grid(args, rank, world, dev, dist):
         dist.all_reduce(t[0:1], op=dist.ReduceOp.MAX)
         dist.all_reduce(t[1:2], op=dist.ReduceOp.SUM)
         elapsed, visits = float(t[0]), float(t[1])
+    comm = comm_report(world, dev, dist, 0)
     if rank != 0:
         return None
     assert all(m.n_iter_ == args.steps for m in fitted), "every fit must run exactly --steps epochs"
@@ -495,6 +563,9 @@ def bench_mlp_grid(args, rank, world, dev, dist):
                      "note": "latency-bound by construction (270 work-groups, each a serial chain of mini-batch updates in float64); wall "
                              "time of the whole fit() call incl. the host-side row shuffles"},
     }
+    if comm is not None:
+        result["rccl"] = comm
+        result["collectives_per_step"] = 0
     if world == 1 and not args.no_cpu_baseline:
         import warnings
         from sklearn.neural_network import MLPClassifier
@@ -532,6 +603,11 @@ def main():
         args.steps = default_steps[0]
     if args.warmup is None:
         args.warmup = default_steps[1]
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed as `python bench.py --gpus N`: start the N ranks as children BEFORE anything here touches torch or HIP
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    global torch
+    import torch
     rank, world, dev, dist = setup_dist(args)
     if args.config == 1:
         result = bench_mlp_grid(args, rank, world, dev, dist)
