@@ -36,6 +36,11 @@ _NP = {"i": ">i1", "U": ">u1", "I": ">i2", "l": ">i4", "L": ">i8", "d": ">f4", "
 def parse_ubjson(buf: bytes) -> Any:
     """Universal Binary JSON (ubjson.org, draft 12) -> Python objects; strongly typed arrays come back as numpy arrays."""
     mv = memoryview(buf)
+    size = len(mv)
+
+    def need(pos, n):
+        if n < 0 or pos + n > size:
+            raise ValueError(f"UBJSON: truncated or corrupt document ({n} bytes wanted at byte {pos} of {size})")
 
     def integer(pos, tag=None):
         if tag is None:
@@ -43,7 +48,14 @@ def parse_ubjson(buf: bytes) -> Any:
         if tag not in _INT:
             raise ValueError(f"UBJSON: integer expected at byte {pos - 1}, found {tag!r}")
         fmt, n = _INT[tag]
+        need(pos, n)
         return struct.unpack_from(fmt, mv, pos)[0], pos + n
+
+    def count_of(pos):
+        c, pos = integer(pos)
+        if c < 0:
+            raise ValueError(f"UBJSON: negative container count {c} at byte {pos}")
+        return c, pos
 
     def value(pos, tag=None):
         if tag is None:
@@ -58,11 +70,13 @@ def parse_ubjson(buf: bytes) -> Any:
             return False, pos
         if tag in _NUM:
             fmt, n = _NUM[tag]
+            need(pos, n)
             return struct.unpack_from(fmt, mv, pos)[0], pos + n
         if tag == "C":
             return chr(mv[pos]), pos + 1
         if tag in ("S", "H"):
-            n, pos = integer(pos)
+            n, pos = count_of(pos)
+            need(pos, n)
             return bytes(mv[pos:pos + n]).decode("utf-8"), pos + n
         if tag == "[":
             etype, count = None, None
@@ -71,9 +85,10 @@ def parse_ubjson(buf: bytes) -> Any:
                 if chr(mv[pos]) != "#":
                     raise ValueError("UBJSON: a typed container needs a count")
             if chr(mv[pos]) == "#":
-                count, pos = integer(pos + 1)
+                count, pos = count_of(pos + 1)
             if etype is not None and etype in _NP:
                 n = count * np.dtype(_NP[etype]).itemsize
+                need(pos, n)
                 return np.frombuffer(mv[pos:pos + n], dtype=_NP[etype]).astype(_NP[etype][1:]), pos + n
             out = []
             if count is not None:
@@ -90,18 +105,24 @@ def parse_ubjson(buf: bytes) -> Any:
             if chr(mv[pos]) == "$":
                 etype = chr(mv[pos + 1]); pos += 2
             if chr(mv[pos]) == "#":
-                count, pos = integer(pos + 1)
+                count, pos = count_of(pos + 1)
             out = {}
             k = 0
             while (count is None and chr(mv[pos]) != "}") or (count is not None and k < count):
-                n, pos = integer(pos)
+                n, pos = count_of(pos)
+                need(pos, n)
                 key = bytes(mv[pos:pos + n]).decode("utf-8"); pos += n
                 out[key], pos = value(pos, etype)
                 k += 1
             return out, (pos + 1 if count is None else pos)
         raise ValueError(f"UBJSON: unknown type marker {tag!r} at byte {pos - 1}")
 
-    obj, end = value(0)
+    try:
+        obj, end = value(0)
+    except (IndexError, struct.error) as e:                    # a marker or number cut off by the end of the buffer
+        raise ValueError(f"UBJSON: truncated document ({e})") from None
+    if end != size:
+        raise ValueError(f"UBJSON: {size - end} trailing bytes after the document")
     return obj
 
 
@@ -118,10 +139,52 @@ def lift_raw_from_pickle(path: str) -> bytes:
     return best
 
 
+GBT_MAX_DEPTH = 1024          # csrc/forest.hip: the device walk gives up (NaN) after this many levels
+
+
+def validate_gbt(left, right, feature, cond, default_left, root, n_features: int) -> int:
+    """Host-side check of flattened gbtree arrays BEFORE they reach the GPU (a shipped model file is untrusted input and the device
+    walk follows child indices and reads ``x[feature[node]]``): equal array lengths; every node a leaf (both children -1) or an
+    internal node whose children lie inside its own tree and whose split index is a feature; no node is the child of two nodes and
+    no root is anybody's child (=> every walk from a root ends in a leaf); depth <= GBT_MAX_DEPTH.  Returns the largest depth."""
+    left, right, feature, root = (np.asarray(a, np.int64) for a in (left, right, feature, root))
+    n = left.size
+    if not (right.size == feature.size == np.asarray(cond).size == np.asarray(default_left).size == n):
+        raise ValueError("gbtree arrays differ in length")
+    if root.ndim != 1 or root.size < 2 or root[0] != 0 or root[-1] != n or np.any(np.diff(root) < 1):
+        raise ValueError("tree offsets must rise from 0 to the node count, one node per tree at least")
+    if int(n_features) < 1:
+        raise ValueError("num_feature must be positive")
+    leaf = left < 0
+    if np.any(leaf != (right < 0)) or np.any(left[leaf] != -1) or np.any(right[leaf] != -1):
+        raise ValueError("a node must have two children or none (-1, -1)")
+    tree_of = np.searchsorted(root, np.arange(n), side="right") - 1
+    lo, hi = root[tree_of], root[tree_of + 1]
+    inner = ~leaf
+    for child in (left, right):
+        if np.any((child[inner] < lo[inner]) | (child[inner] >= hi[inner])):
+            raise ValueError("a child index points outside its tree")
+    if np.any((feature[inner] < 0) | (feature[inner] >= int(n_features))):
+        raise ValueError(f"a split index is outside [0, {int(n_features)})")
+    children = np.concatenate([left[inner], right[inner]])
+    if np.unique(children).size != children.size or np.isin(root[:-1], children).any():
+        raise ValueError("the nodes do not form trees (a node with two parents, or a root that is a child)")
+    frontier, depth = root[:-1], 0
+    while True:
+        frontier = frontier[inner[frontier]]
+        if frontier.size == 0:
+            return depth
+        depth += 1
+        if depth > GBT_MAX_DEPTH:
+            raise ValueError(f"tree deeper than {GBT_MAX_DEPTH} levels")
+        frontier = np.concatenate([left[frontier], right[frontier]])
+
+
 class XGBTrees:
     """Flattened regression trees of a gbtree booster + GPU ``predict``."""
 
     def __init__(self, left, right, feature, cond, default_left, root, n_features: int, base_score: float, device="cuda"):
+        self.max_depth = validate_gbt(left, right, feature, cond, default_left, root, n_features)
         self.arrays = dict(left=np.ascontiguousarray(left, np.int32), right=np.ascontiguousarray(right, np.int32),
                            feature=np.ascontiguousarray(feature, np.int32), cond=np.ascontiguousarray(cond, np.float32),
                            default_left=np.ascontiguousarray(default_left, np.uint8), root=np.ascontiguousarray(root, np.int32))
@@ -151,6 +214,8 @@ class XGBTrees:
         left, right, feature, cond, dleft, root = [], [], [], [], [], [0]
         for tree in gb["model"]["trees"]:
             cl = np.asarray(tree["left_children"], np.int64); cr = np.asarray(tree["right_children"], np.int64)
+            if not (len(cl) == len(cr) == len(tree["split_indices"]) == len(tree["split_conditions"]) == len(tree["default_left"])) or len(cl) == 0:
+                raise ValueError("a tree's node arrays differ in length (or are empty)")
             if "split_type" in tree and np.any(np.asarray(tree["split_type"]) != 0):
                 raise ValueError("categorical splits are not supported")
             off = root[-1]
@@ -160,8 +225,12 @@ class XGBTrees:
             root.append(off + len(cl))
         if root[-1] >= 2 ** 31:
             raise ValueError("model too large for 32-bit node indices")
-        return (np.concatenate(left), np.concatenate(right), np.concatenate(feature), np.concatenate(cond), np.concatenate(dleft),
-                np.asarray(root), int(lmp["num_feature"]), base)
+        if len(root) < 2:
+            raise ValueError("the model holds no trees")
+        flat = (np.concatenate(left), np.concatenate(right), np.concatenate(feature), np.concatenate(cond), np.concatenate(dleft),
+                np.asarray(root), int(lmp["num_feature"]))
+        validate_gbt(*flat)
+        return (*flat, base)
 
     @classmethod
     def from_raw(cls, raw: bytes, device="cuda") -> "XGBTrees":
@@ -207,11 +276,28 @@ class XGBTrees:
         return self.predict_device(X).cpu().numpy()
 
 
+def validate_oblivious(split_feature, split_border, nan_true, tree_first_split, tree_first_leaf, leaf_values, n_features: int) -> None:
+    """Host-side check of flattened oblivious trees before they reach the GPU: feature indices inside [0, n_features) (a NaN-treatment
+    flag per feature), at most 31 levels per tree, 2^depth leaf values per tree inside ``leaf_values``."""
+    sf, fs, fl = np.asarray(split_feature, np.int64), np.asarray(tree_first_split, np.int64), np.asarray(tree_first_leaf, np.int64)
+    if int(n_features) < 1 or np.asarray(nan_true).size < int(n_features):
+        raise ValueError("n_features must be positive, with one NaN-treatment flag per feature")
+    if np.asarray(split_border).size != sf.size:
+        raise ValueError("one border per split")
+    if sf.size and (sf.min() < 0 or sf.max() >= int(n_features)):
+        raise ValueError(f"a float_feature_index is outside [0, {int(n_features)})")
+    if fs.ndim != 1 or fs.size < 2 or fs[0] != 0 or fs[-1] != sf.size or np.any(np.diff(fs) < 0) or np.any(np.diff(fs) > 31):
+        raise ValueError("split offsets must rise from 0 to the split count, at most 31 levels per tree")
+    if fl.size != fs.size - 1 or np.any(fl < 0) or np.any(fl + (1 << np.diff(fs)) > np.asarray(leaf_values).size):
+        raise ValueError("every tree needs 2^depth leaf values inside leaf_values")
+
+
 class CatBoostTrees:
     """Oblivious trees of a CatBoost model exported as JSON + GPU ``predict`` (float features only, single-dimensional output)."""
 
     def __init__(self, split_feature, split_border, nan_true, tree_first_split, tree_first_leaf, leaf_values, n_features: int,
                  scale: float = 1.0, bias: float = 0.0, device="cuda"):
+        validate_oblivious(split_feature, split_border, nan_true, tree_first_split, tree_first_leaf, leaf_values, n_features)
         self.arrays = dict(split_feature=np.ascontiguousarray(split_feature, np.int32), split_border=np.ascontiguousarray(split_border, np.float32),
                            nan_true=np.ascontiguousarray(nan_true, np.uint8), tree_first_split=np.ascontiguousarray(tree_first_split, np.int32),
                            tree_first_leaf=np.ascontiguousarray(tree_first_leaf, np.int64), leaf_values=np.ascontiguousarray(leaf_values, np.float64))
@@ -243,6 +329,8 @@ class CatBoostTrees:
                 if sp.get("split_type", "FloatFeature") != "FloatFeature":
                     raise ValueError("float-feature splits only")
                 fi = int(sp["float_feature_index"])
+                if fi < 0:
+                    raise ValueError("negative float_feature_index")
                 sf.append(flat.get(fi, fi)); sb.append(float(sp["border"]))
             lv = np.asarray(tree["leaf_values"], np.float64)
             if lv.size != 1 << len(splits):

@@ -72,6 +72,7 @@ extern "C" int bbbp_forest_predict(void* stream, const float* X, long n, int n_f
 // base_score + (((l_0 + l_1) + l_2) + ...) summed in float32 in tree order; reg:squarederror returns the margin.
 // The xgboost package is absent from this image: parity of this path is UNPINNED (oracle = the same rule restated in numpy).
 // Kernel 1 walks every (tree, row) pair in parallel into leaf[tree][row]; kernel 2 adds a row's leaves in tree order.
+#define BBBP_GBT_MAX_DEPTH 1024
 namespace {
 __global__ __launch_bounds__(256) void gbt_walk_kernel(const float* X, long n, int n_features, const int* left, const int* right,
                                                       const int* feature, const float* cond, const uint8_t* default_left, const int* root,
@@ -82,12 +83,16 @@ __global__ __launch_bounds__(256) void gbt_walk_kernel(const float* X, long n, i
     const float* x = X + i * (long)n_features;
     int node = root[t];
     int l = left[node];
-    while (l >= 0) {
+    // the host validates the trees (boosters.validate_gbt: children inside the tree, one parent per node, depth <= 1024); the walk is
+    // bounded all the same, so that arrays handed to the C ABI directly cannot spin a wave for ever: NaN marks a walk that gave up
+    int steps = 0;
+    while (l >= 0 && steps < BBBP_GBT_MAX_DEPTH) {
         const float v = x[feature[node]];
         node = (v != v) ? (default_left[node] ? l : right[node]) : (v < cond[node] ? l : right[node]);
         l = left[node];
+        ++steps;
     }
-    leaf[(long)t * n + i] = cond[node];
+    leaf[(long)t * n + i] = (l >= 0) ? __builtin_nanf("") : cond[node];
 }
 __global__ __launch_bounds__(256) void gbt_sum_kernel(const float* leaf, long n, int n_trees, float base_score, float* out) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;

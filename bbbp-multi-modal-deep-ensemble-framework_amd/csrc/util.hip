@@ -4,7 +4,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <mutex>
-#include <set>
+#include <map>
 #include <utility>
 
 static thread_local char g_err[512] = "";
@@ -15,22 +15,25 @@ thread_local size_t g_bbbp_small_lds_pad = 0;
 thread_local int g_bbbp_wino_side_cus = 0;
 thread_local const unsigned long long* g_bbbp_seed_base = nullptr;
 
-// More than 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, DEVICE): code objects are loaded
-// per device, so a process-wide flag is not enough when one process touches two GPUs.
+// More than 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize per (kernel, DEVICE): code objects are loaded
+// per device, so a process-wide flag is not enough when one process touches two GPUs.  Callers pass sizes that vary at run time
+// (attention: grows with the batch; conv: the CU-reservation pad), so the LARGEST size granted so far is remembered and the attribute
+// is raised again whenever a launch needs more -- a first call at B = 320 must not pin the kernel below what B = 512 needs.
 int bbbp_ensure_dyn_lds(const void* kernel, size_t bytes) {
     static std::mutex mu;
-    static std::set<std::pair<int, const void*>> done;
+    static std::map<std::pair<int, const void*>, size_t> granted;
     int dev = 0;
     BBBP_CHECK_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(mu);
     const auto key = std::make_pair(dev, kernel);
-    if (done.count(key)) return BBBP_OK;
+    const auto it = granted.find(key);
+    if (it != granted.end() && it->second >= bytes) return BBBP_OK;
     hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) {
         bbbp_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", bytes, hipGetErrorString(e));
         return BBBP_ERR_HIP;
     }
-    done.insert(key);
+    granted[key] = bytes;
     return BBBP_OK;
 }
 

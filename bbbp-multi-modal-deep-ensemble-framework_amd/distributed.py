@@ -118,14 +118,15 @@ class OverlappedGradAllReduce:
         self.model, self.group, self.min_world = model, group, int(min_world)
         self.comm = None
         L = _lib.lib()
-        L.bbbp_set_graphs(0)
+        self._graphs_before = L.bbbp_set_graphs(0)        # restored by close(): graph replay is off only while a reducer exists
+        self._closed = False
         params = list(model.parameters())
         offs, o = [], 0
         for p in params:
             offs.append(o); o += p.numel()
         self.total = o
         offs.append(o)
-        desc = model._descriptor(2)
+        desc = model._descriptor(2, draw_seed=False)      # layout query only: the global RNG stream is left untouched
         if L.bbbp_mixed_num_params(ctypes.byref(desc)) != len(params):
             raise RuntimeError("OverlappedGradAllReduce: the model's parameter list is not the fused engine's")
         first, count = ctypes.c_int(0), ctypes.c_int(0)
@@ -150,6 +151,26 @@ class OverlappedGradAllReduce:
         if cur < self.total:
             self.rest.append((cur, self.total))
 
+    def close(self) -> None:
+        """Give graph replay back to the process (the mode it had before this reducer was built).  Idempotent; also runs when the
+        reducer is garbage-collected."""
+        if not getattr(self, "_closed", True):
+            self._closed = True
+            try:
+                from . import _lib
+                _lib.lib().bbbp_set_graphs(self._graphs_before)
+            except Exception:      # noqa: BLE001  (interpreter shutdown)
+                pass
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     def schedule(self):
         """The collectives of one call, in order: (stream, bucket event waited for, lo, hi) -- identical on every rank."""
         return ([("comm", b, lo, hi) for b, lo, hi in self.early] + [("comm", 1, lo, hi) for lo, hi in self.rest]
@@ -157,6 +178,8 @@ class OverlappedGradAllReduce:
 
     def __call__(self, params, average: bool = False) -> int:
         from . import _lib
+        if self._closed:
+            raise RuntimeError("OverlappedGradAllReduce: used after close()")
         world = world_size(self.group)
         if world < self.min_world:
             return 0

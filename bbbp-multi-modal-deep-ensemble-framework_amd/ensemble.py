@@ -149,9 +149,12 @@ def screen(model, forest, stack, fingerprints, images, extra_columns=(), batch_s
                 fp, im = fingerprints[i:i + batch_size], images[i:i + batch_size]
                 nn_col = model(fp, im).reshape(-1)
                 cols = []
+                # the tree learners all read hstack([fingerprint, image]) (805 MB per 4096 molecules): built once per batch
+                feats = torch.cat([fp, im], dim=1) if (forest is not None or boosters) else None
                 if forest is not None:
-                    cols.append(forest.predict_device(torch.cat([fp, im], dim=1)))
-                cols += [bst.predict_device(torch.cat([fp, im], dim=1)).double() for bst in boosters]
+                    cols.append(forest.predict_device(feats))
+                cols += [bst.predict_device(feats).double() for bst in boosters]
+                del feats
                 cols += [torch.as_tensor(c[i:i + batch_size], device=nn_col.device) for c in extra_columns]
                 out.append(stack.predict_device(nn_col, *cols))
     finally:

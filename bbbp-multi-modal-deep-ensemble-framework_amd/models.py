@@ -205,7 +205,9 @@ class MixedInputModel(nn.Module):
         flat = flat_view_of(params)
         return flat if flat is not None else flatten_parameters(self)
 
-    def _descriptor(self, batch: int, inference: bool = False) -> _lib.MixedDesc:
+    def _descriptor(self, batch: int, inference: bool = False, draw_seed: bool = True) -> _lib.MixedDesc:
+        """``draw_seed=False``: a descriptor for layout queries only (parameter count, gradient buckets) -- it must not consume the
+        global RNG stream, or constructing a reducer would shift every later dropout seed."""
         p, dff, layers = 0.0, 2048, 0
         if self.NUM_LAYERS > 0:
             layers = len(self.fingerprint_transformer.layers)
@@ -217,7 +219,7 @@ class MixedInputModel(nn.Module):
             if float(layer0.self_attn.dropout) != p:
                 raise RuntimeError("attention dropout must equal the layer dropout")
         training = bool(self.training)
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (training and p > 0) else 0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (training and p > 0 and draw_seed) else 0
         return _lib.MixedDesc(batch=batch, fingerprint_size=self.fingerprint_size, nhead=self.nhead, num_layers=layers,
                               dim_feedforward=dff, training=int(training), dropout_p=p, seed=seed, need_input_grad=0,
                               fusion=0 if self.FUSION == "attention" else 1, inference=int(inference and not training))

@@ -126,22 +126,31 @@ def standardize_features(fingerprints_u8: torch.Tensor, images: torch.Tensor, ba
 class HostFedBatches:
     """Streaming input for data that lives in HOST memory (the step before the hot path: the reference's DataLoader hands over
     per-sample ``torch.tensor`` copies and one synchronous ``.to(device)`` per batch, Models/...20250113.py:31-45,184-186 --
-    197 KB per molecule, 101 MB per batch of 512).  The dataset is pinned once; batches are consecutive rows (wrapping around),
-    copied by DMA on a dedicated copy stream into one of two device buffers ONE BATCH AHEAD of the step that consumes them, so
-    the transfer of batch k+1 runs under the compute of batch k.  ``next()`` makes the current stream wait for the batch's copy
+    197 KB per molecule, 101 MB per batch of 512).  Batches are consecutive rows (wrapping around), copied by DMA on a dedicated copy
+    stream into one of two device buffers ONE BATCH AHEAD of the step that consumes them, so the transfer of batch k+1 runs under
+    the compute of batch k.  Host memory: a dataset that is already pinned (or ``pin="all"``, for sets that comfortably fit) is
+    read in place; otherwise the rows of a batch are first gathered into one of TWO pinned batch-sized staging buffers -- a
+    screening library is never duplicated into page-locked memory.  ``next()`` makes the current stream wait for the batch's copy
     event and returns device views; a buffer is refilled only after the step that read it has been enqueued (event on the
     compute stream).  The tensors are bit-identical to ``host_rows.to(device)``.
 
     Shuffled epochs over a dataset that fits in HBM (B3DB: 208 MB) should stay device-resident (``training.train_fold``); this
     class is for libraries that do not (screening)."""
 
-    def __init__(self, fingerprints, images, labels, batch_size: int, device, start: int = 0):
+    def __init__(self, fingerprints, images, labels, batch_size: int, device, start: int = 0, pin: str = "staging"):
         self.host = tuple(torch.as_tensor(t).contiguous() for t in (fingerprints, images, labels))
         n = self.host[0].shape[0]
         if any(t.shape[0] != n for t in self.host) or batch_size < 1 or n < 1:
             raise ValueError("HostFedBatches: fingerprints, images and labels must have the same, non-zero number of rows")
-        self.host = tuple(t if t.is_pinned() else t.pin_memory() for t in self.host)
+        if pin not in ("staging", "all"):
+            raise ValueError("HostFedBatches: pin must be 'staging' or 'all'")
+        if pin == "all":
+            self.host = tuple(t if t.is_pinned() else t.pin_memory() for t in self.host)
         self.n, self.batch, self.device = n, int(batch_size), torch.device(device)
+        # tensors that are not page-locked go through two pinned batch-sized staging buffers (one per device buffer)
+        self.stage = [tuple(None if t.is_pinned() else torch.empty((self.batch,) + tuple(t.shape[1:]), dtype=t.dtype).pin_memory()
+                            for t in self.host) for _ in range(2)]
+        self.staged = [torch.cuda.Event() for _ in range(2)]       # the DMA out of staging buffer `slot` has finished
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.bufs = [tuple(torch.empty((self.batch,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device) for t in self.host)
                      for _ in range(2)]
@@ -162,11 +171,19 @@ class HostFedBatches:
         with torch.cuda.stream(self.copy_stream):
             if self.k >= 2:
                 self.copy_stream.wait_event(self.free[slot])          # the step that read this buffer has been enqueued and must finish
+            if self.k >= 2 and any(s is not None for s in self.stage[slot]):
+                self.staged[slot].synchronize()                       # host: the previous DMA out of this staging buffer is done
             off = 0
             for lo, hi in self._rows(self.pos):
-                for dst, src in zip(self.bufs[slot], self.host):
-                    dst[off:off + hi - lo].copy_(src[lo:hi], non_blocking=True)
+                for dst, src, stg in zip(self.bufs[slot], self.host, self.stage[slot]):
+                    if stg is not None:
+                        stg[off:off + hi - lo].copy_(src[lo:hi])      # host gather into page-locked memory (memcpy)
+                        src_rows = stg[off:off + hi - lo]
+                    else:
+                        src_rows = src[lo:hi]
+                    dst[off:off + hi - lo].copy_(src_rows, non_blocking=True)
                 off += hi - lo
+            self.staged[slot].record(self.copy_stream)
             self.ready[slot].record(self.copy_stream)
         self.pos = (self.pos + self.batch) % self.n
 

@@ -271,7 +271,7 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
     if args.host_fed:
         from bbbp_amd.preprocess import HostFedBatches
         hfp, himg, hy = synthetic_b3db(2 * BATCH, F, 20250113 + rank, None)
-        feeder = HostFedBatches(hfp, himg, hy, BATCH, dev)
+        feeder = HostFedBatches(hfp, himg, hy, BATCH, dev, pin="all")       # two batches: pinned whole, read in place by the DMA
         fp = img = y = None
     else:
         fp, img, y = synthetic_b3db(2 * BATCH, F, 20250113 + rank, dev)

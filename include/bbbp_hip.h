@@ -266,7 +266,9 @@ int bbbp_forest_predict(void* stream, const float* X, long n, int n_features, co
 /* ---- gradient-boosted regression trees, prediction (the xgb base learner of the stack, ...20250108.py:186-189; fitted model
  * Models/xgb_model_maccs.pkl) -- XGBoost's predict rule: left when x[feature] < split_condition (float32), the default child when
  * the feature is NaN, leaf value in split_condition[leaf], out = base_score + float32 sum of the leaves in tree order.  Node arrays
- * concatenated over trees (child indices rebased, -1 = leaf), root[t] = first node of tree t; leaf_scratch: n_trees * n floats. */
+ * concatenated over trees (child indices rebased, -1 = leaf), root[t] = first node of tree t; leaf_scratch: n_trees * n floats.
+ * The caller validates the arrays (boosters.validate_gbt: children inside their tree, one parent per node, split indices below
+ * n_features); the device walk stops after 1024 levels all the same and then yields NaN for that (tree, row). */
 int bbbp_gbt_predict(void* stream, const float* X, long n, int n_features, const int* left, const int* right, const int* feature,
                      const float* split_condition, const uint8_t* default_left, const int* root, int n_trees, float base_score,
                      float* leaf_scratch, float* out);

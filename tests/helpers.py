@@ -89,6 +89,45 @@ def assert_close_or_as_accurate_as_fp32(actual, ref64, ref32, rtol=RTOL, atol_fr
         f"{what}: max err {err.max():.3e} vs float64 at scale {scale:.3e}; torch-CPU float32 is off by {ref_err:.3e}")
 
 
+def oracle_train(state, fp, img, y, orders, batch_size, faithful, test, lrs=None, dtype=torch.float32):
+    """The reference's per-fold loop (Models/...20250113.py:165-241, incl. the train-once / eval-thereafter quirk when ``faithful``)
+    run with the CPU oracle and the oracle's AdamW, in ``dtype`` (float32 = the reference's own precision; float64 = the yardstick
+    both float32 implementations are measured against).  Returns (mean training loss per epoch, predictions on ``test``)."""
+    from oracle import reference_cpu as oracle
+    cast = (lambda t: t.detach().cpu().to(dtype)) if dtype != torch.float32 else (lambda t: t.detach().cpu())
+    p = {k: (cast(v) if v.dtype.is_floating_point else v.detach().cpu()).clone().requires_grad_(v.dtype.is_floating_point and "running" not in k)
+         for k, v in state.items()}
+    fp, img, y = cast(fp), cast(img), cast(y)
+    test = (cast(test[0]), cast(test[1]))
+    keys = [k for k, v in p.items() if v.requires_grad]
+    m = {k: torch.zeros_like(p[k]) for k in keys}; v2 = {k: torch.zeros_like(p[k]) for k in keys}
+    step, training_mode, losses = 0, True, []
+    for ep, order in enumerate(orders):
+        if not faithful:
+            training_mode = True
+        tot, nb = 0.0, 0
+        for i in range(0, len(order), batch_size):
+            idx = torch.as_tensor(order[i:i + batch_size])
+            for k in keys:
+                p[k].grad = None
+            st = {}
+            loss = oracle.mse_loss(oracle.mixed_input_forward(p, fp[idx], img[idx], training=training_mode, bn_state=st), y[idx])
+            loss.backward()
+            step += 1
+            with torch.no_grad():
+                for k in keys:
+                    oracle.adamw_step(p[k], p[k].grad, m[k], v2[k], step, **({} if lrs is None else {"lr": lrs[ep]}))
+                for k, val in st.items():
+                    p[k] = val
+            tot += float(loss.detach()); nb += 1
+        losses.append(tot / nb)
+        training_mode = False                        # the validation pass leaves the model in eval mode
+    with torch.no_grad():
+        preds = torch.cat([oracle.mixed_input_forward(p, test[0][i:i + batch_size], test[1][i:i + batch_size], training=False).reshape(-1)
+                           for i in range(0, test[0].shape[0], batch_size)])
+    return losses, preds
+
+
 # ---- multi-process launcher for the distributed tests ---------------------------------------------------------------------------
 _RENDEZVOUS_ERRORS = ("Address already in use", "EADDRINUSE", "Connection refused", "connection refused", "failed to connect",
                       "The server socket has failed to listen")

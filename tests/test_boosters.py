@@ -219,3 +219,101 @@ def test_gpu_catboost_predict_is_bit_exact_against_the_oracle(n, n_trees, depth)
     got = m.predict(X)
     assert got.dtype == np.float64 and np.array_equal(got, want)
     assert np.array_equal(m.predict_device(torch.from_numpy(X), rows_per_call=301).cpu().numpy(), want)
+
+
+# ---- untrusted model files: corrupted arrays must be refused on the host, before any array reaches the GPU --------
+def _flat(seed=11):
+    return list(boosters.XGBTrees.flatten(random_model(seed, n_trees=3, n_features=20, depth=5)))
+
+
+@pytest.mark.parametrize("corrupt", ["feature_too_large", "feature_negative", "child_outside_tree", "cycle", "two_parents", "half_leaf",
+                                     "length_mismatch", "root_is_child", "bad_offsets"])
+def test_corrupted_gbtree_arrays_are_refused(corrupt):
+    left, right, feature, cond, dleft, root, nf, base = _flat()
+    left, right, feature = left.copy(), right.copy(), feature.copy()
+    inner = np.flatnonzero(left >= 0)
+    node = int(inner[1])
+    if corrupt == "feature_too_large":
+        feature[node] = nf
+    elif corrupt == "feature_negative":
+        feature[node] = -3
+    elif corrupt == "child_outside_tree":
+        left[node] = int(root[1]) + 1 if node < root[1] else 0          # a node of another tree
+    elif corrupt == "cycle":
+        left[int(left[node])] = node; right[int(left[node])] = node      # the child points back at its parent
+    elif corrupt == "two_parents":
+        right[node] = left[node]
+    elif corrupt == "half_leaf":
+        right[node] = -1
+    elif corrupt == "length_mismatch":
+        cond = cond[:-1]
+    elif corrupt == "root_is_child":
+        left[node] = int(root[np.searchsorted(root, node, side="right") - 1])
+    elif corrupt == "bad_offsets":
+        root = root.copy(); root[1] = root[2]
+    with pytest.raises(ValueError):
+        boosters.validate_gbt(left, right, feature, cond, dleft, root, nf)
+    with pytest.raises(ValueError):
+        boosters.XGBTrees(left, right, feature, cond, dleft, root, nf, base, device="cpu")
+
+
+def test_valid_gbtree_arrays_pass_and_report_their_depth():
+    left, right, feature, cond, dleft, root, nf, base = _flat()
+    assert 2 <= boosters.validate_gbt(left, right, feature, cond, dleft, root, nf) <= 5
+    g = np.load(GOLD)                                       # the shipped model's first trees
+    assert 1 <= boosters.validate_gbt(g["left"], g["right"], g["feature"], g["cond"], g["default_left"], g["root"], int(g["n_features"])) <= 30
+    # a chain deeper than the device walk's bound is refused
+    n = boosters.GBT_MAX_DEPTH + 2
+    left = np.arange(1, 2 * n + 1, 2); right = left + 1                  # node i -> children 2i+1 (inner), 2i+2 (leaf) laid out pairwise
+    L = np.full(2 * n + 1, -1); R = np.full(2 * n + 1, -1)
+    idx = np.concatenate([[0], np.arange(1, 2 * n - 1, 2)])[:n]
+    L[idx] = idx * 0 + np.concatenate([[1], np.arange(3, 2 * n + 1, 2)])[:n]; R[idx] = L[idx] + 1
+    with pytest.raises(ValueError, match="deeper"):
+        boosters.validate_gbt(L, R, np.zeros_like(L), np.zeros(L.size, np.float32), np.zeros(L.size, np.uint8), np.array([0, L.size]), 4)
+
+
+def test_a_model_document_with_ragged_tree_arrays_is_refused():
+    doc = random_model(5, 2, 10, 3)
+    t = doc["Model"]["learner"]["gradient_booster"]["model"]["trees"][1]
+    t["split_indices"] = t["split_indices"][:-1]
+    with pytest.raises(ValueError):
+        boosters.XGBTrees.flatten(doc)
+    doc = random_model(5, 2, 10, 3)
+    doc["Model"]["learner"]["gradient_booster"]["model"]["trees"][0]["split_indices"][0] = 10          # == num_feature
+    with pytest.raises(ValueError):
+        boosters.XGBTrees.from_raw(ubj(doc), device="cpu")
+
+
+def test_truncated_or_padded_ubjson_is_refused():
+    raw = ubj(random_model(6, 2, 10, 3))
+    assert boosters.parse_ubjson(raw)["Model"]["version"] == [2, 0, 3]
+    for cut in (1, 7, len(raw) // 3, len(raw) // 2, len(raw) - 1):
+        with pytest.raises(ValueError):
+            boosters.parse_ubjson(raw[:cut])
+    with pytest.raises(ValueError, match="trailing"):
+        boosters.parse_ubjson(raw + b"\x00\x00")
+    with pytest.raises(ValueError, match="negative"):
+        boosters.parse_ubjson(b"[$d#L" + struct.pack(">q", -4))
+    # a typed array whose payload is shorter than its count (the remainder a multiple of the item size) is not silently shortened
+    with pytest.raises(ValueError, match="truncated"):
+        boosters.parse_ubjson(b"[$d#L" + struct.pack(">q", 4) + struct.pack(">2f", 1.0, 2.0))
+
+
+def test_corrupted_oblivious_trees_are_refused():
+    import json
+    doc = random_catboost_doc(2, n_trees=3, n_features=8, depth=4)
+    good = boosters.CatBoostTrees.flatten(json.loads(json.dumps(doc)))
+    boosters.validate_oblivious(*good[:7])
+    bad = json.loads(json.dumps(doc)); bad["oblivious_trees"][1]["splits"][0]["float_feature_index"] = -1
+    with pytest.raises(ValueError):
+        boosters.CatBoostTrees.flatten(bad)
+    sf, sb, nt, fs, fl, lv, nf, scale, bias = good
+    for args in ((np.where(np.arange(sf.size) == 0, nf, sf), sb, nt, fs, fl, lv, nf),       # feature index == n_features
+                 (sf, sb, nt, fs, fl, lv[:-1], nf),                                          # last tree's leaves cut short
+                 (sf, sb[:-1], nt, fs, fl, lv, nf),                                          # one border missing
+                 (sf, sb, nt[:nf - 1], fs, fl, lv, nf),                                      # NaN flags shorter than the feature count
+                 (sf, sb, nt, fs[::-1].copy(), fl, lv, nf)):                                 # offsets not rising
+        with pytest.raises(ValueError):
+            boosters.validate_oblivious(*args)
+        with pytest.raises(ValueError):
+            boosters.CatBoostTrees(*args, scale, bias, device="cpu")

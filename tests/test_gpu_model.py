@@ -327,7 +327,7 @@ def test_fused_head_backward_matches_the_launch_per_op_chain(dev, B, training):
         assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), float(b.abs().max()))
 
 
-@pytest.mark.parametrize("conv2_form", [0, 3, 28], ids=["direct", "winograd", "split-bf16"])
+@pytest.mark.parametrize("conv2_form", [0, 3, 60], ids=["direct", "winograd", "split-bf16-default"])
 def test_real_molecule_images_against_oracle(dev, conv2_form):
     """The eight depictions shipped with the reference (tests/golden/img, white background: large flat regions, i.e. exact
     ties inside pooling windows in BOTH conv stages) through the full model: output, loss and every gradient element against
@@ -500,3 +500,27 @@ def test_two_host_threads_drive_two_models(dev):
         assert torch.equal(serial[seed][0], parallel[seed][0])
         for k, g in serial[seed][1].items():
             assert torch.equal(g, parallel[seed][1][k]), k
+
+
+def test_dynamic_lds_grant_grows_with_the_batch_in_one_process(dev):
+    """the >64 KB dynamic-LDS opt-in is remembered per (kernel, device) as the LARGEST size granted; a later launch
+    that needs more raises it again.  F = 2048 (head_dim 8: attn_small_* kernels whose LDS grows with the batch) at B = 320
+    (backward ~66 KB) and then B = 512 (~95 KB) in the same process, and a forward at B = 640 followed by B = 960 -- before the
+    fix the second launch of each pair was refused with hipErrorInvalidValue."""
+    m = build(2048, 7, dev)
+    zero_dropout(m)
+    m.train()
+    for B in (320, 512):
+        fp, img, y = synth_inputs(B, B, 2048, 49152)
+        out = m(fp.to(dev), img.to(dev))
+        torch.nn.MSELoss()(out.squeeze(), y.to(dev)).backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all() and all(torch.isfinite(q.grad).all() for q in m.parameters())
+        m.zero_grad(set_to_none=True)
+    m.eval()
+    with torch.no_grad():
+        for B in (640, 960):
+            fp, img, _ = synth_inputs(B, B, 2048, 49152)
+            out = m(fp.to(dev), img.to(dev))
+            torch.cuda.synchronize()
+            assert out.shape == (B, 1) and torch.isfinite(out).all()

@@ -19,11 +19,9 @@ def oracle_params(m, double=True):
             .requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in m.state_dict().items()}
 
 
-@pytest.mark.parametrize("conv2_form", [28, 3, 0], ids=["split-bf16", "winograd", "direct"])
-def test_headline_batch_fwd_bwd_against_oracle(dev, conv2_form):
-    """BASELINE config 3 exactly as bench.py runs it (B = 512, F = 167, train mode, branch overlap ON; conv2 in its default split-bf16
-    form, as Winograd on the 192-CU partition, and in the direct f32 form) with dropout 0: output, loss, BatchNorm running statistics and EVERY element of
-    every non-degenerate gradient against the float64 oracle.
+def check_b512_step_against_float64(dev, F, seed, conv_mask, max_flips=8):
+    """One B = 512 training step (train mode, branch overlap ON, dropout 0) of MixedInputModel(F): output, loss, BatchNorm running
+    statistics and EVERY element of every non-degenerate gradient against the float64 oracle.
 
     ReLU kinks: a step has 6.3 M hidden FFN activations, and a float32 pre-activation carries ~1e-7 of rounding, so in about
     every second step ONE of them lands on the other side of zero than in float64 (measured: tools/exp_b512_accuracy.py).  That
@@ -32,8 +30,8 @@ def test_headline_batch_fwd_bwd_against_oracle(dev, conv2_form):
     GPU's own FFN ReLU decisions (bbbp_mixed_debug_ffn_gate), after checking that they differ from float64's only where the
     float64 pre-activation is within 2e-6 of zero, and at no more than a handful of elements."""
     L = _lib.lib()
-    B, F = 512, 167
-    m = build(F, 20250113, dev)
+    B = 512
+    m = build(F, seed, dev)
     zero_dropout(m)
     m.train()
     m.keep_workspace = True
@@ -41,7 +39,7 @@ def test_headline_batch_fwd_bwd_against_oracle(dev, conv2_form):
     p = oracle_params(m)                                 # before the forward call updates the BatchNorm running statistics
     p32 = oracle_params(m, double=False)                 # the reference's own precision: yardstick for the ill-conditioned sums
     old_w, old_o = L.bbbp_get_conv_winograd(), L.bbbp_set_overlap(1)
-    _lib.check(L.bbbp_set_conv_winograd(conv2_form), "bbbp_set_conv_winograd")
+    _lib.check(L.bbbp_set_conv_winograd(conv_mask), "bbbp_set_conv_winograd")
     try:
         out = m(fp.to(dev), img.to(dev))
         gates = [g.cpu() for g in m.debug_ffn_gates()]
@@ -61,8 +59,8 @@ def test_headline_batch_fwd_bwd_against_oracle(dev, conv2_form):
         flips += int(diff.sum())
         if diff.any():
             assert float(pre[diff].abs().max()) <= 2e-6 * float(pre.abs().mean()), f"layer {l}: ReLU decision differs away from zero"
-    assert flips <= 8, f"{flips} ReLU decisions differ from float64"
-    assert_close(out.detach().cpu().numpy(), free_out.numpy(), rtol=1e-4, atol_frac=2e-5, what="B=512 train output")
+    assert flips <= max_flips, f"{flips} ReLU decisions differ from float64"
+    assert_close(out.detach().cpu().numpy(), free_out.numpy(), rtol=1e-4, atol_frac=2e-5, what=f"F={F} B=512 train output")
     # gradients of the function with those decisions
     st = {}
     ref_out = oracle.mixed_input_forward(p, fp.double(), img.double(), training=True, bn_state=st, ffn_gates=gates)
@@ -73,6 +71,7 @@ def test_headline_batch_fwd_bwd_against_oracle(dev, conv2_form):
     sd = m.state_dict()
     for k in ("fc.2.running_mean", "fc.2.running_var"):
         assert_close(sd[k].cpu().numpy(), st[k].numpy(), rtol=1e-4, what=k)
+    checked = 0
     for k, q in m.named_parameters():
         if k.startswith(FUSION):
             continue
@@ -81,6 +80,24 @@ def test_headline_batch_fwd_bwd_against_oracle(dev, conv2_form):
             assert_close_or_as_accurate_as_fp32(q.grad.cpu().numpy(), p[k].grad.numpy(), p32[k].grad.numpy(), what=k)
         else:
             assert_close(q.grad.cpu().numpy(), p[k].grad.numpy(), rtol=1e-4, atol_frac=5e-5, what=k)
+        checked += 1
+    return checked
+
+
+@pytest.mark.parametrize("conv_mask", [60, 3, 0], ids=["split-bf16-default", "winograd", "direct"])
+def test_headline_batch_fwd_bwd_against_oracle(dev, conv_mask):
+    """BASELINE config 3 exactly as bench.py runs it: B = 512, F = 167, the library's DEFAULT conv mask 60 (conv2 forward / data
+    gradient / weight gradient AND conv1's weight gradient in the split-bf16 form -- conv_b3_wgrad3_kernel at its B = 512 slab
+    count), and the two all-float32 alternatives (Winograd on the 192-CU partition, direct)."""
+    assert _lib.lib().bbbp_get_conv_winograd() == 60, "the library default changed: run the B = 512 step under the new default too"
+    assert check_b512_step_against_float64(dev, 167, 20250113, conv_mask) == 90
+
+
+def test_morgan_2048_batch_512_every_gradient_against_oracle(dev):
+    """BASELINE config 4 at its benchmarked shape: F = 2048 (nhead 256, head_dim 8: fused small-head attention; 160 M parameters;
+    every encoder GEMM on the 128 x 128 split-bf16 plan, wide-row LayerNorm), B = 512, default conv forms -- every non-degenerate
+    gradient tensor, element for element, at the tolerances of the F = 167 step."""
+    assert check_b512_step_against_float64(dev, 2048, 7, 60) == 90
 
 
 def test_screening_batch_4096_eval_and_screen(dev):

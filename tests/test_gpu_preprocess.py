@@ -60,16 +60,28 @@ def test_chunked_standard_scaler_matches_sklearn(dev):
     assert float(np.abs(got_fp[:, 0].cpu().numpy()).max()) == 0.0
 
 
-def test_host_fed_batches_are_bit_identical_to_synchronous_copies(dev):
-    """preprocess.HostFedBatches: pinned dataset, copy stream, two device buffers filled one batch ahead -- every batch equals the
+@pytest.mark.parametrize("pin", ["staging", "all", "caller"])
+def test_host_fed_batches_are_bit_identical_to_synchronous_copies(dev, pin):
+    """preprocess.HostFedBatches: copy stream, two device buffers filled one batch ahead -- every batch equals the
     synchronous `rows.to(device)` bit for bit, across the wrap-around, while a consumer kernel is still reading the previous
-    buffer (the consumer here is a slow elementwise chain on the compute stream)."""
+    buffer (the consumer here is a slow elementwise chain on the compute stream).  Three host-memory modes: pageable data through
+    the two pinned batch-sized staging buffers (the default: the dataset is never duplicated into page-locked memory), the whole
+    dataset pinned by the loader, and data the caller pinned (read in place)."""
     import torch
     from bbbp_amd.preprocess import HostFedBatches
     g = torch.Generator().manual_seed(0)
     n, F, I, B = 37, 167, 49152, 8
     fp = torch.randn(n, F, generator=g); img = torch.randn(n, I, generator=g); y = torch.randn(n, generator=g)
-    feeder = HostFedBatches(fp, img, y, B, dev)
+    if pin == "caller":
+        feeder = HostFedBatches(fp.pin_memory(), img.pin_memory(), y.pin_memory(), B, dev)
+        assert all(s is None for s in feeder.stage[0]) and all(t.is_pinned() for t in feeder.host)
+    else:
+        feeder = HostFedBatches(fp, img, y, B, dev, pin=pin)
+        if pin == "staging":
+            assert not any(t.is_pinned() for t in feeder.host)                 # the dataset itself stays pageable ...
+            assert all(s.is_pinned() and s.shape[0] == B for s in feeder.stage[0] + feeder.stage[1])     # ... two batches are page-locked
+        else:
+            assert all(t.is_pinned() for t in feeder.host)
     sums = []
     for k in range(12):                                  # 96 rows: wraps the 37-row dataset twice
         bfp, bimg, by = feeder.next()
@@ -85,3 +97,5 @@ def test_host_fed_batches_are_bit_identical_to_synchronous_copies(dev):
         assert torch.equal(cimg.cpu(), img[rows]) and torch.equal(cfp.cpu(), fp[rows]) and torch.equal(cy.cpu(), y[rows])
     with pytest.raises(ValueError):
         HostFedBatches(fp, img[:5], y, B, dev)
+    with pytest.raises(ValueError):
+        HostFedBatches(fp, img, y, B, dev, pin="everything")

@@ -340,3 +340,38 @@ def test_rdkit_single_head_fusion_golden():
             assert p[k].grad is None or float(p[k].grad.abs().sum()) == 0.0
         else:
             check_summary(g, f"train/B6/{k}", p[k].grad, rtol=2e-4)
+
+
+def test_oof_f64_fixture_is_reproduced_by_the_float32_oracle_on_one_fold():
+    """tests/golden/oof_f64.npz (tools/make_golden.py:case_oof_f64 -- the reference class's seeded initial weights, float64 oracle
+    loop): the drop-in's constructor draws the same weights under the same seed, and the float32 oracle loop lands within
+    many-step float32 rounding of the stored float64 predictions on a fold (the GPU suite checks all ten)."""
+    import bbbp_amd
+    from bbbp_amd import training
+    from helpers import oracle_train
+    g = golden("oof_f64")
+    F, N, BS, EPOCHS, SEED = int(g["meta/F"]), int(g["meta/N"]), int(g["meta/batch_size"]), int(g["meta/epochs"]), int(g["meta/init_seed"])
+    fp, img, y = synth_inputs(int(g["meta/input_seed"]), N, F, 49152)
+    y = (0.5 * fp[:, 0] - 0.3 * fp[:, 1] + 0.2 * y)
+    np.testing.assert_allclose([float(fp.double().sum()), float(img.double().sum()), float(y.double().sum())], g["inputs/checksum"], rtol=1e-12)
+    folds = training.kfold_indices(N, 10)
+    rng = np.random.default_rng(3)
+    orders = [[rng.permutation(len(tr)) for _ in range(EPOCHS)] for tr, _ in folds]
+    k = 3
+    tr, te = folds[k]
+    assert np.array_equal(te, g[f"fold{k}/test_idx"])
+    torch.manual_seed(SEED + k)
+    model = bbbp_amd.MixedInputModel(F, 128)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    sd = model.state_dict()
+    np.testing.assert_allclose([sum(float(v.double().sum()) for v in sd.values() if v.dtype.is_floating_point),
+                                sum(float(v.double().abs().sum()) for v in sd.values() if v.dtype.is_floating_point)],
+                               g[f"fold{k}/param_checksum"], rtol=1e-9)
+    losses, preds = oracle_train({kk: v.clone() for kk, v in sd.items()}, fp[tr], img[tr], y[tr], orders[k], BS, True, (fp[te], img[te]))
+    want = g["nn_f64"][te]
+    np.testing.assert_allclose(losses, g[f"fold{k}/train_loss"], rtol=2e-3)
+    assert np.max(np.abs(preds.numpy() - want)) <= 5e-3 * max(1.0, np.max(np.abs(g["nn_f64"])))

@@ -243,6 +243,46 @@ def case_xgb_head(n_keep=6):
     print("xgb_maccs_head:", hi, "nodes of", int(root[-1]), "| tree 0 bytes", nxt - start)
 
 
+def case_oof_f64():
+    """The network column of the published fold loop (...20250113.py:147-266), all ten folds, by the FLOAT64 oracle: the yardstick for
+    tests/test_gpu_training.py::test_out_of_fold_driver_and_stack_against_oracle_folds.  Per fold the REFERENCE class is constructed
+    under torch.manual_seed(40 + k) (its initial weights are what the drop-in's constructor draws under the same seed -- checked by the
+    parameter checksums stored here), dropout off, and trained by the oracle's faithful loop in float64 on the seeded 96-molecule set
+    the test rebuilds (helpers.synth_inputs(2025, ...), KFold(10, shuffle, random_state=42), batch orders from default_rng(3))."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+    from helpers import oracle_train
+    from sklearn.model_selection import KFold
+    ns = load_classes("Models/multi_input_data_regression_opt_transformer_cnn_20250113.py",
+                      {"MixedDataset", "MultiHeadAttentionFusion", "MixedInputModel"})
+    F, N, BS, EPOCHS, SEED = 64, 96, 32, 2, 40
+    fp, img, y = synth_inputs(2025, N, F, 49152)
+    y = (0.5 * fp[:, 0] - 0.3 * fp[:, 1] + 0.2 * y)
+    folds = list(KFold(10, shuffle=True, random_state=42).split(np.arange(N)))
+    rng = np.random.default_rng(3)
+    orders = [[rng.permutation(len(tr)) for _ in range(EPOCHS)] for tr, _ in folds]
+    nn64 = np.zeros(N)
+    out = {"meta/F": np.array(F), "meta/N": np.array(N), "meta/batch_size": np.array(BS), "meta/epochs": np.array(EPOCHS),
+           "meta/init_seed": np.array(SEED), "meta/input_seed": np.array(2025),
+           "inputs/checksum": np.array([float(fp.double().sum()), float(img.double().sum()), float(y.double().sum())])}
+    for k, (tr, te) in enumerate(folds):
+        torch.manual_seed(SEED + k)
+        model = ns["MixedInputModel"](F, 128)
+        zero_dropout(model)
+        state0 = {kk: v.clone() for kk, v in model.state_dict().items()}
+        out[f"fold{k}/param_checksum"] = np.array([sum(float(v.double().sum()) for v in state0.values() if v.dtype.is_floating_point),
+                                                   sum(float(v.double().abs().sum()) for v in state0.values() if v.dtype.is_floating_point)])
+        losses, preds = oracle_train(state0, fp[tr], img[tr], y[tr], orders[k], BS, True, (fp[te], img[te]), dtype=torch.float64)
+        nn64[te] = preds.numpy()
+        out[f"fold{k}/test_idx"] = np.asarray(te, dtype=np.int64)
+        out[f"fold{k}/train_loss"] = np.asarray(losses)
+        print(f"oof_f64 fold {k}: losses {losses}", flush=True)
+    out["nn_f64"] = nn64
+    path = os.path.join(OUT, "oof_f64.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
@@ -288,6 +328,8 @@ def main():
     case_ops()
     if not only or "xgb_head" in only:
         case_xgb_head()
+    if not only or "oof_f64" in only:
+        case_oof_f64()
 
 
 if __name__ == "__main__":
