@@ -60,6 +60,7 @@ _SIGNATURES = {
     "bbbp_mixed_bucket_param": (c_int, [POINTER(MixedDesc), c_int]),
     "bbbp_mixed_bucket_range": (c_int, [POINTER(MixedDesc), c_int, POINTER(c_int), POINTER(c_int)]),
     "bbbp_mixed_debug_ffn_gate": (c_int, [c_void_p, POINTER(MixedDesc), c_void_p, c_int, c_void_p]),
+    "bbbp_mixed_debug_pool_mask": (c_int, [c_void_p, POINTER(MixedDesc), c_void_p, c_int, c_void_p]),
     "bbbp_set_graphs": (c_int, [c_int]),
     "bbbp_set_fused_head_bwd": (c_int, [c_int]),
     "bbbp_set_fused_encoder": (c_int, [c_int]),

@@ -274,11 +274,20 @@ int join_side(hipStream_t main, SideStream* ss) {
 
 // ---- optional per-section timing with HIP events on the launch stream (bench.py roofline leg) ----
 enum { SEC_CONV1_FWD = 0, SEC_CONV2_FWD, SEC_IMGFC_FWD, SEC_ENCODER_FWD, SEC_HEAD_FWD, SEC_HEAD_BWD, SEC_IMGFC_BWD,
-       SEC_CONV2_WGRAD, SEC_CONV2_DGRAD, SEC_CONV1_WGRAD, SEC_ENCODER_BWD, SEC_FFN1_FWD, SEC_FFN2_FWD, SEC_COUNT };
+       SEC_CONV2_WGRAD, SEC_CONV2_DGRAD, SEC_CONV1_WGRAD, SEC_ENCODER_BWD, SEC_FFN1_FWD, SEC_FFN2_FWD,
+       // the other per-layer kernels of the launch-per-op encoder schedule (one instance per layer and step): chain ...
+       SEC_QKV_FWD, SEC_ATTN_FWD, SEC_OUTPROJ_FWD, SEC_LN_FWD, SEC_LN_BWD, SEC_FFN2_DGRAD, SEC_FFN1_DGRAD, SEC_OUTPROJ_DGRAD, SEC_ATTN_BWD,
+       SEC_QKV_DGRAD,
+       // ... and weight-gradient leaves (leaf stream)
+       SEC_FFN2_WGRAD, SEC_FFN1_WGRAD, SEC_OUTPROJ_WGRAD, SEC_QKV_WGRAD, SEC_COUNT };
+static_assert(SEC_COUNT <= 32, "bbbp_profile_select takes a 32-bit mask");
 const char* const kSectionNames[SEC_COUNT] = {"conv1_fwd", "conv2_fwd", "imgfc_fwd", "encoder_fwd", "head_fwd", "head_bwd",
                                               "imgfc_bwd", "conv2_wgrad", "conv2_dgrad", "conv1_wgrad", "encoder_bwd",
-                                              "ffn1_fwd", "ffn2_fwd"};          // the encoder's two FFN GEMMs, one instance per layer
-constexpr int PROF_MAX = 4096;
+                                              "ffn1_fwd", "ffn2_fwd",          // the encoder's two FFN GEMMs, one instance per layer
+                                              "qkv_fwd", "attn_fwd", "outproj_fwd", "ln_fwd", "ln_bwd", "ffn2_dgrad", "ffn1_dgrad",
+                                              "outproj_dgrad", "attn_bwd", "qkv_dgrad", "ffn2_wgrad", "ffn1_wgrad", "outproj_wgrad",
+                                              "qkv_wgrad"};
+constexpr int PROF_MAX = 16384;
 struct ProfState {
     bool on = false;
     unsigned mask = ~0u;          // sections that record events (bbbp_profile_select)
@@ -569,7 +578,12 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
     for (int l = 0; l < (fused_rows ? 0 : plan.L); ++l) {
         const LayerOff& o = plan.layer[l];
         float* qkv = c.f(o.qkv); float* prob = c.f(o.prob); float* ctx = c.f(o.ctx);
-        TRY(linear_fwd(ce, x, F, P[ix.layer(l, L_INW)], P[ix.layer(l, L_INB)], qkv, 3 * F, B, 3 * F, F, 0));
+        {
+            Section sq(ce.st, SEC_QKV_FWD);
+            TRY(linear_fwd(ce, x, F, P[ix.layer(l, L_INW)], P[ix.layer(l, L_INB)], qkv, 3 * F, B, 3 * F, F, 0));
+        }
+        std::optional<Section> sec_attn;
+        sec_attn.emplace(ce.st, SEC_ATTN_FWD);
         if (plan.flash) {
             TRY(bbbp_attn_small_fwd(ce.st, qkv, ctx, c.f(o.lse), B, F, NH, scale, p_drop, site_seed(d->seed, l, 0)));
         } else {
@@ -582,6 +596,7 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         TRY(bbbp_gemm_f32(ce.st, 0, 0, B, D, B, 1.f, pd, B, qkv + 2 * F, 3 * F, ctx, F, nullptr, nullptr, 0, 0, NH, (long)B * B,
                           D, D, 0, ce.scratch(), ce.scratch_bytes()));
         }
+        sec_attn.reset();
         float* z1 = c.f(o.z1); float* y1 = c.f(o.y1);
         // out_proj -> (dropout) + residual -> norm1: one launch when the output is narrow (gemm.hip: gemm_direct_ln_kernel)
         // OPT-IN (BBBP_FUSED_LINEAR_LN=1), measured slower at B = 512: the 11-wave work-groups need three wave slots on three SIMDs of a CU
@@ -593,7 +608,11 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
             TRY(bbbp_linear_layernorm_fwd(ce.st, ctx, F, P[ix.layer(l, L_OUTW)], P[ix.layer(l, L_OUTB)], x, F, z1, F, y1, F, P[ix.layer(l, L_N1W)],
                                           P[ix.layer(l, L_N1B)], c.f(o.mean1), c.f(o.rstd1), B, F, F, 1e-5f, p_drop, site_seed(d->seed, l, 1)));
         } else {
-        TRY(linear_fwd(ce, ctx, F, P[ix.layer(l, L_OUTW)], P[ix.layer(l, L_OUTB)], z1, F, B, F, F, 0));
+        {
+            Section so(ce.st, SEC_OUTPROJ_FWD);
+            TRY(linear_fwd(ce, ctx, F, P[ix.layer(l, L_OUTW)], P[ix.layer(l, L_OUTB)], z1, F, B, F, F, 0));
+        }
+        Section sl(ce.st, SEC_LN_FWD);
         TRY(bbbp_layernorm_fwd(ce.st, z1, x, y1, P[ix.layer(l, L_N1W)], P[ix.layer(l, L_N1B)], c.f(o.mean1), c.f(o.rstd1), B, F,
                                1e-5f, p_drop, site_seed(d->seed, l, 1)));
         }
@@ -615,8 +634,11 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
             Section sf(ce.st, SEC_FFN2_FWD);
             TRY(linear_fwd(ce, hff, DFF, P[ix.layer(l, L_W2)], P[ix.layer(l, L_B2)], z2, F, B, F, DFF, 0));
         }
-        TRY(bbbp_layernorm_fwd(ce.st, z2, y1, y2, P[ix.layer(l, L_N2W)], P[ix.layer(l, L_N2B)], c.f(o.mean2), c.f(o.rstd2), B, F,
-                               1e-5f, p_drop, site_seed(d->seed, l, 3)));
+        {
+            Section sl(ce.st, SEC_LN_FWD);
+            TRY(bbbp_layernorm_fwd(ce.st, z2, y1, y2, P[ix.layer(l, L_N2W)], P[ix.layer(l, L_N2B)], c.f(o.mean2), c.f(o.rstd2), B, F,
+                                   1e-5f, p_drop, site_seed(d->seed, l, 3)));
+        }
         x = y2;
     }
     // fingerprint_fc (R:79-82, 112) -> combined[:, 0:128]
@@ -900,29 +922,50 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         float* dyout = c.f(g.dyout); float* dz2 = c.f(g.dz2); float* dff = c.f(g.dz2d); float* dhff = c.f(g.dhff);
         float* dy1 = c.f(g.dy1); float* dz1 = c.f(g.dz1); float* dsa = c.f(g.dz1d); float* dqkv = c.f(g.dqkv);
         // norm2: dz2 (residual gradient, flows to y1) and its dropped copy dff (gradient of the FFN output)
-        TRY(bbbp_layernorm_bwd(ce.st, dyout, z2, P[ix.layer(l, L_N2W)], c.f(o.mean2), c.f(o.rstd2), dz2, plan.drop ? dff : nullptr,
-                               nullptr, nullptr, B, F, p_drop, site_seed(d->seed, l, 3)));
+        {
+            Section sl(ce.st, SEC_LN_BWD);
+            TRY(bbbp_layernorm_bwd(ce.st, dyout, z2, P[ix.layer(l, L_N2W)], c.f(o.mean2), c.f(o.rstd2), dz2, plan.drop ? dff : nullptr,
+                                   nullptr, nullptr, B, F, p_drop, site_seed(d->seed, l, 3)));
+        }
         // linear2 input gradient, then ReLU (+ dropout: hff is the post-dropout value, hff > 0 <=> active and kept)
         // the ReLU / dropout mask rides in the GEMM epilogue; the bias gradient (a column sum) is a leaf
         {
+            Section sg(ce.st, SEC_FFN2_DGRAD);
             bbbp_gemm_desc g = gemm_desc(0, 0, B, DFF, F, 1.f, dff, F, P[ix.layer(l, L_W2)], DFF, dhff, DFF);
             g.gate = hff; g.ldg = DFF; g.gate_scale = inv_keep;
             TRY(bbbp_gemm_f32_grouped(ce.st, &g, 1, ce.scratch(), ce.scratch_bytes()));
         }
         // leaves of this half layer (they only read per-layer buffers, so ONE event per half layer orders them all)
         TRY(leaf_after(ce));
-        TRY(linear_bwd_weight_bias(cl, dff, F, hff, DFF, G[ix.layer(l, L_W2)], G[ix.layer(l, L_B2)], B, F, DFF));
-        TRY(linear_bwd_weight_bias(cl, dhff, DFF, y1, F, G[ix.layer(l, L_W1)], G[ix.layer(l, L_B1)], B, DFF, F));
+        {
+            Section sw(cl.st, SEC_FFN2_WGRAD);
+            TRY(linear_bwd_weight_bias(cl, dff, F, hff, DFF, G[ix.layer(l, L_W2)], G[ix.layer(l, L_B2)], B, F, DFF));
+        }
+        {
+            Section sw(cl.st, SEC_FFN1_WGRAD);
+            TRY(linear_bwd_weight_bias(cl, dhff, DFF, y1, F, G[ix.layer(l, L_W1)], G[ix.layer(l, L_B1)], B, DFF, F));
+        }
         // dy1 = dhff W1 + dz2
-        TRY(linear_bwd_input(ce, dhff, DFF, P[ix.layer(l, L_W1)], dy1, F, B, DFF, F, dz2, F));
+        {
+            Section sg(ce.st, SEC_FFN1_DGRAD);
+            TRY(linear_bwd_input(ce, dhff, DFF, P[ix.layer(l, L_W1)], dy1, F, B, DFF, F, dz2, F));
+        }
         // norm1
-        TRY(bbbp_layernorm_bwd(ce.st, dy1, z1, P[ix.layer(l, L_N1W)], c.f(o.mean1), c.f(o.rstd1), dz1, plan.drop ? dsa : nullptr,
-                               nullptr, nullptr, B, F, p_drop, site_seed(d->seed, l, 1)));
+        {
+            Section sl(ce.st, SEC_LN_BWD);
+            TRY(bbbp_layernorm_bwd(ce.st, dy1, z1, P[ix.layer(l, L_N1W)], c.f(o.mean1), c.f(o.rstd1), dz1, plan.drop ? dsa : nullptr,
+                                   nullptr, nullptr, B, F, p_drop, site_seed(d->seed, l, 1)));
+        }
         // out_proj input gradient
-        TRY(linear_bwd_input(ce, dsa, F, P[ix.layer(l, L_OUTW)], dctx, F, B, F, F));
+        {
+            Section sg(ce.st, SEC_OUTPROJ_DGRAD);
+            TRY(linear_bwd_input(ce, dsa, F, P[ix.layer(l, L_OUTW)], dctx, F, B, F, F));
+        }
         // attention backward.  Products that become ready together share a launch (bbbp_gemm_f32_grouped):
         //   dV_h = Pd_h^T dctx_h -> dqkv[:, 2F + hD]   |   dPd_h = dctx_h V_h^T
         const float* pdp = c.f(o.pd);
+        std::optional<Section> sec_attn;
+        sec_attn.emplace(ce.st, SEC_ATTN_BWD);
         if (plan.flash) {
             TRY(bbbp_attn_small_bwd(ce.st, qkv, ctx, c.f(o.lse), dctx, dqkv, B, F, NH, scale, p_drop, site_seed(d->seed, l, 0)));
         } else {
@@ -941,12 +984,21 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
             TRY(bbbp_gemm_f32_grouped(ce.st, g, 2, ce.scratch(), ce.scratch_bytes()));
         }
         }
+        sec_attn.reset();
         TRY(leaf_after(ce));
-        TRY(linear_bwd_weight_bias(cl, dsa, F, ctx, F, G[ix.layer(l, L_OUTW)], G[ix.layer(l, L_OUTB)], B, F, F));
-        TRY(linear_bwd_weight_bias(cl, dqkv, 3 * F, xin, F, G[ix.layer(l, L_INW)], G[ix.layer(l, L_INB)], B, 3 * F, F));
+        {
+            Section sw(cl.st, SEC_OUTPROJ_WGRAD);
+            TRY(linear_bwd_weight_bias(cl, dsa, F, ctx, F, G[ix.layer(l, L_OUTW)], G[ix.layer(l, L_OUTB)], B, F, F));
+        }
+        {
+            Section sw(cl.st, SEC_QKV_WGRAD);
+            TRY(linear_bwd_weight_bias(cl, dqkv, 3 * F, xin, F, G[ix.layer(l, L_INW)], G[ix.layer(l, L_INB)], B, 3 * F, F));
+        }
         TRY(layer_norm_leaves(l));
-        if (l > 0) TRY(linear_bwd_input(ce, dqkv, 3 * F, P[ix.layer(l, L_INW)], c.f(plan.lgrad[l - 1].dyout), F, B, 3 * F, F, dz1, F));
-        else if (d->need_input_grad) TRY(linear_bwd_input(ce, dqkv, 3 * F, P[ix.layer(l, L_INW)], c.f(plan.dA), F, B, 3 * F, F, dz1, F));
+        if (l > 0 || d->need_input_grad) {
+            Section sg(ce.st, SEC_QKV_DGRAD);
+            TRY(linear_bwd_input(ce, dqkv, 3 * F, P[ix.layer(l, L_INW)], l > 0 ? c.f(plan.lgrad[l - 1].dyout) : c.f(plan.dA), F, B, 3 * F, F, dz1, F));
+        }
     }
     {
         // bucket 1 is final when the chain AND the leaves are: make the leaf stream wait for the chain's tail, record there
@@ -1047,6 +1099,17 @@ extern "C" int bbbp_mixed_debug_ffn_gate(void* stream, const bbbp_mixed_desc* d,
     const float* hff = reinterpret_cast<const float*>(static_cast<const char*>(workspace) + plan.layer[layer].hff);
     hipLaunchKernelGGL(positive_gate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), hff, gate, n);
     BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+extern "C" int bbbp_mixed_debug_pool_mask(void* stream, const bbbp_mixed_desc* d, const void* workspace, int stage, uint8_t* mask) {
+    Plan plan;
+    TRY(make_plan(d, &plan));
+    BBBP_CHECK_ARG(workspace && mask, "debug_pool_mask: null pointer");
+    BBBP_CHECK_ARG(stage == 1 || stage == 2, "debug_pool_mask: stage %d (1 = conv1, 2 = conv2)", stage);
+    BBBP_CHECK_ARG(!plan.inference, "debug_pool_mask: an inference workspace keeps no masks");
+    const size_t n = stage == 1 ? (size_t)plan.B * C1 * (IMG / 2) * (IMG / 2) : (size_t)plan.B * IMG_FLAT;
+    const char* src = static_cast<const char*>(workspace) + (stage == 1 ? plan.mask1 : plan.mask2);
+    BBBP_CHECK_HIP(hipMemcpyAsync(mask, src, n, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
     return BBBP_OK;
 }
 extern "C" int bbbp_mixed_bucket_param(const bbbp_mixed_desc* d, int bucket) {

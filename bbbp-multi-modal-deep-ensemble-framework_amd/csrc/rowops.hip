@@ -7,6 +7,7 @@
 // result is bit-reproducible run to run (no float atomics).
 #include "common.h"
 #include "bbbp_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -81,6 +82,132 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dy, con
         dz[(long)row * cols + c] = v;
         if (dx) dx[(long)row * cols + c] = p > 0.f ? v * dropout_scale(seed, (uint64_t)row * cols + c, p, inv_keep) : v;
     }
+}
+
+// Wide rows (the F = 2048 encoder: 8 KB per row).  One wave per row left 512 waves on 1024 SIMDs walking 2048 columns three times
+// with a full Philox block per ELEMENT: 39 / 45 us per call for 16 MB of traffic (0.3 TB/s, profiles/r02_kernel_stats_config4.csv).
+// Here a 256-thread work-group owns a row and keeps it in registers (NV float4 per thread, cols <= 1024 * NV): every byte is
+// read once with 16-byte loads, one Philox block serves the four elements of a float4 (the same stream as dropout_scale: element
+// idx draws component idx & 3 of block idx >> 2), the two row statistics are two block reductions in a fixed order.
+__device__ __forceinline__ float block_sum4(float v, float* red) {     // 4 waves; every thread gets the sum, same order everywhere
+    v = wave_sum(v);
+    __syncthreads();                           // the previous use of `red` has been read
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((red[0] + red[1]) + red[2]) + red[3];
+}
+__device__ __forceinline__ float4 dropout_scale4(uint64_t seed, uint64_t idx4, float p, float inv_keep) {
+    const uint4 r = philox4(seed, idx4);
+    const float k = 1.0f / 16777216.0f;
+    return make_float4((float)(r.x >> 8) * k >= p ? inv_keep : 0.f, (float)(r.y >> 8) * k >= p ? inv_keep : 0.f,
+                       (float)(r.z >> 8) * k >= p ? inv_keep : 0.f, (float)(r.w >> 8) * k >= p ? inv_keep : 0.f);
+}
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_wide_kernel(float* x, const float* r, float* y, const float* gamma,
+                                                                const float* beta, float* mean_out, float* rstd_out,
+                                                                int rows, int cols, float eps, float p, uint64_t seed_in, const unsigned long long* seed_base) {
+    const uint64_t seed = effective_seed(seed_in, seed_base);
+    BBBP_HIGH_PRIO();
+    __shared__ float red[4];
+    const int t = threadIdx.x, nq = cols >> 2;
+    const long row = blockIdx.x;
+    float4* xr = reinterpret_cast<float4*>(x + row * cols);
+    const float4* rr = r ? reinterpret_cast<const float4*>(r + row * cols) : nullptr;
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int q = t + i * 256;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < nq) {
+            v[i] = xr[q];
+            if (p > 0.f) {
+                const float4 k = dropout_scale4(seed, ((uint64_t)row * cols >> 2) + q, p, inv_keep);
+                v[i].x *= k.x; v[i].y *= k.y; v[i].z *= k.z; v[i].w *= k.w;
+            }
+            if (rr) { const float4 a = rr[q]; v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w; }
+            xr[q] = v[i];
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = block_sum4(s, red) / cols;
+    float qd = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (t + i * 256 < nq) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            qd += (a * a + b * b) + (c * c + d * d);
+        }
+    const float rstd = rsqrtf(block_sum4(qd, red) / cols + eps);
+    float4* yr = reinterpret_cast<float4*>(y + row * cols);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int q = t + i * 256;
+        if (q < nq) {
+            const float4 g = g4[q], b = b4[q];
+            yr[q] = make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                                (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+        }
+    }
+    if (t == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const float* dy, const float* z, const float* gamma,
+                                                                const float* mean, const float* rstd, float* dz, float* dx,
+                                                                int rows, int cols, float p, uint64_t seed_in, const unsigned long long* seed_base) {
+    const uint64_t seed = effective_seed(seed_in, seed_base);
+    BBBP_HIGH_PRIO();
+    __shared__ float red[4];
+    const int t = threadIdx.x, nq = cols >> 2;
+    const long row = blockIdx.x;
+    const float4* dyr = reinterpret_cast<const float4*>(dy + row * cols);
+    const float4* zr = reinterpret_cast<const float4*>(z + row * cols);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float mu = mean[row], rs = rstd[row];
+    float4 g[NV], xh[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int q = t + i * 256;
+        g[i] = xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < nq) {
+            const float4 d = dyr[q], w = g4[q], zz = zr[q];
+            g[i] = make_float4(d.x * w.x, d.y * w.y, d.z * w.z, d.w * w.w);
+            xh[i] = make_float4((zz.x - mu) * rs, (zz.y - mu) * rs, (zz.z - mu) * rs, (zz.w - mu) * rs);
+            s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+            s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+        }
+    }
+    s1 = block_sum4(s1, red) / cols;
+    s2 = block_sum4(s2, red) / cols;
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    float4* dzr = reinterpret_cast<float4*>(dz + row * cols);
+    float4* dxr = dx ? reinterpret_cast<float4*>(dx + row * cols) : nullptr;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int q = t + i * 256;
+        if (q < nq) {
+            const float4 v = make_float4(rs * (g[i].x - s1 - xh[i].x * s2), rs * (g[i].y - s1 - xh[i].y * s2),
+                                         rs * (g[i].z - s1 - xh[i].z * s2), rs * (g[i].w - s1 - xh[i].w * s2));
+            dzr[q] = v;
+            if (dxr) {
+                if (p > 0.f) {
+                    const float4 k = dropout_scale4(seed, ((uint64_t)row * cols >> 2) + q, p, inv_keep);
+                    dxr[q] = make_float4(v.x * k.x, v.y * k.y, v.z * k.z, v.w * k.w);
+                } else {
+                    dxr[q] = v;
+                }
+            }
+        }
+    }
+}
+// the wide form serves rows of 1024..4096 columns in whole float4s (gfx950 global loads need 4-byte alignment only)
+inline int ln_wide_nv(int cols) {
+    static const int on = [] { const char* e = getenv("BBBP_LN_WIDE"); return e ? atoi(e) : 1; }();
+    return (on && cols >= 1024 && cols <= 4096 && cols % 4 == 0) ? (cols + 1023) / 1024 : 0;
 }
 
 // column sums over rows of (a) dy * xhat and (b) dy:  LayerNorm dgamma / dbeta.
@@ -445,8 +572,18 @@ extern "C" int bbbp_layernorm_fwd(void* stream, float* x_inout_z, const float* r
     BBBP_CHECK_ARG(rows >= 0 && cols > 0, "layernorm: bad shape %d x %d", rows, cols);
     BBBP_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "layernorm: bad dropout %f", dropout_p);
     if (rows == 0) return BBBP_OK;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), g_bbbp_small_lds_pad, ST, x_inout_z, residual, y, gamma, beta,
-                       mean, rstd, rows, cols, eps, dropout_p, seed, g_bbbp_seed_base);
+#define BBBP_LN_FWD_WIDE(NV) hipLaunchKernelGGL(layernorm_fwd_wide_kernel<NV>, dim3(rows), dim3(256), g_bbbp_small_lds_pad, ST, x_inout_z, residual, \
+                                                y, gamma, beta, mean, rstd, rows, cols, eps, dropout_p, seed, g_bbbp_seed_base)
+    switch (ln_wide_nv(cols)) {
+        case 1: BBBP_LN_FWD_WIDE(1); break;
+        case 2: BBBP_LN_FWD_WIDE(2); break;
+        case 3: BBBP_LN_FWD_WIDE(3); break;
+        case 4: BBBP_LN_FWD_WIDE(4); break;
+        default:
+            hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), g_bbbp_small_lds_pad, ST, x_inout_z, residual, y, gamma, beta,
+                               mean, rstd, rows, cols, eps, dropout_p, seed, g_bbbp_seed_base);
+    }
+#undef BBBP_LN_FWD_WIDE
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }
@@ -458,8 +595,18 @@ extern "C" int bbbp_layernorm_bwd(void* stream, const float* dy, const float* z,
     // dz == NULL skips the input gradient, dgamma == NULL skips the parameter gradients (the engine runs the two
     // halves on different streams: the parameter gradients are off the critical dependency chain)
     if (rows > 0 && dz) {
-        hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), g_bbbp_small_lds_pad, ST, dy, z, gamma, mean, rstd, dz, dx,
-                           rows, cols, dropout_p, seed, g_bbbp_seed_base);
+#define BBBP_LN_BWD_WIDE(NV) hipLaunchKernelGGL(layernorm_bwd_wide_kernel<NV>, dim3(rows), dim3(256), g_bbbp_small_lds_pad, ST, dy, z, gamma, mean, \
+                                                rstd, dz, dx, rows, cols, dropout_p, seed, g_bbbp_seed_base)
+        switch (ln_wide_nv(cols)) {
+            case 1: BBBP_LN_BWD_WIDE(1); break;
+            case 2: BBBP_LN_BWD_WIDE(2); break;
+            case 3: BBBP_LN_BWD_WIDE(3); break;
+            case 4: BBBP_LN_BWD_WIDE(4); break;
+            default:
+                hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), g_bbbp_small_lds_pad, ST, dy, z, gamma, mean, rstd, dz, dx,
+                                   rows, cols, dropout_p, seed, g_bbbp_seed_base);
+        }
+#undef BBBP_LN_BWD_WIDE
         BBBP_CHECK_LAUNCH();
     }
     if (dgamma) {

@@ -238,6 +238,21 @@ class MixedInputModel(nn.Module):
             gates.append(g)
         return gates
 
+    def debug_pool_masks(self):
+        """Test hook: the u8 pooling / ReLU decisions ([B,32,64,64], [B,64,32,32]) of the two conv stages in the most recent forward
+        call made with ``self.keep_workspace = True`` (``bbbp_mixed_debug_pool_mask``: 0..3 = first maximum of the 2x2 window in
+        scan order, 4 = ReLU inactive)."""
+        if self not in _LAST_WS:
+            raise RuntimeError("set model.keep_workspace = True before the forward call")
+        desc, ws = _LAST_WS[self]
+        L, masks = _lib.lib(), []
+        for stage, shape in ((1, (desc.batch, 32, 64, 64)), (2, (desc.batch, 64, 32, 32))):
+            m = torch.empty(shape, dtype=torch.uint8, device=ws.device)
+            _lib.check(L.bbbp_mixed_debug_pool_mask(ops._stream(), ctypes.byref(desc), ws.data_ptr(), stage, m.data_ptr()),
+                       "bbbp_mixed_debug_pool_mask")
+            masks.append(m)
+        return masks
+
     def forward(self, fingerprint, image):
         if not fingerprint.is_cuda:
             raise RuntimeError("MixedInputModel runs on MI355X only (HIP kernels); move the model and inputs to 'cuda'. "

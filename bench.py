@@ -64,7 +64,11 @@ CONFIGS = {
     4: dict(F=2048, batch=512, train=True, model="MixedInputModel", layers=6, fusion=True,
             workload="MixedInputModel F=2048 (Morgan, nhead 256, 160 M parameters) + 3x128x128 image (BASELINE config 4); "
                      "forward + MSE + backward + fused AdamW, train mode (dropout 0.1)",
-            metric="molecules/sec fwd+bwd (3-branch ensemble, Morgan-2048, B=512)", candidates=("ffn1_fwd",)),
+            metric="molecules/sec fwd+bwd (3-branch ensemble, Morgan-2048, B=512)",
+            # every GEMM / attention kernel of the encoder layer (one instance per layer and step) and the conv2 kernels: the dominant one
+            # is the section with the largest TOTAL time per step (launches x mean), chosen from an untimed pass before the timed region
+            candidates=("qkv_fwd", "attn_fwd", "outproj_fwd", "ffn1_fwd", "ffn2_fwd", "ffn2_dgrad", "ffn1_dgrad", "outproj_dgrad", "attn_bwd",
+                        "qkv_dgrad", "ffn2_wgrad", "ffn1_wgrad", "outproj_wgrad", "qkv_wgrad", "conv2_fwd", "conv2_dgrad", "conv2_wgrad")),
     5: dict(F=167, batch=4096, train=False, model="MixedInputModel", layers=6, fusion=True,
             workload="screening (BASELINE config 5): eval-mode forward of MixedInputModel F=167 at B=4096 + the shipped linear "
                      "meta-learner over [nn, rf, xgb] with synthetic rf / xgb columns",
@@ -335,9 +339,33 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
     L = _lib.lib()
     nsec = L.bbbp_profile_num_sections()
     names = [L.bbbp_profile_section_name(i).decode() for i in range(nsec)]
+    ms_sum = (ctypes.c_float * nsec)()
+    cnt = (ctypes.c_int * nsec)()
     # HIP events on the launch stream, recorded INSIDE the timed region, around the candidates for the dominant kernel only;
     # the full per-section breakdown comes from an untimed pass below
-    L.bbbp_profile_select(sum(1 << i for i, n in enumerate(names) if n in cfg["candidates"]))
+    timed_sections = set(cfg["candidates"])
+    per_step_pre = {}
+    if len(timed_sections) > 4:
+        # many candidates (config 4: every encoder GEMM / attention kernel, 6 instances each): events around all of them would cost
+        # the timed region ~200 event records per step.  An untimed pass picks the section with the largest total time per step; the
+        # timed region then records that one only.  Every rank makes the pass (collectives included) so the ranks stay in step.
+        L.bbbp_profile_select(sum(1 << i for i, n in enumerate(names) if n in timed_sections))
+        L.bbbp_profile_enable(1)
+        pre_steps = 3
+        for i in range(pre_steps):
+            step(i)
+        torch.cuda.synchronize()
+        _lib.check(L.bbbp_profile_collect(ms_sum, cnt), "bbbp_profile_collect")
+        L.bbbp_profile_enable(0)
+        per_step_pre = {names[i]: dict(ms_per_launch=round(ms_sum[i] / cnt[i], 4), launches_per_step=round(cnt[i] / pre_steps, 2),
+                                       ms_per_step=round(ms_sum[i] / pre_steps, 4)) for i in range(nsec) if cnt[i] and names[i] in timed_sections}
+        dom_pre = max(per_step_pre, key=lambda k: per_step_pre[k]["ms_per_step"])
+        if world > 1:              # all ranks must record the same section: rank 0's choice
+            pick = [dom_pre]
+            dist.broadcast_object_list(pick, src=0)
+            dom_pre = pick[0]
+        timed_sections = {dom_pre}
+    L.bbbp_profile_select(sum(1 << i for i, n in enumerate(names) if n in timed_sections))
     L.bbbp_profile_enable(1)
     fence()
     t0 = time.perf_counter()
@@ -345,11 +373,10 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
         last = step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    ms_sum = (ctypes.c_float * nsec)()
-    cnt = (ctypes.c_int * nsec)()
     _lib.check(L.bbbp_profile_collect(ms_sum, cnt), "bbbp_profile_collect")     # events of the timed region itself
     L.bbbp_profile_enable(0)
     sections = {names[i]: ms_sum[i] / cnt[i] for i in range(nsec) if cnt[i]}
+    launches_per_step = {names[i]: cnt[i] / args.steps for i in range(nsec) if cnt[i]}
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -399,8 +426,16 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
     fl = fwd_flops(BATCH, F, L=cfg["layers"], fusion=cfg["fusion"])
     conv2 = fl["conv2"]
     ffn1 = 2 * BATCH * F * 2048
-    kernel_flops = {"conv2_fwd": conv2, "conv2_dgrad": conv2, "conv2_wgrad": conv2, "ffn1_fwd": ffn1}
+    qkv, outp, attn = 2 * BATCH * F * 3 * F, 2 * BATCH * F * F, 4 * BATCH * BATCH * F
+    kernel_flops = {"conv2_fwd": conv2, "conv2_dgrad": conv2, "conv2_wgrad": conv2,
+                    # per encoder layer: in_proj, QK^T + PV (backward: dV, dP, dQ, dK), out_proj, the two FFN products
+                    "qkv_fwd": qkv, "qkv_dgrad": qkv, "qkv_wgrad": qkv, "outproj_fwd": outp, "outproj_dgrad": outp, "outproj_wgrad": outp,
+                    "ffn1_fwd": ffn1, "ffn1_dgrad": ffn1, "ffn1_wgrad": ffn1, "ffn2_fwd": ffn1, "ffn2_dgrad": ffn1, "ffn2_wgrad": ffn1,
+                    "attn_fwd": attn, "attn_bwd": 2 * attn}
+    # candidates present in the timed region, weighted by how often they run per step: the dominant kernel is the one with the largest
+    # TOTAL time per step (configs 2, 3, 5: the three conv2 kernels, one launch each; config 4: chosen by the untimed pass above)
     cand = {k: sections[k] for k in cfg["candidates"] if k in sections}
+    cand_total = {k: sections[k] * launches_per_step.get(k, 1.0) for k in cand}
     # conv2's forward / data gradient may run as Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36.  The roofline
     # line prices the kernel at the algorithmic (direct) flop count of SURVEY.md 8(d); `winograd` also gives the executed flops.
     wmask = L.bbbp_get_conv_winograd()
@@ -408,7 +443,7 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
     wino = {k: bool(wmask & bit) and not b3[k] for k, bit in (("conv2_fwd", 1), ("conv2_dgrad", 2))}
     roofline = None
     if cand:
-        dom = max(cand, key=cand.get)
+        dom = max(cand_total, key=cand_total.get)
         kf = kernel_flops[dom]
         achieved = kf / (cand[dom] * 1e-3) / 1e12
         traffic, tsrc = traffic_for(cfg_id, dom)
@@ -416,7 +451,8 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
         # of that form is the dense bf16 peak / 6.  `achieved` stays the algorithmic rate of SURVEY.md 8(d); `peak` is the ceiling of the
         # pipe the kernel actually issues to (f32 MFMA peak for the f32 kernels).
         gemm_b3 = bool(L.bbbp_set_gemm_split_bf16(1)); L.bbbp_set_gemm_split_bf16(int(gemm_b3))
-        split_form = b3.get(dom, False) or (dom == "ffn1_fwd" and gemm_b3 and BATCH >= 256 and F >= 512 and F % 32 == 0)
+        is_gemm = dom.split("_")[0] in ("qkv", "outproj", "ffn1", "ffn2")
+        split_form = b3.get(dom, False) or (is_gemm and gemm_b3 and BATCH >= 256 and F >= 512 and F % 32 == 0)
         peak = PEAK_BF16_MFMA_TFLOPS / 6 if split_form else PEAK_F32_MFMA_TFLOPS
         roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=round(peak, 1), unit="TFLOP/s",
                         frac=round(achieved / peak, 4), traffic=traffic, traffic_source=tsrc,
@@ -424,6 +460,8 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
                                     if split_form else "dense f32 MFMA peak"),
                         frac_of_f32_mfma_peak=round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                         flops_per_launch=kf, ms_per_launch=round(cand[dom], 4),
+                        launches_per_step=round(launches_per_step.get(dom, 1.0), 2), ms_per_step=round(cand_total[dom], 4),
+                        share_of_step=round(cand_total[dom] / ms_per_step, 4),
                         note="timed inside the step, where the kernel shares the GPU with the other branch's side-stream "
                              "kernels; *_isolated = same kernel, overlap off, after the timed region",
                         ms_per_launch_isolated=round(isolated.get(dom, 0.0), 4),
@@ -437,8 +475,13 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
         roofline["algorithm"] = ("winograd F(2x2,3x3) f32" if wino.get(dom) else
                                  "direct implicit GEMM, f32 operands split into 3 bf16 pieces (6 bf16 MFMAs per f32 product, f32 accumulate)" if b3.get(dom)
                                  else "direct implicit GEMM f32") if dom.startswith("conv2") \
-            else ("split-bf16 GEMM, 128 x 128 tiles (linear1 of one encoder layer, M=B, N=2048, K=F)" if split_form else
-                  "f32 MFMA GEMM (linear1 of one encoder layer, M=B, N=2048, K=F)")
+            else ("fused small-head attention (one work-group per head, v_mfma_f32_16x16x4_f32; bound by its exp / Philox / LDS work)"
+                  if dom.startswith("attn") else
+                  f"split-bf16 GEMM, 128 x 128 tiles ({dom} of one encoder layer)" if split_form else f"f32 MFMA GEMM ({dom} of one encoder layer)")
+        if per_step_pre:
+            roofline["dominant_chosen_by"] = ("largest total time per step (launches x mean) among the candidates, from an untimed 3-step pass "
+                                              "with events around all of them; the timed region records the chosen section only")
+            roofline["candidates_untimed_pass"] = per_step_pre
         if any(b3.get(k) and k in sections for k in b3):
             # priced at the algorithmic (f32) flop count against the f32 MFMA peak, like every conv line; the kernel executes 6 bf16
             # MFMA flops per algorithmic flop on the bf16 pipe (dense peak ~2.5 PFLOP/s)

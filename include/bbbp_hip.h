@@ -320,6 +320,13 @@ int bbbp_mixed_backward_wait_bucket(void* stream, int bucket);
  * activation is > 0.  Parity tests at B = 512 hand these to the float64 oracle: a pre-activation within float32 rounding of
  * zero may legitimately fall on either side, and ONE such element changes that unit's weight-gradient row by percents. */
 int bbbp_mixed_debug_ffn_gate(void* stream, const bbbp_mixed_desc* d, const void* workspace, int layer, uint8_t* gate);
+/* Test hook, same purpose for the conv stages: the u8 pooling / ReLU decision the forward call saved per POOLED element of stage 1
+ * (Conv2d(3,32)+ReLU+MaxPool2d: [B,32,64,64]) or stage 2 (Conv2d(32,64)+...: [B,64,32,32]): 0..3 = position of the first maximum of the
+ * 2x2 window in PyTorch's scan order (0,0),(0,1),(1,0),(1,1); 4 = the maximum is <= 0 (ReLU inactive, no gradient).  A window whose
+ * two largest pre-activations agree to float32 rounding may legitimately route its gradient to either, and the conv weight / bias
+ * gradients are 10^7-term sums over such decisions: B = 512 parity tests hand these to the float64 oracle after checking that they
+ * differ from float64's own only at such near-ties. */
+int bbbp_mixed_debug_pool_mask(void* stream, const bbbp_mixed_desc* d, const void* workspace, int stage, uint8_t* mask);
 int bbbp_mixed_bucket_param(const bbbp_mixed_desc* d, int bucket);
 /* Buckets 2 + l (l = encoder layer): the layer's twelve tensors, final when its weight-gradient leaves are (layer L-1 first,
  * layer 0 last).  bucket_range gives first parameter index and tensor count of bucket 0 or 2 + l (consecutive in params[]

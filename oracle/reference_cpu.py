@@ -94,9 +94,38 @@ def encoder(x: torch.Tensor, p: Params, prefix: str, nhead: int, num_layers: int
 # --------------------------------------------------------------------------------------------
 # a6/a7: conv3x3(pad 1) + ReLU + maxpool 2x2
 # --------------------------------------------------------------------------------------------
-def conv3x3_relu_pool(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """...20250113.py:85-90: Conv2d(k=3,s=1,p=1) -> ReLU -> MaxPool2d(2,2)."""
-    return F.max_pool2d(F.relu(F.conv2d(x, w, b, stride=1, padding=1)), 2, 2)
+def pool_windows(c: torch.Tensor) -> torch.Tensor:
+    """[B,C,H,W] -> [B,C,H/2,W/2,4]: the 2x2 windows of MaxPool2d(2,2), last axis in scan order (0,0),(0,1),(1,0),(1,1)."""
+    B, C, H, W = c.shape
+    return c.reshape(B, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(B, C, H // 2, W // 2, 4)
+
+
+def pool_decisions(c: torch.Tensor) -> torch.Tensor:
+    """The decision ReLU + MaxPool2d(2,2) take per pooled element of pre-activations ``c``, in the encoding of the HIP path's saved
+    mask (include/bbbp_hip.h: bbbp_mixed_debug_pool_mask): 0..3 = position of the FIRST maximum of the window (PyTorch's rule on
+    ties), 4 = the maximum is <= 0 (ReLU passes nothing)."""
+    win = pool_windows(c)
+    best, idx = win.max(dim=-1)                                   # torch.max returns the first index among equal maxima on CPU
+    first = (win == best.unsqueeze(-1)).to(torch.uint8).argmax(dim=-1)
+    return torch.where(best > 0, first, torch.full_like(first, 4)).to(torch.uint8)
+
+
+def conv3x3_relu_pool(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, pool_mask: Optional[torch.Tensor] = None,
+                      pre: Optional[list] = None) -> torch.Tensor:
+    """...20250113.py:85-90: Conv2d(k=3,s=1,p=1) -> ReLU -> MaxPool2d(2,2).
+    ``pool_mask`` (u8 per pooled element, encoding of ``pool_decisions``) replaces the stage's own ReLU / arg-max decisions: parity
+    tests at large batch hand in the decisions of the implementation under test, so that a window whose two largest
+    pre-activations agree to float32 rounding (where float32 and float64 may legitimately pick different elements, or disagree
+    about the sign of a pre-activation at zero) does not turn into a gradient difference; the test checks separately that the
+    decisions differ only at such near-ties.  ``pre`` (a list) receives the pre-activations."""
+    c = F.conv2d(x, w, b, stride=1, padding=1)
+    if pre is not None:
+        pre.append(c.detach())
+    if pool_mask is None:
+        return F.max_pool2d(F.relu(c), 2, 2)
+    m = pool_mask.to(torch.int64)
+    picked = pool_windows(c).gather(-1, m.clamp(max=3).unsqueeze(-1)).squeeze(-1)
+    return picked * (m < 4).to(c.dtype)
 
 
 # --------------------------------------------------------------------------------------------
@@ -157,7 +186,7 @@ def mixed_input_forward(p: Params, fingerprint: torch.Tensor, image: torch.Tenso
                         training: bool = False, num_layers: int = 6,
                         bn_state: Optional[Dict[str, torch.Tensor]] = None,
                         parts: Optional[dict] = None, fusion: str = "attention",
-                        ffn_gates: Optional[list] = None) -> torch.Tensor:
+                        ffn_gates: Optional[list] = None, pool_masks: Optional[tuple] = None) -> torch.Tensor:
     """MixedInputModel.forward(fingerprint[B,F], image[B,49152]) -> [B,1].
     ``fusion="concat"`` is the earliest variant, Descriptors/multi_input_data_regression_opt_round_2_transformer_cnn.py:89-102
     (plain torch.cat, no attention_fusion parameters); with ``num_layers=0`` on top, BASELINE config 2 (that class without
@@ -170,8 +199,10 @@ def mixed_input_forward(p: Params, fingerprint: torch.Tensor, image: torch.Tenso
     x = encoder(fingerprint, p, "fingerprint_transformer.", nhead, num_layers, ffn_gates=ffn_gates, ffn_pre=ffn_pre)
     fp_out = F.relu(F.linear(x, p["fingerprint_fc.0.weight"], p["fingerprint_fc.0.bias"]))
     img = image.reshape(-1, 3, 128, 128)
-    p1 = conv3x3_relu_pool(img, p["image_cnn.0.weight"], p["image_cnn.0.bias"])
-    p2 = conv3x3_relu_pool(p1, p["image_cnn.3.weight"], p["image_cnn.3.bias"])
+    conv_pre = [] if parts is not None else None
+    pm1, pm2 = pool_masks if pool_masks is not None else (None, None)
+    p1 = conv3x3_relu_pool(img, p["image_cnn.0.weight"], p["image_cnn.0.bias"], pm1, conv_pre)
+    p2 = conv3x3_relu_pool(p1, p["image_cnn.3.weight"], p["image_cnn.3.bias"], pm2, conv_pre)
     img_out = F.relu(F.linear(p2.flatten(1), p["image_cnn.7.weight"], p["image_cnn.7.bias"]))
     if fusion == "attention":
         fused = attention_fusion(fp_out, img_out, p, "attention_fusion.")
@@ -185,7 +216,7 @@ def mixed_input_forward(p: Params, fingerprint: torch.Tensor, image: torch.Tenso
     h3 = F.relu(F.linear(h2, p["fc.5.weight"], p["fc.5.bias"]))
     out = F.linear(h3, p["fc.7.weight"], p["fc.7.bias"])
     if parts is not None:
-        parts.update(ffn_pre=ffn_pre, enc=x, fp_out=fp_out, pool1=p1, pool2=p2, img_out=img_out, fused=fused,
+        parts.update(ffn_pre=ffn_pre, conv_pre=conv_pre, enc=x, fp_out=fp_out, pool1=p1, pool2=p2, img_out=img_out, fused=fused,
                      h=h, hb=hb, h2=h2, h3=h3)
     return out
 

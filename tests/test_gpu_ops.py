@@ -258,7 +258,7 @@ def test_conv_rejects_unsupported(dev):
         ops.conv3x3_relu_pool_fwd(torch.zeros(1, 5, 64, 64, device=dev), torch.zeros(8, 5, 3, 3, device=dev), torch.zeros(8, device=dev))
 
 
-@pytest.mark.parametrize("rows,cols", [(5, 7), (512, 167), (33, 2048), (4, 64)])
+@pytest.mark.parametrize("rows,cols", [(5, 7), (512, 167), (33, 2048), (4, 64), (512, 2048), (3, 1024), (7, 1500), (2, 4096), (5, 1022), (3, 4100)])
 def test_layernorm(dev, rows, cols):
     x, r = rnd(rows, cols, seed=1), rnd(rows, cols, seed=2)
     gam, bet, dy = rnd(cols, seed=3), rnd(cols, seed=4), rnd(rows, cols, seed=5)
@@ -271,6 +271,24 @@ def test_layernorm(dev, rows, cols):
     assert_close(dz.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol_frac=2e-5, what="ln dx")
     assert_close(dg.cpu().numpy(), gr.grad.numpy(), rtol=1e-4, atol_frac=2e-5, what="ln dgamma")
     assert_close(db.cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol_frac=2e-5, what="ln dbeta")
+
+
+@pytest.mark.parametrize("rows,cols", [(6, 2048), (3, 1500), (5, 167)])
+def test_layernorm_dropout_draws_the_dropout_kernels_stream(dev, rows, cols):
+    """z = dropout(x) + residual inside the LayerNorm kernels (the work-group-per-row form for 1024..4096 columns draws one Philox block
+    per float4, the wave-per-row form one per element): both must give the elements bbbp_dropout draws for the contiguous [rows, cols]
+    tensor -- bit for bit -- and the backward's dx must apply the same mask."""
+    x, r, gam, bet, dy = rnd(rows, cols, seed=1).to(dev), rnd(rows, cols, seed=2).to(dev), rnd(cols, seed=3).to(dev), rnd(cols, seed=4).to(dev), rnd(rows, cols, seed=5).to(dev)
+    p, seed = 0.3, 777
+    y, z, mean, rstd = ops.layernorm_fwd(x, r, gam, bet, dropout_p=p, seed=seed)
+    xd = ops.dropout(x, p, seed)
+    assert torch.equal(z, xd + r)
+    kept = (xd != 0).float().mean().item()
+    assert abs(kept - (1 - p)) < 0.06
+    want = F.layer_norm(z.double().cpu(), (cols,), gam.double().cpu(), bet.double().cpu(), 1e-5)
+    assert_close(y.cpu().numpy(), want.numpy(), rtol=1e-5, what="ln(dropout) fwd")
+    dz, dx, _, _ = ops.layernorm_bwd(dy, z, gam, mean, rstd, dropout_p=p, seed=seed)
+    assert torch.equal(dx, ops.dropout(dz, p, seed))
 
 
 @pytest.mark.parametrize("rows,cols", [(9, 9), (512, 512), (3, 4096), (70, 33)])

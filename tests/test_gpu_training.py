@@ -108,19 +108,31 @@ def test_cosine_warm_restarts_schedule_is_followed(dev):
     want = [1e-4 * (1 + math.cos(math.pi * (e if e < 10 else e - 10) / (10 if e < 10 else 20))) / 2 for e in range(EPOCHS)]
     np.testing.assert_allclose(hist["lr"], want, rtol=1e-12)
     assert hist["lr"][10] == 1e-4 and hist["lr"][9] < 3e-6          # restart after T_0 = 10 epochs
-    # Yardstick: the SAME twelve steps by the oracle in float64 and in float32 (torch CPU, the reference's own precision).  Twelve
-    # AdamW steps amplify float32 rounding between any two correct implementations ("many-step runs"); how much
-    # is measured here, not assumed: the GPU trajectory may deviate from float64 by at most twice what torch-CPU float32 has
-    # deviated by so far (running envelope: single epochs of either float32 run can sit on float64 by chance), plus a 1e-5 floor.
-    ref64, _ = oracle_train(state0, fp[:N], img[:N], y[:N], orders, BS, False, (fp[N:], img[N:]), lrs=want, dtype=torch.float64)
-    ref32, _ = oracle_train(state0, fp[:N], img[:N], y[:N], orders, BS, False, (fp[N:], img[N:]), lrs=want)
+    # Yardstick: the SAME twelve steps by the oracle in float64, and in float32 (torch CPU, the reference's own precision) three times:
+    # as is, and twice with every initial weight moved by half an ulp (x (1 +- 2^-24), random signs) -- the size of difference any
+    # other correct float32 implementation starts from.  Twelve AdamW steps amplify float32 rounding ("many-step
+    # runs"; the growth is chaotic, so ONE float32 run is a noisy ruler: it can sit on float64 by chance in an epoch); how much is
+    # measured here, not assumed: the GPU trajectory may deviate from float64 by at most twice the largest deviation any of the three
+    # CPU float32 runs has shown up to that epoch, plus a 1e-5 floor.
+    train = (fp[:N], img[:N], y[:N])
+    ref64, _ = oracle_train(state0, *train, orders, BS, False, (fp[N:], img[N:]), lrs=want, dtype=torch.float64)
+    dev_f32 = []
+    for member in range(3):
+        st = {k: v.clone() for k, v in state0.items()}
+        if member:
+            g = torch.Generator().manual_seed(100 + member)
+            for k, v in st.items():
+                if v.dtype.is_floating_point and "running" not in k:
+                    v.mul_(1.0 + (torch.randint(0, 2, v.shape, generator=g).float() * 2 - 1) * 2.0 ** -24)
+        r32, _ = oracle_train(st, *train, orders, BS, False, (fp[N:], img[N:]), lrs=want)
+        dev_f32.append([abs(a - b) / abs(b) for a, b in zip(r32, ref64)])
     dev_gpu = [abs(a - b) / abs(b) for a, b in zip(hist["train_loss"], ref64)]
-    dev_f32 = [abs(a - b) / abs(b) for a, b in zip(ref32, ref64)]
-    report = dict(gpu=[f"{v:.2e}" for v in dev_gpu], cpu_f32=[f"{v:.2e}" for v in dev_f32])
+    report = "\n".join(["gpu      " + " ".join(f"{v:.1e}" for v in dev_gpu)] + [f"cpu f32 {i} " + " ".join(f"{v:.1e}" for v in d) for i, d in enumerate(dev_f32)])
+    print(report)
     envelope = 0.0
     for e in range(EPOCHS):
-        envelope = max(envelope, dev_f32[e])
-        assert dev_gpu[e] <= 2.0 * envelope + 1e-5, (e, report)
+        envelope = max([envelope] + [d[e] for d in dev_f32])
+        assert dev_gpu[e] <= 2.0 * envelope + 1e-5, f"epoch {e}\n{report}"
     assert dev_gpu[0] <= 1e-5, report                                  # before any update: the forward/loss itself
     # a constant-lr run separates from the scheduled one: the schedule really reached the kernel
     model2 = small_model(F, 3).to(dev)
