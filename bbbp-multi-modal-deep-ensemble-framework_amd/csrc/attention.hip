@@ -31,6 +31,8 @@ struct AttnParams {
     int B, F, NH, D;
     float scale, p, inv_keep;
     uint64_t seed; const unsigned long long* seed_base;
+    uint8_t* keep;                     // optional [NH][ceil(B/16)][ceil(B/16)][64]: dropout keep bits per (head, query block, key tile, lane),
+                                       // bit r of lane (q, kq) <-> key 4 kq + r of query q; written by the forward pass, read by backward
 };
 
 __device__ __forceinline__ void keep4(uint64_t seed, uint64_t idx0, float p, float inv_keep, float (&s)[4]) {
@@ -111,7 +113,13 @@ __global__ __launch_bounds__(NTH) void attn_small_fwd_kernel(AttnParams P) {
             for (int i = 0; i < KT; ++i) {
                 if (t0 + i < ntile) {
                     float ks[4] = {1.f, 1.f, 1.f, 1.f};
-                    if (drop) keep4(seed, ((uint64_t)h * B + min(query, B - 1)) * B + (t0 + i) * 16 + 4 * kq, P.p, P.inv_keep, ks);
+                    if (drop) {
+                        keep4(seed, ((uint64_t)h * B + min(query, B - 1)) * B + (t0 + i) * 16 + 4 * kq, P.p, P.inv_keep, ks);
+                        // the backward pass reads the decisions back instead of drawing the Philox blocks again (its dominant cost)
+                        if (P.keep)
+                            P.keep[(((long)h * ntile + qb) * ntile + (t0 + i)) * 64 + lane] =
+                                (uint8_t)((ks[0] != 0.f) | ((ks[1] != 0.f) << 1) | ((ks[2] != 0.f) << 2) | ((ks[3] != 0.f) << 3));
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float pv = __expf(s[i][r] - mn);
@@ -173,7 +181,15 @@ __global__ __launch_bounds__(NTH) void attn_small_bwd_kernel(AttnParams P) {
         const int query = qb * 16 + q;
         const float L = sL[query], dl = sDelta[query];
         float ks[4] = {1.f, 1.f, 1.f, 1.f};
-        if (drop) keep4(seed, ((uint64_t)h * B + min(query, B - 1)) * B + kt * 16 + 4 * kq, P.p, P.inv_keep, ks);
+        if (drop) {
+            if (P.keep) {
+                const unsigned bits = P.keep[(((long)h * ntile + qb) * ntile + kt) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ks[r] = (bits >> r) & 1u ? P.inv_keep : 0.f;
+            } else {
+                keep4(seed, ((uint64_t)h * B + min(query, B - 1)) * B + kt * 16 + 4 * kq, P.p, P.inv_keep, ks);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int key = kt * 16 + 4 * kq + r;
@@ -238,8 +254,148 @@ __global__ __launch_bounds__(NTH) void attn_small_bwd_kernel(AttnParams P) {
     }
 }
 
+// Backward in ONE sweep (round 3; one work-group per head, B <= 16 * NW * NKT).  The two-sweep kernel above evaluates every (key tile,
+// query block) pair twice -- S and dP on the matrix pipe, four exp and, with dropout, a Philox block per lane each time -- and moves the
+// transposed tiles through wave-private LDS behind two wave barriers per pair: at head_dim 8 a pair is a ~1600-cycle dependent chain
+// with two waves per SIMD to cover it (0.27 ms per layer at F = 2048, B = 512).  Here
+//   * wave w owns key tiles w, w + 8, ... (dV^T, dK^T accumulators in registers for the whole sweep); all eight waves walk the query
+//     blocks in step, and a block's dQ^T partials (one per wave: its key tiles' share) are added through LDS in wave order by 256
+//     threads -- one barrier per query block, a fixed summation order, no atomics;
+//   * a pair's probabilities are produced in BOTH register layouts by the matrix pipe (S^T = K Q^T: rows = keys, the B operand of
+//     dQ^T += K^T dS^T; S = Q K^T: rows = queries, the B operand of dV^T += dO^T Pd and dK^T += Q^T dS), so nothing is transposed
+//     through LDS and there is no barrier inside a pair: 20 independent-enough MFMAs and 8 exp per pair, four pairs in flight;
+//   * the dropout decisions come back as the bytes the forward pass saved (AttnParams::keep, S^T layout) instead of being drawn
+//     again; the S layout reads them out of four wave-wide ballots.
+template <int NS, int NKT>
+__global__ __launch_bounds__(NTH) void attn_small_bwd1_kernel(AttnParams P) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int D = 4 * NS, DP = D + 1;
+    const int B = P.B, Bp = (B + 15) & ~15, F = P.F, h = blockIdx.x;
+    float* sK = smem; float* sV = sK + Bp * DP; float* sQ = sV + Bp * DP; float* sdO = sQ + Bp * DP;
+    float* sL = sdO + Bp * DP; float* sDelta = sL + Bp;
+    float* sR = sDelta + Bp;                                                               // [2][NW][256] dQ^T partials, double-buffered
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane & 15, kq = lane >> 4;
+    head_to_lds(sK, DP, P.qkv + F + h * D, 3 * F, B, Bp, D, t);
+    head_to_lds(sV, DP, P.qkv + 2 * F + h * D, 3 * F, B, Bp, D, t);
+    head_to_lds(sQ, DP, P.qkv + h * D, 3 * F, B, Bp, D, t);
+    head_to_lds(sdO, DP, P.dctx + h * D, F, B, Bp, D, t);
+    for (int r = t; r < Bp; r += NTH) {
+        float dl = 0.f;
+        if (r < B) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) dl += P.dctx[(long)r * F + h * D + c] * P.ctx[(long)r * F + h * D + c];
+        }
+        sDelta[r] = dl;
+        sL[r] = r < B ? P.lse[(long)h * B + r] : INFINITY;       // exp(s - inf) = 0 for padded queries
+    }
+    __syncthreads();
+    const bool drop = P.p > 0.f;                                  // the launcher guarantees P.keep when drop
+    const int ntile = Bp >> 4;
+    const uint8_t* keep = drop ? P.keep + (long)h * ntile * ntile * 64 + lane : nullptr;
+
+    // Vector work per pair is what is left to save (the f32 MFMA and the vector ALU share a SIMD's FMA lanes): the softmax scale and
+    // log2(e) are folded into the saved logsumexp and one multiply per score (exp2 of a difference), the scale of dS into the K^T / Q^T
+    // operands of dQ^T / dK^T, and ragged tiles need no selects -- a padded key's K row is zero, so its dS reaches dQ^T through a zero
+    // operand and its dV^T / dK^T columns are never stored; a padded query has logsumexp = +inf, i.e. probability 0.
+    const float LOG2E = 1.4426950408889634f;
+    const float sc2 = P.scale * LOG2E;
+    f32x4 dv[NKT], dk[NKT];                                      // dV^T, dK^T [d = 4 kq + r][key = q] of the wave's key tiles
+    float ak[NKT][4];                                            // scale * K^T[d = q][key 4 kq + r] of the wave's key tiles: A operand of dQ^T
+#pragma unroll
+    for (int i = 0; i < NKT; ++i) {
+        const int kt = wave + NW * i;
+        dv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ak[i][r] = (kt < ntile && q < D) ? P.scale * sK[(kt * 16 + 4 * kq + r) * DP + q] : 0.f;
+    }
+    unsigned kb_next[NKT];
+#pragma unroll
+    for (int i = 0; i < NKT; ++i) kb_next[i] = (keep && wave + NW * i < ntile) ? keep[(long)(wave + NW * i) * 64] : 0xfu;
+    // S layout: lane (q, kq), register r <-> query 4 kq + r, key q.  Its keep bit sits in the S^T layout's lane (query, key >> 2), bit
+    // key & 3, i.e. bit ((q >> 2) * 16 + 4 kq + r) of the ballot of bit (q & 3)
+    const int bal_sel = q & 3, bal_shift = (q >> 2) * 16 + 4 * kq;
+
+    for (int qb = 0; qb < ntile; ++qb) {
+        unsigned kb[NKT];
+#pragma unroll
+        for (int i = 0; i < NKT; ++i) {
+            kb[i] = kb_next[i];
+            // the next query block's bytes travel while this block is computed
+            if (keep && qb + 1 < ntile && wave + NW * i < ntile) kb_next[i] = keep[((long)(qb + 1) * ntile + wave + NW * i) * 64];
+        }
+        const float Lt = sL[qb * 16 + q] * LOG2E, dlt = sDelta[qb * 16 + q];
+        float Ln[4], dln[4], adO[4], aQ[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = qb * 16 + 4 * kq + r;
+            Ln[r] = sL[row] * LOG2E; dln[r] = sDelta[row];
+            adO[r] = q < D ? sdO[row * DP + q] : 0.f;              // dO^T[d = q][query 4 kq + r]
+            aQ[r] = q < D ? P.scale * sQ[row * DP + q] : 0.f;      // scale * Q^T[d = q][query 4 kq + r]
+        }
+        f32x4 dq = {0.f, 0.f, 0.f, 0.f};                          // dQ^T[d = 4 kq + r][query = q], this wave's key tiles only
+#pragma unroll
+        for (int i = 0; i < NKT; ++i) {
+            const int kt = wave + NW * i;
+            if (kt < ntile) {                                     // wave-uniform
+                const f32x4 st = tile_xyT<NS>(sK, kt * 16, sQ, qb * 16, DP, q, kq);       // S^T: rows keys
+                const f32x4 dpt = tile_xyT<NS>(sV, kt * 16, sdO, qb * 16, DP, q, kq);
+                const f32x4 sn = tile_xyT<NS>(sQ, qb * 16, sK, kt * 16, DP, q, kq);       // S: rows queries
+                const f32x4 dpn = tile_xyT<NS>(sdO, qb * 16, sV, kt * 16, DP, q, kq);
+                if (drop) {
+                    const unsigned long long b0 = __ballot(kb[i] & 1u), b1 = __ballot(kb[i] & 2u), b2 = __ballot(kb[i] & 4u), b3 = __ballot(kb[i] & 8u);
+                    const unsigned mine = (unsigned)((bal_sel == 0 ? b0 : bal_sel == 1 ? b1 : bal_sel == 2 ? b2 : b3) >> bal_shift);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float kst = (kb[i] >> r) & 1u ? P.inv_keep : 0.f, ksn = (mine >> r) & 1u ? P.inv_keep : 0.f;
+                        const float pt = __builtin_amdgcn_exp2f(st[r] * sc2 - Lt);
+                        // dQ^T[d][query] += (scale K^T)[d][key] (dS^T / scale)[key][query]: the score registers are the B operand as they stand
+                        dq = __builtin_amdgcn_mfma_f32_16x16x4f32(ak[i][r], pt * (dpt[r] * kst - dlt), dq, 0, 0, 0);
+                        const float pn = __builtin_amdgcn_exp2f(sn[r] * sc2 - Ln[r]);
+                        // dV^T[d][key] += dO^T[d][query] Pd[query][key];  dK^T[d][key] += (scale Q^T)[d][query] (dS / scale)[query][key]
+                        dv[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(adO[r], pn * ksn, dv[i], 0, 0, 0);
+                        dk[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(aQ[r], pn * (dpn[r] * ksn - dln[r]), dk[i], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pt = __builtin_amdgcn_exp2f(st[r] * sc2 - Lt);
+                        dq = __builtin_amdgcn_mfma_f32_16x16x4f32(ak[i][r], pt * (dpt[r] - dlt), dq, 0, 0, 0);
+                        const float pn = __builtin_amdgcn_exp2f(sn[r] * sc2 - Ln[r]);
+                        dv[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(adO[r], pn, dv[i], 0, 0, 0);
+                        dk[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(aQ[r], pn * (dpn[r] - dln[r]), dk[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // the eight partial dQ^T tiles of this query block -> LDS; 256 threads add them in wave order
+        float* rb = sR + (qb & 1) * (NW * 256);
+        *reinterpret_cast<f32x4*>(rb + wave * 256 + lane * 4) = dq;
+        __syncthreads();
+        if (t < 256) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += rb[w * 256 + t];
+            const int ql = (t >> 2) & 15, d = 4 * (t >> 6) + (t & 3), qrow = qb * 16 + ql;
+            if (d < D && qrow < B) P.dqkv[(long)qrow * 3 * F + h * D + d] = sum;
+        }
+        // the buffer written two blocks later is this one: every thread passes the next block's barrier only after these reads
+    }
+#pragma unroll
+    for (int i = 0; i < NKT; ++i) {
+        const int key = (wave + NW * i) * 16 + q;
+        if (wave + NW * i < ntile && key < B && 4 * kq < D) {
+            float* dvp = P.dqkv + (long)key * 3 * F + 2 * F + h * D + 4 * kq;
+            float* dkp = P.dqkv + (long)key * 3 * F + F + h * D + 4 * kq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { dvp[r] = dv[i][r]; dkp[r] = dk[i][r]; }
+        }
+    }
+}
+
 size_t fwd_lds(int B, int D) { const size_t Bp = (B + 15) & ~15; return 3 * Bp * (D + 1) * sizeof(float); }
 size_t bwd_lds(int B, int D) { const size_t Bp = (B + 15) & ~15; return (4 * Bp * (D + 1) + 2 * Bp + NW * 2 * 16 * 17) * sizeof(float); }
+size_t bwd1_lds(int B, int D) { const size_t Bp = (B + 15) & ~15; return (4 * Bp * (D + 1) + 2 * Bp + 2 * NW * 256) * sizeof(float); }
+constexpr int BWD1_NKT = 4;            // key tiles per wave in the single-sweep backward: B <= 16 * NW * BWD1_NKT = 512
 constexpr size_t LDS_MAX = 160 * 1024;
 // few heads (F = 64: 8) cannot fill the chip by themselves: split a head's query blocks / key tiles over several work-groups
 int head_parts(int nhead, int B) {
@@ -560,10 +716,18 @@ bool bbbp_attn_small_supported(int B, int nhead, int head_dim) { return small_su
 // latency-path launches they replace, because 32 work-groups cannot use more than 32 CUs' matrix pipes.
 bool bbbp_attn_wide_supported(int B, int nhead, int head_dim) { return wide_supported(B, nhead, head_dim); }
 
-int bbbp_attn_small_fwd(hipStream_t st, const float* qkv, float* ctx, float* lse, int B, int F, int nhead, float scale, float p, uint64_t seed) {
+// bytes of the dropout keep mask the small-head forward can leave for the backward pass (0: the shape runs on the wide-head kernels)
+size_t bbbp_attn_small_keep_bytes(int B, int nhead, int head_dim) {
+    if (!small_supported(B, nhead, head_dim)) return 0;
+    const size_t nt = (B + 15) / 16;
+    return (size_t)nhead * nt * nt * 64;
+}
+
+int bbbp_attn_small_fwd(hipStream_t st, const float* qkv, float* ctx, float* lse, int B, int F, int nhead, float scale, float p, uint64_t seed,
+                        uint8_t* keep) {
     const int D = F / nhead;
     BBBP_CHECK_ARG(small_supported(B, nhead, D) || wide_supported(B, nhead, D), "attn_small: B=%d nhead=%d head_dim=%d not supported", B, nhead, D);
-    AttnParams P{qkv, ctx, lse, nullptr, nullptr, B, F, nhead, D, scale, p, p > 0.f ? 1.f / (1.f - p) : 1.f, seed, g_bbbp_seed_base};
+    AttnParams P{qkv, ctx, lse, nullptr, nullptr, B, F, nhead, D, scale, p, p > 0.f ? 1.f / (1.f - p) : 1.f, seed, g_bbbp_seed_base, keep};
     if (!small_supported(B, nhead, D)) {
         int rc = set_dyn_lds(attn_wide_fwd_kernel, WIDE_FWD_LDS); if (rc) return rc;
         hipLaunchKernelGGL(attn_wide_fwd_kernel, dim3(nhead, (B + 15) / 16), dim3(64 * WFW), WIDE_FWD_LDS, st, P);
@@ -578,14 +742,23 @@ int bbbp_attn_small_fwd(hipStream_t st, const float* qkv, float* ctx, float* lse
 }
 
 int bbbp_attn_small_bwd(hipStream_t st, const float* qkv, const float* ctx, const float* lse, const float* dctx, float* dqkv, int B, int F,
-                        int nhead, float scale, float p, uint64_t seed) {
+                        int nhead, float scale, float p, uint64_t seed, const uint8_t* keep) {
     const int D = F / nhead;
     BBBP_CHECK_ARG(small_supported(B, nhead, D) || wide_supported(B, nhead, D), "attn_small: B=%d nhead=%d head_dim=%d not supported", B, nhead, D);
     AttnParams P{qkv, const_cast<float*>(ctx), const_cast<float*>(lse), dctx, dqkv, B, F, nhead, D, scale, p, p > 0.f ? 1.f / (1.f - p) : 1.f, seed,
-                 g_bbbp_seed_base};
+                 g_bbbp_seed_base, const_cast<uint8_t*>(keep)};
     if (!small_supported(B, nhead, D)) {
         int rc = set_dyn_lds(attn_wide_bwd_kernel, WIDE_BWD_LDS); if (rc) return rc;
         hipLaunchKernelGGL(attn_wide_bwd_kernel, dim3(nhead, (B + 15) / 16, 2), dim3(64 * WBW), WIDE_BWD_LDS, st, P);
+        BBBP_CHECK_LAUNCH();
+        return BBBP_OK;
+    }
+    // one work-group per head and at most NW * BWD1_NKT key tiles: the single-sweep kernel (BBBP_ATTN_BWD1=0: the two-sweep kernel)
+    static const int bwd1 = [] { const char* e = getenv("BBBP_ATTN_BWD1"); return e ? atoi(e) : 1; }();
+    if (bwd1 && (p == 0.f || keep != nullptr) && head_parts(nhead, B) == 1 && (B + 15) / 16 <= NW * BWD1_NKT && bwd1_lds(B, D) <= LDS_MAX) {
+        const size_t lds1 = bwd1_lds(B, D);
+        if (D == 8) { int rc = set_dyn_lds(attn_small_bwd1_kernel<2, BWD1_NKT>, lds1); if (rc) return rc; hipLaunchKernelGGL((attn_small_bwd1_kernel<2, BWD1_NKT>), dim3(nhead), dim3(NTH), lds1, st, P); }
+        else { int rc = set_dyn_lds(attn_small_bwd1_kernel<4, BWD1_NKT>, lds1); if (rc) return rc; hipLaunchKernelGGL((attn_small_bwd1_kernel<4, BWD1_NKT>), dim3(nhead), dim3(NTH), lds1, st, P); }
         BBBP_CHECK_LAUNCH();
         return BBBP_OK;
     }

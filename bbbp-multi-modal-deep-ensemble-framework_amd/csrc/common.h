@@ -84,9 +84,13 @@ int bbbp_ln_param_grad_multi(hipStream_t st, int n, const float* const* dy, cons
 // attention.hip: fused (flash-style) self-attention for many heads of head_dim 8 / 16, one work-group per head
 bool bbbp_attn_small_supported(int B, int nhead, int head_dim);
 bool bbbp_attn_wide_supported(int B, int nhead, int head_dim);      // one wide head (161..176 columns): opt-in, see attention.hip
-int bbbp_attn_small_fwd(hipStream_t st, const float* qkv, float* ctx, float* lse, int B, int F, int nhead, float scale, float p, uint64_t seed);
+// `keep` (optional, bbbp_attn_small_keep_bytes): the forward pass leaves its dropout decisions there and the backward pass reads them
+// back instead of drawing the Philox blocks again; NULL: backward recomputes them (same stream, same result)
+size_t bbbp_attn_small_keep_bytes(int B, int nhead, int head_dim);
+int bbbp_attn_small_fwd(hipStream_t st, const float* qkv, float* ctx, float* lse, int B, int F, int nhead, float scale, float p, uint64_t seed,
+                        uint8_t* keep = nullptr);
 int bbbp_attn_small_bwd(hipStream_t st, const float* qkv, const float* ctx, const float* lse, const float* dctx, float* dqkv, int B, int F,
-                        int nhead, float scale, float p, uint64_t seed);
+                        int nhead, float scale, float p, uint64_t seed, const uint8_t* keep = nullptr);
 constexpr size_t BBBP_CONV_MIN_LDS = 120 * 1024;
 // conv_wino.hip: Winograd F(2x2,3x3) form of the 32 -> 64 @ 64x64 stage; workspace = 16*32*64 floats of transformed filters
 int bbbp_wino_conv2_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* y, uint8_t* mask, int B,

@@ -54,7 +54,7 @@ struct Bump {
     size_t f(size_t n) { return take(n * sizeof(float)); }
 };
 
-struct LayerOff { size_t qkv, prob, pd, ctx, z1, y1, hff, z2, y2, mean1, rstd1, mean2, rstd2, lse; };
+struct LayerOff { size_t qkv, prob, pd, ctx, z1, y1, hff, z2, y2, mean1, rstd1, mean2, rstd2, lse, keep; };      // keep: 0 = none
 // per-layer gradient buffers: weight-gradient kernels read them on a third stream while the dependency
 // chain moves on to the next layer, so they must not be recycled within one backward pass
 struct LayerGrad { size_t dyout, dz2, dz2d, dhff, dy1, dz1, dz1d, dqkv; };
@@ -111,6 +111,12 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
         // every launch on the encoder's chain costs more than the bytes
         o.pd = (p->drop && !p->flash) ? b.f(NH * B * B) : o.prob;
         o.lse = b.f(NH * B);
+        // fused small-head attention with dropout: the forward pass leaves its keep decisions (one byte per lane and tile pair, 17 MB
+        // per layer at F = 2048, B = 512) for the backward pass, whose dominant cost was drawing them again
+        {
+            const size_t kbytes = (p->flash && p->drop && !p->inference) ? bbbp_attn_small_keep_bytes(p->B, p->NH, p->D) : 0;
+            o.keep = kbytes ? b.take(kbytes) : 0;          // offset 0 is the seed slot: 0 means "no mask kept"
+        }
         o.z1 = b.f(B * F); o.y1 = b.f(B * F); o.hff = b.f(B * DFF); o.z2 = b.f(B * F); o.y2 = b.f(B * F);
         o.mean1 = b.f(B); o.rstd1 = b.f(B); o.mean2 = b.f(B); o.rstd2 = b.f(B);
     }
@@ -585,7 +591,7 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         std::optional<Section> sec_attn;
         sec_attn.emplace(ce.st, SEC_ATTN_FWD);
         if (plan.flash) {
-            TRY(bbbp_attn_small_fwd(ce.st, qkv, ctx, c.f(o.lse), B, F, NH, scale, p_drop, site_seed(d->seed, l, 0)));
+            TRY(bbbp_attn_small_fwd(ce.st, qkv, ctx, c.f(o.lse), B, F, NH, scale, p_drop, site_seed(d->seed, l, 0), o.keep ? c.u8(o.keep) : nullptr));
         } else {
         // scores_h = scale * Q_h K_h^T
         TRY(bbbp_gemm_f32(ce.st, 0, 1, B, B, D, scale, qkv, 3 * F, qkv + F, 3 * F, prob, B, nullptr, nullptr, 0, 0, NH, D, D,
@@ -967,7 +973,8 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         std::optional<Section> sec_attn;
         sec_attn.emplace(ce.st, SEC_ATTN_BWD);
         if (plan.flash) {
-            TRY(bbbp_attn_small_bwd(ce.st, qkv, ctx, c.f(o.lse), dctx, dqkv, B, F, NH, scale, p_drop, site_seed(d->seed, l, 0)));
+            TRY(bbbp_attn_small_bwd(ce.st, qkv, ctx, c.f(o.lse), dctx, dqkv, B, F, NH, scale, p_drop, site_seed(d->seed, l, 0),
+                                    o.keep ? c.u8(o.keep) : nullptr));
         } else {
         {
             bbbp_gemm_desc g[2] = {

@@ -408,7 +408,10 @@ def test_fused_encoder_rows_match_the_launch_per_op_schedule(dev, F, B, training
 
 
 @pytest.mark.parametrize("F,B,training", [(64, 37, True), (128, 16, True), (64, 512, True), (2048, 24, True), (128, 33, False),
-                                          (167, 37, True), (167, 7, True), (167, 512, True), (167, 130, False)])
+                                          (167, 37, True), (167, 7, True), (167, 512, True), (167, 130, False),
+                                          # one work-group per head: the single-sweep backward (attn_small_bwd1_kernel) with the forward's
+                                          # saved keep bytes; 200 rows: ragged last tile, waves with one and two key tiles; 512: four each
+                                          (2048, 200, True), (2048, 512, True)])
 def test_fused_small_head_attention_matches_materialised_attention(dev, F, B, training):
     """csrc/attention.hip (one work-group per head, scores in registers, logsumexp saved, P recomputed in backward; F = 167: the single
     167-wide head of the MACCS encoder on the attn_wide kernels, operands straight from global memory) against the
