@@ -48,7 +48,8 @@ def predict(model, fingerprints: torch.Tensor, images: torch.Tensor, batch_size:
 
 def train_fold(model, train, test=None, *, epochs: int = 50, batch_size: int = 32, lr: float = 1e-4, weight_decay: float = 1e-5,
                faithful_mode: bool = True, shuffle: bool = True, generator: Optional[torch.Generator] = None,
-               optimizer=None, batch_orders: Optional[List[np.ndarray]] = None, scheduler=None) -> Dict[str, list]:
+               optimizer=None, batch_orders: Optional[List[np.ndarray]] = None, scheduler=None,
+               early_stopping_patience: Optional[int] = None) -> Dict[str, list]:
     """Train ``model`` on ``train = (fingerprints[N,F], images[N,49152], labels[N])`` (device tensors).  Returns the per-epoch
     mean training / validation losses like the reference's ``train_losses`` / ``val_losses`` lists.  ``batch_orders``
     (one permutation per epoch) overrides the shuffling for reproducible comparisons.
@@ -57,7 +58,12 @@ def train_fold(model, train, test=None, *, epochs: int = 50, batch_size: int = 3
     stepped once per EPOCH after the epoch's batches (Models/multi_input_data_regression_opt_transformer_cnn.py:161,177; the
     published ...20250113.py has no scheduler).  Pass ``"cosine_warm_restarts"`` for exactly that, or a callable
     ``optimizer -> torch.optim.lr_scheduler.LRScheduler``; the fused AdamW reads ``group["lr"]`` at every step.  The learning
-    rate used in each epoch is recorded in ``hist["lr"]``."""
+    rate used in each epoch is recorded in ``hist["lr"]``.
+
+    ``early_stopping_patience``: the dense-MLP scripts stop on the TRAINING loss (Descriptors/multi_input_data_nn.py:114-143,
+    ``patience = 10``): after each epoch, ``avg_loss < best_loss`` resets a counter, anything else increments it, and the loop breaks
+    once the counter EXCEEDS the patience (i.e. after patience + 1 epochs without a new best).  ``hist["stopped_epoch"]`` is the
+    0-based epoch the loop broke at, or None."""
     fp, img, y = train
     if not (fp.is_cuda and img.is_cuda and y.is_cuda):
         raise RuntimeError("train_fold expects device-resident tensors")
@@ -69,7 +75,8 @@ def train_fold(model, train, test=None, *, epochs: int = 50, batch_size: int = 3
         scheduler = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=10, T_mult=2)
     elif callable(scheduler) and not hasattr(scheduler, "step"):
         scheduler = scheduler(opt)
-    hist = {"train_loss": [], "val_loss": [], "lr": []}
+    hist = {"train_loss": [], "val_loss": [], "lr": [], "stopped_epoch": None}
+    best_loss, patience_counter = float("inf"), 0
     model.train()                                   # reference :179 -- once, outside the epoch loop
     for epoch in range(epochs):
         if not faithful_mode:
@@ -104,6 +111,14 @@ def train_fold(model, train, test=None, *, epochs: int = 50, batch_size: int = 3
                     p = model(tfp[i:i + batch_size], timg[i:i + batch_size]).squeeze()
                     vl += float(crit(p, ty[i:i + batch_size].to(torch.float32))); vb += 1
             hist["val_loss"].append(vl / vb)
+        if early_stopping_patience is not None:     # multi_input_data_nn.py:134-141
+            if hist["train_loss"][-1] < best_loss:
+                best_loss, patience_counter = hist["train_loss"][-1], 0
+            else:
+                patience_counter += 1
+            if patience_counter > early_stopping_patience:
+                hist["stopped_epoch"] = epoch
+                break
     return hist
 
 

@@ -7,6 +7,8 @@ the HIP GEMM / BatchNorm / dropout / fusion ops through per-op autograd nodes.
   architecture of the shipped ``best_nn_model*.pth``.
 * ``RdkitPCAFusionModel`` -- Models/multi_input_data_regression_opt_transformer_cnn_rdkit.py:53-105: the same with the
   single-head ``AttentionFusion``.
+* ``OptMoreFusionModel`` -- Models/multi_input_data_regression_opt_transformer_cnn_opt_more.py:80-107: the PCA-MLP fusion model with
+  256-wide branches, ReLU -> BatchNorm1d -> Dropout(0.3) in each, fusion over 512 columns and a 512->256->128->1 BatchNorm head.
 * ``DenseMLPModel``   -- Models/multi_input_data_regression_opt.py:41-85: raw fingerprint F->512->256->128 and raw image
   49152->1024->256->128 with ReLU -> BatchNorm1d -> Dropout(0.2), concat, BatchNorm head.
 """
@@ -70,6 +72,32 @@ class RdkitPCAFusionModel(nn.Module):
         self.image_fc = nn.Sequential(nn.Linear(image_feature_size, 128), nn.ReLU())
         self.attention_fusion = AttentionFusion(256)
         self.fc = nn.Sequential(nn.Linear(256, 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU(), nn.Linear(64, 1))
+        flatten_parameters(self)
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        flatten_parameters(self)
+        return out
+
+    def forward(self, fingerprint, image):
+        _need_cuda(fingerprint)
+        a = run_sequential(self.fingerprint_fc, fingerprint.float().contiguous())
+        b = run_sequential(self.image_fc, image.float().contiguous())
+        return run_sequential(self.fc, self.attention_fusion(a, b))
+
+
+class OptMoreFusionModel(nn.Module):
+    """``MixedInputModel`` of Models/multi_input_data_regression_opt_transformer_cnn_opt_more.py:80-107 (the Descriptors/ copy is the
+    same class): PCA-reduced fingerprint and image each through ``Linear(n, 256) -> ReLU -> BatchNorm1d(256) -> Dropout(0.3)``,
+    ``MultiHeadAttentionFusion(512)``, head ``Linear(512,256) -> ReLU -> BatchNorm1d(256) -> Linear(256,128) -> ReLU -> Linear(128,1)``.
+    Same constructor signature and ``state_dict`` keys as the reference class."""
+
+    def __init__(self, fingerprint_size, image_feature_size):
+        super().__init__()
+        self.fingerprint_fc = nn.Sequential(nn.Linear(fingerprint_size, 256), nn.ReLU(), nn.BatchNorm1d(256), nn.Dropout(0.3))
+        self.image_fc = nn.Sequential(nn.Linear(image_feature_size, 256), nn.ReLU(), nn.BatchNorm1d(256), nn.Dropout(0.3))
+        self.attention_fusion = MultiHeadAttentionFusion(512)
+        self.fc = nn.Sequential(nn.Linear(512, 256), nn.ReLU(), nn.BatchNorm1d(256), nn.Linear(256, 128), nn.ReLU(), nn.Linear(128, 1))
         flatten_parameters(self)
 
     def _apply(self, fn, *a, **k):

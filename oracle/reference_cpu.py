@@ -241,6 +241,19 @@ def pca_mlp_forward(p: Params, fingerprint: torch.Tensor, image: torch.Tensor, s
     return F.linear(h, p["fc.4.weight"], p["fc.4.bias"])
 
 
+def opt_more_forward(p: Params, fingerprint: torch.Tensor, image: torch.Tensor, *, training: bool = False,
+                     bn_state: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    """Models/multi_input_data_regression_opt_transformer_cnn_opt_more.py:80-107: 256-wide branches Linear -> ReLU -> BatchNorm1d
+    (-> Dropout(0.3): identity here), MultiHeadAttentionFusion(512), head Linear(512,256) -> ReLU -> BatchNorm1d -> Linear(256,128)
+    -> ReLU -> Linear(128,1)."""
+    a = batchnorm1d(F.relu(F.linear(fingerprint, p["fingerprint_fc.0.weight"], p["fingerprint_fc.0.bias"])), p, "fingerprint_fc.2.", training, bn_state)
+    b = batchnorm1d(F.relu(F.linear(image, p["image_fc.0.weight"], p["image_fc.0.bias"])), p, "image_fc.2.", training, bn_state)
+    fused = attention_fusion(a, b, p, "attention_fusion.")
+    h = batchnorm1d(F.relu(F.linear(fused, p["fc.0.weight"], p["fc.0.bias"])), p, "fc.2.", training, bn_state)
+    h = F.relu(F.linear(h, p["fc.3.weight"], p["fc.3.bias"]))
+    return F.linear(h, p["fc.5.weight"], p["fc.5.bias"])
+
+
 # --------------------------------------------------------------------------------------------
 # a16: dense raw-feature MLP (Models/multi_input_data_regression_opt.py:41-85), dropout = identity
 # --------------------------------------------------------------------------------------------

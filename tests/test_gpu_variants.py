@@ -141,3 +141,43 @@ def test_rdkit_single_head_fusion_model(dev):
             assert float(q.grad.abs().max()) == 0.0, k           # exact zeros, as in the reference
         else:
             check_summary(g, f"train/B6/{k}", q.grad, rtol=5e-4)
+
+
+def test_opt_more_fusion_model(dev):
+    """OptMoreFusionModel (Models/multi_input_data_regression_opt_transformer_cnn_opt_more.py:80-107) on the HIP ops: eval and train-mode
+    outputs against the reference class's goldens, every gradient and the three BatchNorms' running statistics against the float64
+    oracle (dropout off for the comparison), and Dropout(0.3) active in train mode."""
+    from bbbp_amd.variants import OptMoreFusionModel
+    g = golden("opt_more")
+    torch.manual_seed(11)
+    m = OptMoreFusionModel(64, 128)
+    check_param_checksums(g, m.state_dict())
+    m = m.to(dev).eval()
+    for B in (1, 9):
+        fp, img, _ = synth_inputs(1000 + B, B, 64, 128)
+        with torch.no_grad():
+            assert_close(m(fp.to(dev), img.to(dev)).cpu().numpy(), g[f"eval/B{B}/out"], rtol=1e-4, atol_frac=2e-5, what=f"opt_more eval B={B}")
+    m.train()
+    fp, img, y = synth_inputs(1006, 6, 64, 128)
+    torch.manual_seed(1)
+    a, b = m(fp.to(dev), img.to(dev)), m(fp.to(dev), img.to(dev))
+    assert not torch.equal(a, b)                          # Dropout(0.3) draws a fresh mask per call
+    torch.manual_seed(11)
+    m = OptMoreFusionModel(64, 128).to(dev).train()       # fresh running statistics
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    sd0 = {k: v.detach().cpu().double().clone() if v.dtype.is_floating_point else v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    out = m(fp.to(dev), img.to(dev))
+    assert_close(out.detach().cpu().numpy(), g["train/B6/out"], rtol=1e-4, atol_frac=2e-5, what="opt_more train")
+    torch.nn.MSELoss()(out.squeeze(), y.to(dev)).backward()
+    p = {k: v.requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd0.items()}
+    st = {}
+    oracle.mse_loss(oracle.opt_more_forward(p, fp.double(), img.double(), training=True, bn_state=st), y.double()).backward()
+    for k, q in m.named_parameters():
+        if not k.startswith("attention_fusion."):
+            assert_close(q.grad.cpu().numpy(), p[k].grad.numpy(), rtol=2e-4, atol_frac=1e-4, what=k)
+    for k, v in st.items():
+        if "running" in k:
+            assert_close(m.state_dict()[k].cpu().numpy(), v.numpy(), rtol=1e-5, what=k)
+    assert int(m.state_dict()["fc.2.num_batches_tracked"]) == 1 and int(m.state_dict()["image_fc.2.num_batches_tracked"]) == 1

@@ -375,3 +375,31 @@ def test_oof_f64_fixture_is_reproduced_by_the_float32_oracle_on_one_fold():
     want = g["nn_f64"][te]
     np.testing.assert_allclose(losses, g[f"fold{k}/train_loss"], rtol=2e-3)
     assert np.max(np.abs(preds.numpy() - want)) <= 5e-3 * max(1.0, np.max(np.abs(g["nn_f64"])))
+
+
+def test_opt_more_golden():
+    """Models/multi_input_data_regression_opt_transformer_cnn_opt_more.py:80-107 (256-wide BatchNorm + Dropout(0.3) branches, fusion over
+    512 columns): the oracle against the reference class's goldens; the drop-in draws the reference's initial weights."""
+    from bbbp_amd.variants import OptMoreFusionModel
+    g = golden("opt_more")
+    torch.manual_seed(11)
+    m = OptMoreFusionModel(64, 128)
+    check_param_checksums(g, m.state_dict())
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    for B in (1, 9):
+        fp, img, _ = synth_inputs(1000 + B, B, 64, 128)
+        with torch.no_grad():
+            out = oracle.opt_more_forward(sd, fp, img, training=False)
+        assert_close(out.numpy(), g[f"eval/B{B}/out"], rtol=1e-5, what=f"opt_more eval B={B}")
+    fp, img, y = synth_inputs(1006, 6, 64, 128)
+    p = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
+    st = {}
+    out = oracle.opt_more_forward(p, fp, img, training=True, bn_state=st)
+    assert_close(out.detach().numpy(), g["train/B6/out"], rtol=1e-5, what="opt_more train")
+    oracle.mse_loss(out, y).backward()
+    for k in p:
+        if p[k].requires_grad and not k.startswith("attention_fusion."):
+            check_summary(g, f"train/B6/{k}", p[k].grad, rtol=5e-4, atol_frac=1e-4)
+    for k, v in st.items():
+        if "running" in k:
+            assert_close(v.numpy(), g[f"train/B6/bn/{k}"], rtol=1e-5, what=k)

@@ -325,6 +325,9 @@ def main():
     # PCA-MLP fusion with the single-head AttentionFusion (softmax over a size-1 dim => weights == 1)
     case_model("rdkit_pca", M + "multi_input_data_regression_opt_transformer_cnn_rdkit.py",
                128, 256, 256, Bs=(1, 9), init_seed=3, train_Bs=(6,))
+    # PCA-MLP fusion with 256-wide BatchNorm + Dropout(0.3) branches, fusion over 512 columns
+    case_model("opt_more", M + "multi_input_data_regression_opt_transformer_cnn_opt_more.py",
+               64, 128, 128, Bs=(1, 9), init_seed=11, train_Bs=(6,))
     case_ops()
     if not only or "xgb_head" in only:
         case_xgb_head()
