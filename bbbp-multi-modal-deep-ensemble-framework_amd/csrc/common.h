@@ -48,6 +48,11 @@ int bbbp_ensure_dyn_lds(const void* kernel, size_t bytes);   // hipFuncAttribute
 // grids left free.  Measured without it: a 5 us kernel sharing CUs with a conv kernel takes 35-85 us.
 extern thread_local int g_bbbp_reserved_cus;
 extern thread_local size_t g_bbbp_small_lds_pad;
+// engine scope: keep the first conv stage's forward on the f32 kernel for this call even when bit 6 of the conv mask selects the split-bf16
+// form.  Set while a training step's encoder chain runs beside the image branch: the split-bf16 kernel is faster alone (0.19 vs 0.26 ms
+// at B = 512) but holds 2 x 248 registers per lane slot on every SIMD, and the forward pass of that step is bound by the encoder's
+// latency chain, which then finds no wave slots (measured: conv1 0.31 -> 0.20 ms in-step, encoder forward 1.21 -> 1.33, step 2.61 -> 2.70)
+extern thread_local int g_bbbp_conv1_fwd_f32;
 extern thread_local int g_bbbp_wino_side_cus;      // CUs the Winograd conv grids leave free while the engine overlaps its branches
 // head.hip: fused fusion-block + regression-head forward (two launches); `partial`: ceil(B/16) * 2 * 256 floats
 int bbbp_head_forward_fused(hipStream_t st, const float* comb, const float* const* fw1, const float* const* fb1,
@@ -104,6 +109,9 @@ int bbbp_b3_conv2_fwd(hipStream_t st, const float* x, const float* w, const floa
 int bbbp_b3_conv2_dgrad(hipStream_t st, const float* gy, const uint8_t* gmask, const float* w, float* dx, int B, void* workspace);
 int bbbp_b3_conv2_wgrad(hipStream_t st, const float* x, const float* gy, const uint8_t* mask, float* slab, float* bslab, int B, int grid);
 int bbbp_b3_last_clock(unsigned long long* shader_cycles, unsigned long long* ticks_100mhz);
+// conv_b3c1.hip: forward of the first stage (3 -> 32 @ 128x128) in the same arithmetic, channel-innermost LDS strip, no operand assembly
+size_t bbbp_b3_conv1_fwd_workspace_bytes();
+int bbbp_b3_conv1_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* y, uint8_t* mask, int B, void* workspace);
 int bbbp_b3_conv1_wgrad(hipStream_t st, const float* x, const float* gy, const uint8_t* mask, float* slab, float* bslab, int B, int grid);
 int bbbp_wino_last_phases(unsigned long long* phases4);     // BBBP_WINO_PROBE=1 builds of the kernel only
 

@@ -801,7 +801,7 @@ inline int winograd_mask() {
     // the training step 0.47 / 0.42 vs 0.57 / 0.61 ms: 66 KB of LDS and 160 registers per wave leave room for the other branch's
     // kernels on every CU (the Winograd work-groups take whole CUs and give 64 of them up), and a bf16 MFMA holds the vector issue
     // for 8 of its 32 cycles where the f32 MFMA blocks it for all 64
-    if (g_winograd < 0) { const char* e = getenv("BBBP_CONV_WINOGRAD"); g_winograd = e ? atoi(e) & 127 : 60; }
+    if (g_winograd < 0) { const char* e = getenv("BBBP_CONV_WINOGRAD"); g_winograd = e ? atoi(e) & 127 : 124; }
     return g_winograd;
 }
 
@@ -861,6 +861,10 @@ extern "C" int bbbp_conv3x3_relu_pool_fwd(void* stream, const float* x, const fl
         BBBP_CHECK_ARG(workspace_bytes >= (size_t)16 * 32 * 64 * sizeof(float), "conv fwd: workspace too small");
         g_last_clock_wino = 1;
         return bbbp_wino_conv2_fwd(st, x, w, bias, y, mask, B, wt);
+    }
+    if (cin == 3 && cout == 32 && W == 128 && (winograd_mask() & 64) && !g_bbbp_conv1_fwd_f32) {          // split-bf16 forward of the first stage (conv_b3c1.hip)
+        BBBP_CHECK_ARG(workspace_bytes >= bbbp_b3_conv1_fwd_workspace_bytes(), "conv fwd: workspace too small");
+        return bbbp_b3_conv1_fwd(st, x, w, bias, y, mask, B, workspace);
     }
     int total = 9 * cinp * cout;
     hipLaunchKernelGGL(conv_prep_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, wt, cin, cout, cinp, MODE_FWD);

@@ -94,8 +94,11 @@ int bbbp_conv_last_clock(unsigned long long* shader_cycles, unsigned long long* 
  * bit 2 = forward, bit 3 = data gradient, bit 4 = weight gradient run as the direct implicit GEMM on the bf16 matrix pipe with
  * every float32 operand split into three bf16 pieces (six bf16 products per float32 product, float32 accumulate: float32
  * accuracy, csrc/conv_b3.hip); these bits take precedence over the Winograd bits.  bit 5 = the weight gradient of the 3->32 @
- * 128x128 stage (R:85-87) in the same split-bf16 form.  0 = direct implicit GEMM on the f32 MFMA everywhere.  Initial value:
- * environment BBBP_CONV_WINOGRAD, else 60. */
+ * 128x128 stage (R:85-87) in the same split-bf16 form; bit 6 = that stage's forward (csrc/conv_b3c1.hip: channel-innermost LDS strip,
+ * in-lane pooling windows).  Inside bbbp_mixed_forward the engine keeps the first stage's forward on the f32 kernel while a training
+ * step's encoder chain runs beside it (the split-bf16 kernel leaves that chain no wave slots: measured slower for the step), so bit 6
+ * acts on eval / screening passes, the encoder-less two-branch model, single-stream runs and the op-level entry point.
+ * 0 = direct implicit GEMM on the f32 MFMA everywhere.  Initial value: environment BBBP_CONV_WINOGRAD, else 124. */
 int bbbp_set_conv_winograd(int mask);
 int bbbp_get_conv_winograd(void);
 /* Measurement aid: with BBBP_WINO_PROBE=1 in the environment the Winograd kernels stamp the shader clock at phase boundaries;

@@ -327,11 +327,14 @@ def test_fused_head_backward_matches_the_launch_per_op_chain(dev, B, training):
         assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), float(b.abs().max()))
 
 
-@pytest.mark.parametrize("conv2_form", [0, 3, 60], ids=["direct", "winograd", "split-bf16-default"])
-def test_real_molecule_images_against_oracle(dev, conv2_form):
+@pytest.mark.parametrize("conv2_form,overlap", [(0, 1), (3, 1), (124, 1), (124, 0)],
+                         ids=["direct", "winograd", "split-bf16-default", "split-bf16-one-stream"])
+def test_real_molecule_images_against_oracle(dev, conv2_form, overlap):
     """The eight depictions shipped with the reference (tests/golden/img, white background: large flat regions, i.e. exact
     ties inside pooling windows in BOTH conv stages) through the full model: output, loss and every gradient element against
-    the float64 oracle, for the direct and the Winograd form of conv2.  A mis-routed tie would show up in the conv gradients."""
+    the float64 oracle, for the direct and the Winograd form of conv2 and the split-bf16 default.  On one stream (overlap off) the
+    first stage's forward runs in the split-bf16 form too (conv_b3c1.hip; beside the encoder chain the engine keeps the f32 kernel).
+    A mis-routed tie would show up in the conv gradients."""
     import glob, os
     from bbbp_amd import _lib
     from oracle import preprocess_cpu
@@ -352,7 +355,7 @@ def test_real_molecule_images_against_oracle(dev, conv2_form):
     lo = oracle.mse_loss(ref_out, y.double())
     lo.backward()
     L = _lib.lib()
-    old = L.bbbp_get_conv_winograd()
+    old, old_o = L.bbbp_get_conv_winograd(), L.bbbp_set_overlap(overlap)
     _lib.check(L.bbbp_set_conv_winograd(conv2_form), "bbbp_set_conv_winograd")
     try:
         out = m(fp.to(dev), img.to(dev))
@@ -360,6 +363,7 @@ def test_real_molecule_images_against_oracle(dev, conv2_form):
         loss.backward()
     finally:
         L.bbbp_set_conv_winograd(old)
+        L.bbbp_set_overlap(old_o)
     assert_close(out.detach().cpu().numpy().reshape(-1), ref_out.detach().numpy().reshape(-1), rtol=1e-4, atol_frac=1e-5, what="output")
     assert abs(float(loss.detach()) - float(lo.detach())) <= 1e-4 * abs(float(lo.detach()))
     for k, q in m.named_parameters():

@@ -176,11 +176,12 @@ def _conv_case(dev, B, cin, cout, hw, seed, uniform_patches=False):
         assert_close(dx.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol_frac=2e-5, what="conv dx")
 
 
-@pytest.fixture(params=[0, 32], ids=["f32", "split-bf16"])
+@pytest.fixture(params=[0, 32, 96], ids=["f32", "split-bf16-wgrad", "split-bf16-fwd+wgrad"])
 def conv1_algo(request):
-    """The forms of the 3 -> 32 @ 128x128 stage: f32 MFMA kernels, or (bit 5 of bbbp_set_conv_winograd) the weight gradient on the
-    bf16 matrix pipe with split operands (conv_b3.hip); the forward stays on the f32 MFMA (a split-bf16 forward was built and
-    measured slower: 0.283 vs 0.267 ms, its per-lane operand assembly and pooling epilogue outweigh the cheaper MFMAs)."""
+    """The forms of the 3 -> 32 @ 128x128 stage: f32 MFMA kernels; bit 5 of bbbp_set_conv_winograd: the weight gradient on the bf16
+    matrix pipe with split operands (conv_b3.hip); bit 6 (round 3): the forward too (conv_b3c1.hip: channel-innermost LDS strip, a
+    lane's operand is two taps = two aligned 8-byte reads, no operand assembly -- round 2's first split-bf16 forward assembled operands
+    per lane with 72 alignbits per 36 MFMAs and lost)."""
     L = _lib.lib()
     old = L.bbbp_get_conv_winograd()
     _lib.check(L.bbbp_set_conv_winograd(request.param), "bbbp_set_conv_winograd")
@@ -191,6 +192,32 @@ def conv1_algo(request):
 @pytest.mark.parametrize("B", [1, 3, 9])
 def test_conv1_3to32(dev, B, conv1_algo):
     _conv_case(dev, B, 3, 32, 128, seed=10 + B)
+
+
+def test_conv1_split_bf16_forward_keeps_ties_and_matches_f32(dev):
+    """conv_b3c1.hip against the f32 form on an image with a flat band (the white background of the depictions: the four pre-activations
+    of a pooling window are computed from identical inputs, hence bit-equal in either form, and PyTorch's first-maximum rule must pick
+    position 0 -- or 4 when the value is not positive): masks identical on the band and on >= 99.99 % of the random part, values to
+    float32 rounding; a ragged batch (B = 5 < one strip set per work-group) and the image borders are in the comparison."""
+    L = _lib.lib()
+    old = L.bbbp_get_conv_winograd()
+    x = rnd(5, 3, 128, 128, seed=91)
+    x[:, :, 20:90, :] = 1.0                                  # flat band incl. the left / right borders
+    x[1] = 1.0                                               # a completely flat image: every window a tie, every border case
+    w, b = rnd(32, 3, 3, 3, seed=92, scale=0.2), rnd(32, seed=93, scale=0.1)
+    try:
+        L.bbbp_set_conv_winograd(0)
+        y0, m0 = ops.conv3x3_relu_pool_fwd(x.to(dev), w.to(dev), b.to(dev))
+        L.bbbp_set_conv_winograd(64)
+        y1, m1 = ops.conv3x3_relu_pool_fwd(x.to(dev), w.to(dev), b.to(dev))
+    finally:
+        L.bbbp_set_conv_winograd(old)
+    assert float((y1 - y0).abs().max()) <= 2e-6 * float(y0.abs().max())
+    band = slice(11, 44)                                     # pooled rows whose 3x3 neighbourhoods lie inside the flat band
+    assert torch.equal(m1[:, :, band, 1:63], m0[:, :, band, 1:63])
+    assert set(torch.unique(m1[:, :, band, 1:63]).tolist()) <= {0, 4}
+    assert torch.equal(m1[1], m0[1])                         # the flat image, borders included
+    assert float((m1 != m0).float().mean()) < 1e-4           # near-ties on the random part only
 
 
 @pytest.fixture(params=[0, 3, 28], ids=["direct", "winograd", "split-bf16"])

@@ -23,7 +23,7 @@ def main():
     gy = torch.randn(B, 32, 64, 64, generator=g).to(dev)
     ref = None
     old = L.bbbp_get_conv_winograd()
-    for mask, name in ((0, "f32"), (32, "split-bf16 weight gradient")):
+    for mask, name in ((0, "f32"), (32, "split-bf16 weight gradient"), (96, "split-bf16 forward + weight gradient")):
         L.bbbp_set_conv_winograd(mask)
         y, m = ops.conv3x3_relu_pool_fwd(x, w, bias)
         dw, db = ops.conv3x3_relu_pool_bwd_weight(x, gy, m)
@@ -32,7 +32,7 @@ def main():
         if ref is None:
             ref = (y, m, dw, db)
         fb = B * (3 * 128 * 128 * 4 + 32 * 64 * 64 * 5)
-        print(f"{name:10s} B={B}: fwd {tf:.3f} ms ({fb / tf / 1e6:.0f} GB/s), wgrad {tw:.3f} ms ({fb / tw / 1e6:.0f} GB/s); "
+        print(f"{name:38s} B={B}: fwd {tf:.3f} ms ({fb / tf / 1e6:.0f} GB/s), wgrad {tw:.3f} ms ({fb / tw / 1e6:.0f} GB/s); "
               f"max|y - f32| {float((y - ref[0]).abs().max()):.2e}, masks equal {bool((m == ref[1]).all())}, "
               f"max|dw - f32| {float((dw - ref[2]).abs().max()):.2e} of {float(ref[2].abs().max()):.2e}, "
               f"max|db - f32| {float((db - ref[3]).abs().max()):.2e} of {float(ref[3].abs().max()):.2e}", flush=True)
