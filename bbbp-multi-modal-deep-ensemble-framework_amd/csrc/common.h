@@ -136,6 +136,10 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // clang vectors stay in registers; arrays of HIP's uint4 struct were demoted to scratch
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // hi / mid / lo of two floats, packed pairwise (a in the low half).  The residuals are formed with packed-f32 subtractions.
+// Range: |x| > 3.3895e38 (the largest bf16, 0x7F7F) rounds to +-inf in the `hi` piece and the residuals become -+inf / NaN: such an
+// element poisons its products like an overflow would.  Irrelevant on this path (standardised inputs, weights of order 1, gradients
+// far below 1e38) -- stated so that nobody re-uses the split on unscaled data without a clamp.  NaN stays NaN, +-inf stays +-inf in
+// `hi` (v_cvt_pk_bf16_f32) with NaN residuals.
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
     f32x2v v = {a, b};
     bf16x2 h = __builtin_convertvector(v, bf16x2);

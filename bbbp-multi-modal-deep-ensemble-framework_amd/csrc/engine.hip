@@ -537,7 +537,8 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         Section s1(c.st, SEC_CONV1_FWD);
         // beside a training step's encoder chain the f32 form stays (common.h: g_bbbp_conv1_fwd_f32); screening batches, eval loops and
         // the encoder-less two-branch model take the split-bf16 form when the conv mask selects it (bit 6, default)
-        g_bbbp_conv1_fwd_f32 = (ss != nullptr && !plan.inference && plan.L > 0) ? 1 : 0;
+        // (the rule looks at the plan only, not at the stream mode: one stream or three give bit-identical steps)
+        g_bbbp_conv1_fwd_f32 = (!plan.inference && plan.L > 0) ? 1 : 0;
         const int rc1 = bbbp_conv3x3_relu_pool_fwd(c.st, image, P[ix.c1_w()], P[ix.c1_b()], pool1, c.u8(plan.mask1), B, 3, C1, IMG, IMG,
                                                    c.scratch(), c.scratch_bytes());
         g_bbbp_conv1_fwd_f32 = 0;

@@ -97,7 +97,7 @@ int bbbp_conv_last_clock(unsigned long long* shader_cycles, unsigned long long* 
  * 128x128 stage (R:85-87) in the same split-bf16 form; bit 6 = that stage's forward (csrc/conv_b3c1.hip: channel-innermost LDS strip,
  * in-lane pooling windows).  Inside bbbp_mixed_forward the engine keeps the first stage's forward on the f32 kernel while a training
  * step's encoder chain runs beside it (the split-bf16 kernel leaves that chain no wave slots: measured slower for the step), so bit 6
- * acts on eval / screening passes, the encoder-less two-branch model, single-stream runs and the op-level entry point.
+ * acts on forward-only (inference-plan) passes -- eval loops, screening --, the encoder-less two-branch model and the op-level entry point.
  * 0 = direct implicit GEMM on the f32 MFMA everywhere.  Initial value: environment BBBP_CONV_WINOGRAD, else 124. */
 int bbbp_set_conv_winograd(int mask);
 int bbbp_get_conv_winograd(void);

@@ -328,13 +328,13 @@ def test_fused_head_backward_matches_the_launch_per_op_chain(dev, B, training):
 
 
 @pytest.mark.parametrize("conv2_form,overlap", [(0, 1), (3, 1), (124, 1), (124, 0)],
-                         ids=["direct", "winograd", "split-bf16-default", "split-bf16-one-stream"])
+                         ids=["direct", "winograd", "split-bf16-default", "split-bf16-default-one-stream"])
 def test_real_molecule_images_against_oracle(dev, conv2_form, overlap):
     """The eight depictions shipped with the reference (tests/golden/img, white background: large flat regions, i.e. exact
     ties inside pooling windows in BOTH conv stages) through the full model: output, loss and every gradient element against
-    the float64 oracle, for the direct and the Winograd form of conv2 and the split-bf16 default.  On one stream (overlap off) the
-    first stage's forward runs in the split-bf16 form too (conv_b3c1.hip; beside the encoder chain the engine keeps the f32 kernel).
-    A mis-routed tie would show up in the conv gradients."""
+    the float64 oracle, for the direct and the Winograd form of conv2 and the split-bf16 default (on three streams and on one).
+    A mis-routed tie would show up in the conv gradients.  The eval-mode forward of the same images follows: there (inference plan) the
+    first stage runs in its split-bf16 form as well (conv_b3c1.hip; in a training step the engine keeps that stage's f32 kernel)."""
     import glob, os
     from bbbp_amd import _lib
     from oracle import preprocess_cpu
