@@ -621,7 +621,10 @@ struct DirectOperand {
 template <int LAYOUT, int TM, int TN>
 __device__ __forceinline__ void gemm_direct_body(const DirectParams& p, int batch, float* red) {
     constexpr bool A_KMAJ = (LAYOUT == 2), B_KMAJ = (LAYOUT != 0);
-    constexpr int D = 4;                         // chunks in flight per wave
+#ifndef BBBP_DIRECT_DEPTH
+#define BBBP_DIRECT_DEPTH 4
+#endif
+    constexpr int D = BBBP_DIRECT_DEPTH;         // chunks in flight per wave (A/B builds: -DBBBP_DIRECT_DEPTH=n, tools/build_variant.sh)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ks = wave % p.ks, sp = wave / p.ks;
     const int wm = sp / p.wsn, wn = sp % p.wsn;

@@ -50,7 +50,7 @@ IMG_FLAT = 3 * 128 * 128
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense (MI355X_MICROARCH.md: Matrix cores)
 HBM_PEAK_GBS = 8000.0
-ROUND = "r02"
+ROUND = "r03"
 
 CONFIGS = {
     2: dict(F=167, batch=256, train=True, model="TwoBranchConcatModel", layers=0, fusion=False,
