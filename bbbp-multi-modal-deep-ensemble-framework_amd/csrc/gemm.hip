@@ -280,7 +280,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 //     80-byte row stride; a k-major global tile ([K][M]) is transposed in registers: a thread loads a 4 (k) x 4 (m) block with four
 //     16-byte loads and writes four 8-byte k-quads per plane.  The rows a half-wave writes are 4 apart (80 * 4 bytes = 16 banks): no
 //     bank conflicts on the way in either;
-//   * needs K % 32 == 0 (no K tail: no selects in the split) and extent % 4 == 0 for a k-major operand; anything else keeps the f32 kernel.
+//   * a K that is not a multiple of 32 (round 3: the MACCS width 167 at screening batch sizes -- linear1, the in / out projections and
+//     Q K^T of a 4096-row forward) ends in ONE partial stage whose loads are element-wise with clamped addresses and zero fill
+//     (B3Loader::load_tail); every other stage keeps the select-free 16-byte path.  A k-major operand still needs extent % 4 == 0.
 constexpr int B3_BK = 32;
 constexpr int B3_LD = B3_BK + 8;
 constexpr int B3_PLANE = 128 * B3_LD;
@@ -289,13 +291,16 @@ constexpr size_t B3_LDS = (size_t)6 * B3_PLANE * sizeof(uint16_t);
 template <bool KMAJ>
 struct B3Loader {
     const float* ptr[4];     // this thread's four 16-byte loads of the next stage to fetch
+    const float* X0;         // a valid address for clamped loads of the tail stage
     long step;               // pointer advance per stage
+    int kpos, kend;          // k of this thread's first element in the next stage to fetch; end of this work-group's K range
     int soff[4];             // LDS offsets (bf16 elements) of its four k-quads
     f32x4u raw[2][4];
     u32x2 pk[4][3];
     // thread (kq = t & 7, rq = t >> 3): k-contiguous operand: rows row(rq) + 32 i, k = 4 kq ..+3;  k-major: k = 4 kq + j, rows 4 rq ..+3
-    __device__ __forceinline__ void init(const float* X, int ld, int extent, int row0, int kbeg, int t) {
+    __device__ __forceinline__ void init(const float* X, int ld, int extent, int row0, int kbeg, int kend_, int t) {
         const int kq = t & 7, rq = t >> 3;
+        X0 = X; kpos = kbeg + 4 * kq; kend = kend_;
         if constexpr (KMAJ) {
             const int col = min(row0 + 4 * rq, extent - 4);
 #pragma unroll
@@ -315,6 +320,29 @@ struct B3Loader {
     __device__ __forceinline__ void load(int set) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { raw[set][i] = *reinterpret_cast<const f32x4u*>(ptr[i]); ptr[i] += step; }
+        kpos += B3_BK;
+    }
+    // the last, partial stage of a K range that is not a multiple of 32: k >= kend contributes zeros
+    __device__ __forceinline__ void load_tail(int set) {
+        if constexpr (KMAJ) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = kpos + j < kend;
+                const f32x4u v = *reinterpret_cast<const f32x4u*>(ok ? ptr[j] : X0);
+                raw[set][j] = ok ? v : f32x4u{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+            const int nv = kend - kpos;                      // valid elements of this thread's quad (<= 0: none)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* q = nv > 0 ? ptr[i] : X0;
+                f32x4u v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float x = q[e < nv ? e : 0]; v[e] = e < nv ? x : 0.f; }
+                raw[set][i] = v;
+            }
+        }
+        kpos += B3_BK;
     }
     __device__ __forceinline__ void split(int set) {
 #pragma unroll
@@ -357,12 +385,17 @@ __device__ __forceinline__ void gemm_b3_body(const GemmParams& p) {
     const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
     const int kbeg = split * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
-    const int nt = (kend - kbeg) / B3_BK;                 // K % 32 == 0 and kchunk % 32 == 0: whole stages only
+    const int nt = (kend - kbeg + B3_BK - 1) / B3_BK;     // kchunk % 32 == 0: only the last K range can end in a partial stage
+    const int tail_stage = ((kend - kbeg) % B3_BK) ? nt - 1 : -1;
 
     B3Loader<A_KMAJ> la;
     B3Loader<B_KMAJ> lb;
-    la.init(p.A + (long)batch * p.sA, p.lda, p.M, m0, kbeg, t);
-    lb.init(p.B + (long)batch * p.sB, p.ldb, p.N, n0, kbeg, t);
+    la.init(p.A + (long)batch * p.sA, p.lda, p.M, m0, kbeg, kend, t);
+    lb.init(p.B + (long)batch * p.sB, p.ldb, p.N, n0, kbeg, kend, t);
+    auto load_stage = [&](int stage, int set) __attribute__((always_inline)) {
+        if (stage == tail_stage) { la.load_tail(set); lb.load_tail(set); }       // wave-uniform
+        else { la.load(set); lb.load(set); }
+    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -373,8 +406,8 @@ __device__ __forceinline__ void gemm_b3_body(const GemmParams& p) {
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
     if (nt > 0) {
-        la.load(0); lb.load(0);
-        if (nt > 1) { la.load(1); lb.load(1); }
+        load_stage(0, 0);
+        if (nt > 1) load_stage(1, 1);
         la.split(0); lb.split(0);
         la.store(As); lb.store(Bs);
     }
@@ -388,7 +421,7 @@ __device__ __forceinline__ void gemm_b3_body(const GemmParams& p) {
             if (cur >= nt) break;
             if (PROBE) c0 = __builtin_readcyclecounter();
             // float32 set u held stage `cur` (split one stage ago): refill it with stage cur + 2
-            if (cur + 2 < nt) { la.load(u); lb.load(u); }
+            if (cur + 2 < nt) load_stage(cur + 2, u);
             if (PROBE) { const unsigned long long c = __builtin_readcyclecounter(); ph[0] += c - c0; c0 = c; }
 #pragma unroll
             for (int kk = 0; kk < B3_BK / 16; ++kk) {
@@ -963,7 +996,7 @@ int gemm_b3_on() {
 }
 // the split-bf16 form serves 128 x 128 plans whose operands can be read in aligned-extent quads
 bool b3_eligible(const GemmParams& p, int layout) {
-    if (!gemm_b3_on() || p.K < 32 || p.K % 32 != 0) return false;
+    if (!gemm_b3_on() || p.K < 32) return false;          // any K >= 32: a partial last stage is handled by B3Loader::load_tail
     const bool a_ok = layout != 2 || (p.M % 4 == 0 && p.M >= 4);
     const bool b_ok = layout == 0 || (p.N % 4 == 0 && p.N >= 4);
     return a_ok && b_ok;
@@ -997,6 +1030,14 @@ static void gemm_plan(int M, int N, int K, int batch, int* tile, int* splits, in
     {
         const long covered = (long)cdiv(M, 128) * 128 * (long)cdiv(N, 128) * 128;
         if (K >= 512 && M >= 256 && N >= 256 && covered * 100 <= (long)M * N * 115) *tile = 128;
+    }
+    // A deep K over many rows and one or two column tiles (linear2 of a 4096-row screening batch: N = 167, K = 2048): the 64 x 64 f32
+    // plan runs it at 49 TFLOP/s (66 us); on the bf16 pipe the padded columns (167 -> 256) cost less than the pipe gains.
+    // BBBP_GEMM_TALL_B3=0 keeps the old plan.
+    {
+        static const int tall = [] { const char* e = getenv("BBBP_GEMM_TALL_B3"); return e ? atoi(e) : 1; }();
+        const long covered = (long)cdiv(M, 128) * 128 * (long)cdiv(N, 128) * 128;
+        if (tall && K >= 1024 && M >= 1024 && N >= 128 && covered * 10 <= (long)M * N * 16) *tile = 128;
     }
     long tiles = (*tile == 128) ? t128 : t64;
     // Few output tiles and a deep K (weight gradients over the batch, the 65536-wide image FC, FFN2): these

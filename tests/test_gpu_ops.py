@@ -25,7 +25,12 @@ GEMM_SHAPES = [(512, 501, 167), (512, 167, 167), (512, 2048, 167), (512, 167, 20
                (384, 49152, 128), (512, 33000, 100),
                # 128 x 128 tiles on the bf16 pipe with split operands: full tiles, ragged M / N, K not a multiple of the 32-deep stage,
                # split-K over a deep K; (516, 1028, 514): K % 4 != 0 keeps the f32 kernel for the k-contiguous layouts
-               (512, 2048, 2048), (500, 2044, 516), (260, 6144, 2048), (2048, 2048, 512), (516, 1028, 514)]
+               (512, 2048, 2048), (500, 2044, 516), (260, 6144, 2048), (2048, 2048, 512), (516, 1028, 514),
+               # a K that ends in a partial 32-deep stage on the bf16 pipe (B3Loader::load_tail): linear1 / Q K^T of a 4096-row screening
+               # batch at the MACCS width (K = 167 = 5 stages + 7), and a tail of exactly one element
+               (4096, 2048, 167), (4096, 4096, 167), (1024, 2048, 161),
+               # tall, deep-K product with one or two column tiles (linear2 of a 4096-row screening batch): 128 x 128 plan, ragged N, split-K
+               (4096, 167, 2048), (2048, 130, 1024)]
 
 
 @pytest.fixture(params=[1, 0], ids=["split-bf16", "f32"])
