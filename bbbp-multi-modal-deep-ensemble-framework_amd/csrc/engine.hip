@@ -6,6 +6,7 @@
 // (R below) and its autograd under loss.backward() (R:190).  The encoder is called with a [B,1,F]
 // tensor and batch_first=False (R:110-111), so self-attention runs ACROSS the mini-batch: S = B, N = 1.
 #include "common.h"
+#include "attention_b3.h"
 #include <optional>
 #include "bbbp_hip.h"
 #include <mutex>
@@ -63,6 +64,8 @@ struct Plan {
     int B, F, NH, D, L, DFF;
     bool drop, concat, inference;
     bool flash;            // many heads of head_dim 8 / 16: fused attention (attention.hip), no [NH,B,B] probability tensors
+    bool attn_b3;          // forward-only plan, wide head, >= 1024 rows: split-bf16 attention (attention_b3.hip)
+    size_t attn_part, attn_part_bytes;
     LayerOff layer[32];
     LayerGrad lgrad[32];
     size_t scratch3, scratch3_bytes;
@@ -92,11 +95,15 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     p->B = d->batch; p->F = d->fingerprint_size; p->NH = d->nhead; p->D = p->F / p->NH; p->L = d->num_layers;
     p->DFF = d->dim_feedforward;
     p->drop = d->training && d->dropout_p > 0.f;
-    if (g_flash_attention < 0) { const char* e = getenv("BBBP_FLASH_ATTENTION"); g_flash_attention = e ? atoi(e) & 7 : 5; }
+    if (g_flash_attention < 0) { const char* e = getenv("BBBP_FLASH_ATTENTION"); g_flash_attention = e ? atoi(e) & 31 : 13; }
+    // bit 3 (round 3): forward-only plans of 2048 rows and more with a wide head run the split-bf16 attention kernel (attention_b3.hip);
+    // bit 4: that kernel from 256 rows on (tests; below ~2048 rows its 128-query work-groups leave most CUs idle)
+    p->attn_b3 = (g_flash_attention & 8) && p->inference && p->L > 0 && p->B >= ((g_flash_attention & 16) ? 256 : 2048) &&
+                 bbbp_attn_b3_supported(p->B, p->NH, p->D);
     // bit 2: the wide-head kernel where it wins -- forward-only plans of 2048 rows and more (256+ work-groups fill the chip and the
     // [B, B] probability tensor, 67 MB per layer at B = 4096, is never written): config 5 8.28 -> 7.84 ms per 4096 molecules
     const bool wide = (g_flash_attention & 2) || ((g_flash_attention & 4) && p->inference && p->B >= 2048);
-    p->flash = p->L > 0 && (((g_flash_attention & 1) && bbbp_attn_small_supported(p->B, p->NH, p->D)) ||
+    p->flash = p->L > 0 && (p->attn_b3 || ((g_flash_attention & 1) && bbbp_attn_small_supported(p->B, p->NH, p->D)) ||
                             (wide && bbbp_attn_wide_supported(p->B, p->NH, p->D)));
     const size_t B = p->B, F = p->F, NH = p->NH, DFF = p->DFF;
     Bump b;
@@ -120,6 +127,8 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
         o.z1 = b.f(B * F); o.y1 = b.f(B * F); o.hff = b.f(B * DFF); o.z2 = b.f(B * F); o.y2 = b.f(B * F);
         o.mean1 = b.f(B); o.rstd1 = b.f(B); o.mean2 = b.f(B); o.rstd2 = b.f(B);
     }
+    p->attn_part_bytes = p->attn_b3 ? bbbp_attn_b3_workspace_bytes(p->B, p->NH, p->D) : 0;
+    p->attn_part = p->attn_part_bytes ? b.take(p->attn_part_bytes) : 0;
     p->pool1 = b.f(B * C1 * (IMG / 2) * (IMG / 2)); p->mask1 = b.take(B * C1 * (IMG / 2) * (IMG / 2));
     p->pool2 = b.f(B * IMG_FLAT); p->mask2 = b.take(B * IMG_FLAT);
     p->combined = b.f(B * COMB); p->hid = b.f(NHEADS_FUSION * B * FUS_HID); p->attn = b.f(B * NHEADS_FUSION);
@@ -451,9 +460,9 @@ extern "C" int bbbp_set_fused_encoder(int on) {
 }
 
 extern "C" int bbbp_set_flash_attention(int on) {
-    if (g_flash_attention < 0) { const char* e = getenv("BBBP_FLASH_ATTENTION"); g_flash_attention = e ? atoi(e) & 7 : 5; }
+    if (g_flash_attention < 0) { const char* e = getenv("BBBP_FLASH_ATTENTION"); g_flash_attention = e ? atoi(e) & 31 : 13; }
     const int prev = g_flash_attention;
-    g_flash_attention = on & 7;
+    g_flash_attention = on & 31;
     return prev;
 }
 
@@ -596,7 +605,9 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         }
         std::optional<Section> sec_attn;
         sec_attn.emplace(ce.st, SEC_ATTN_FWD);
-        if (plan.flash) {
+        if (plan.attn_b3) {
+            TRY(bbbp_attn_b3_fwd(ce.st, qkv, ctx, B, F, NH, scale, plan.attn_part_bytes ? c.f(plan.attn_part) : nullptr, plan.attn_part_bytes));
+        } else if (plan.flash) {
             TRY(bbbp_attn_small_fwd(ce.st, qkv, ctx, c.f(o.lse), B, F, NH, scale, p_drop, site_seed(d->seed, l, 0), o.keep ? c.u8(o.keep) : nullptr));
         } else {
         // scores_h = scale * Q_h K_h^T

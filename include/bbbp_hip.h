@@ -294,11 +294,14 @@ int bbbp_set_fused_head_bwd(int on);
  * out_proj input gradient backward) as ONE launch each (csrc/encoder.hip) instead of 6 + 6, for d_model <= 192 (default OFF:
  * measured slower, see csrc/engine.hip; initial value BBBP_FUSED_ENCODER).  Returns the previous setting.  Both schedules fill the same workspace. */
 int bbbp_set_fused_encoder(int on);
-/* Fused flash-style self-attention (csrc/attention.hip), a bit mask (default 5, initial value BBBP_FLASH_ATTENTION):
+/* Fused flash-style self-attention (csrc/attention.hip, csrc/attention_b3.hip), a bit mask (default 13, initial value BBBP_FLASH_ATTENTION):
  * bit 0: many heads of head_dim 8 / 16 (F = 2048: 256 x 8), one work-group per head, scores in registers, no [nhead, B, B] tensors;
  * bit 1: one wide head of 161 .. 176 columns (F = 167, nhead = 1), operands straight from global memory, everywhere -- correct but
  *        measured slower than the batched-GEMM + softmax schedule in the B = 512 .. 2048 training steps, hence opt-in;
- * bit 2: that kernel only where it is faster: forward-only (inference) plans of 2048 rows and more (screening batches).
+ * bit 2: that kernel only where it is faster: forward-only (inference) plans of 2048 rows and more (screening batches);
+ * bit 3: forward-only plans of 2048 rows and more (bit 4: from 256 rows, for tests) with a wide head (96 < head_dim <= 192) on the bf16 matrix pipe with split operands
+ *        (attention_b3.hip: K / V^T tiles staged once per 128 queries, scores fed back as the second product's operand, key axis split
+ *        over work-groups + a merge pass); takes precedence over bit 2.
  * 0 selects the batched GEMM + softmax schedule everywhere.  Returns the previous mask.  Changes the workspace layout: set it
  * before the forward call, not between forward and backward. */
 int bbbp_set_flash_attention(int on);

@@ -452,6 +452,32 @@ def test_fused_small_head_attention_matches_materialised_attention(dev, F, B, tr
             assert rel <= 2e-3 and float((g0[k] - g1[k]).abs().max()) <= 5e-2 * float(g0[k].abs().max()), (k, rel)
 
 
+@pytest.mark.parametrize("B", [1024, 1100, 2500])
+def test_wide_head_bf16_attention_matches_materialised_attention(dev, B):
+    """csrc/attention_b3.hip (forward-only plans of 1024+ rows: the single 167-wide head of the MACCS encoder on the bf16 matrix pipe with
+    split operands, key axis split over work-groups + merge pass) against the batched-GEMM + softmax schedule with materialised
+    probabilities, eval mode: outputs agree to float32 rounding.  1100 / 2500 rows: ragged last query block, ragged last key tile,
+    key ranges of unequal length; and against the float64 oracle at B = 1100."""
+    from bbbp_amd import _lib
+    L = _lib.lib()
+    m = build(167, 31, dev).eval()
+    fp, img, _ = synth_inputs(900 + B, B, 167, 49152)
+    outs = {}
+    for flash in (0, 13 | 16):           # bit 4: the kernel from 256 rows on (the default starts it at 2048 rows)
+        old = L.bbbp_set_flash_attention(flash)
+        try:
+            with torch.no_grad():
+                outs[flash & 15] = m(fp.to(dev), img.to(dev)).cpu().double()
+        finally:
+            L.bbbp_set_flash_attention(old)
+    assert float((outs[0] - outs[13]).abs().max()) <= 2e-5 * float(outs[0].abs().max()) + 1e-7
+    if B == 1100:
+        p = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        with torch.no_grad():
+            want = oracle.mixed_input_forward(p, fp, img, training=False)
+        assert_close(outs[13].numpy(), want.numpy(), rtol=1e-4, atol_frac=2e-5, what="B=1100 eval, bf16-pipe attention")
+
+
 def test_two_host_threads_drive_two_models(dev):
     """The library's per-call scopes are thread-local and the engine serialises ENQUEUEING: two host threads, each training its own
     model on its own stream at the same time, get bit for bit what they get one after the other.  (Models and inputs are built on
