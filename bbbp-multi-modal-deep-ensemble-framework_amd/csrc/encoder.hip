@@ -16,6 +16,7 @@
 // Sized to run BESIDE the image branch's persistent conv work-groups: 4 waves (one per SIMD), <= 64 VGPRs, ~23 KB of LDS.
 #include "common.h"
 #include "bbbp_hip.h"
+#include "encoder_sliced.h"
 
 namespace {
 
@@ -76,11 +77,14 @@ struct AGlb {
 // D[n][row] = W_tile * A^T, so lane (q, kq) ends up with row q and the 4 CONSECUTIVE columns n0 = 16 t + 4 kq .. +3:
 // one Philox block per lane, 16-byte stores.  epi(n0, row, acc4) is called for every (tile, lane); columns >= N must be skipped
 // by the callee.  A must be zero beyond K (LDS rows are padded; AGlb zero-fills its tail), W's tail k is clamped.
+// Column tiles [tbeg, tend) only (tend < 0: all): the sliced persistent kernel gives every work-group of a row block its own tiles.
 template <int TPW, class ASrc, class Epi>
-__device__ __forceinline__ void rb_gemm_nt(const ASrc& A, const float* __restrict__ W, int ldw, int N, int K, int wave, int lane, Epi&& epi) {
+__device__ __forceinline__ void rb_gemm_nt(const ASrc& A, const float* __restrict__ W, int ldw, int N, int K, int wave, int lane, Epi&& epi,
+                                           int tbeg = 0, int tend = -1) {
     const int q = lane & 15, kq = lane >> 4;
-    const int ntile = (N + 15) >> 4, nfull = K >> 4, tail = K & 15;
-    for (int t0 = wave * TPW; t0 < ntile; t0 += NW * TPW) {
+    const int nfull = K >> 4, tail = K & 15;
+    const int ntile = tend < 0 ? (N + 15) >> 4 : min(tend, (N + 15) >> 4);
+    for (int t0 = tbeg + wave * TPW; t0 < ntile; t0 += NW * TPW) {
         const float* wrow[TPW];
 #pragma unroll
         for (int u = 0; u < TPW; ++u) wrow[u] = W + (long)min((t0 + u) * 16 + q, N - 1) * ldw + 4 * kq;
@@ -193,7 +197,8 @@ __device__ __forceinline__ void rows_to_lds(float* s, int ld, int ldz, const flo
 // LayerNorm of the block's rows: z (LDS, columns < F) -> y = (z - mean) rstd gamma + beta into `ys` (LDS, zero-padded) and `yg`
 // (global); the pre-norm rows go to `zg`, the statistics to mean / rstd.  4 rows per wave, eps 1e-5 (nn.LayerNorm default).
 __device__ __forceinline__ void ln_fwd_rows(const float* zs, float* ys, int ld, int ldz, int F, int nrows, long row0, const float* gamma,
-                                            const float* beta, float* zg, float* yg, float* mean_out, float* rstd_out, int wave, int lane) {
+                                            const float* beta, float* zg, float* yg, float* mean_out, float* rstd_out, int wave, int lane,
+                                            bool store = true) {
     for (int r = wave; r < ROWS; r += NW) {
         const float* z = zs + r * ld;
         float s = 0.f;
@@ -207,11 +212,11 @@ __device__ __forceinline__ void ln_fwd_rows(const float* zs, float* ys, int ld, 
             float y = 0.f;
             if (c < F) {
                 y = (z[c] - mean) * rstd * gamma[c] + beta[c];
-                if (live) { zg[(row0 + r) * F + c] = z[c]; yg[(row0 + r) * F + c] = y; }
+                if (live && store) { zg[(row0 + r) * F + c] = z[c]; yg[(row0 + r) * F + c] = y; }
             }
             ys[r * ld + c] = live ? y : 0.f;
         }
-        if (live && lane == 0) { mean_out[row0 + r] = mean; rstd_out[row0 + r] = rstd; }
+        if (live && store && lane == 0) { mean_out[row0 + r] = mean; rstd_out[row0 + r] = rstd; }
     }
 }
 
@@ -462,6 +467,270 @@ __global__ __launch_bounds__(LCW * LRL) void ln_param_grad_multi_kernel(LnGradPa
     }
 }
 
+
+// ==================================================================================================================================
+// Sliced persistent forward (round 3): the whole encoder chain of a SMALL batch (B <= 128) as one launch.
+//
+// The launch-per-op schedule needs ~78 dependent launches for the forward chain whatever the batch: at the reference's own batch size
+// (DataLoader(batch_size=32), ...20250113.py:167-168) each is at its 5-10 us latency floor and the step is bound by their count.
+// The row-fused kernels above cut the count but leave ONE work-group per 16 rows to stream a whole layer's weights (3.2 MB) by itself:
+// 0.18 ms per layer.  Here a 16-row block is shared by S work-groups ("slices") that split the COLUMN tiles of every product, so
+// S x ceil(B / 16) = 64 work-groups stream the weights; what the row kernel kept in LDS between stages goes through the workspace
+// buffers the backward pass reads anyway.  Stages of a layer, per (row block, slice):
+//   attention : every slice computes the block's 16 query rows against ALL keys redundantly (1.4 MFLOP at B = 128) -- scores in
+//               registers (one 16-key tile per wave), softmax across the 8 waves through LDS, dropout from the softmax kernel's Philox
+//               stream, P.V through LDS -- so the context rows are in every slice's LDS without a barrier; slice 0 stores prob / pd / ctx;
+//   out_proj  : its column tiles -> z1 (global)                                        | row-block barrier
+//   LN1 + linear1: LayerNorm of the 16 rows (every slice, from z1), its tiles of hff   | row-block barrier
+//   linear2   : its K range of all column tiles -> partial sums                        | row-block barrier
+//   reduce + LN2 (every slice, partials added in slice order), next in_proj tiles      | GRID barrier (the next attention reads every row)
+// Barriers are monotonic counters in device memory (zeroed before the launch): arrive = every wave drains its stores, work-group
+// barrier, lane 0: agent-scope release fence + relaxed add; wait = relaxed polling with s_sleep, then an agent-scope acquire fence
+// (invalidates this CU's L1; MI355X_MICROARCH.md "barrier-counter").  All work-groups must be resident at once: the grid is
+// <= 128 work-groups of 512 threads / 26 KB LDS; a wait that exceeds SL_SPIN_LIMIT polls sets the abort word and falls through, so a
+// launch can never hang the GPU (the host reads the word: bbbp_enc_sliced_aborted).
+// Same saved activations, same dropout streams as the launch-per-op schedule: the backward pass does not know which forward ran.
+constexpr unsigned SL_SPIN_LIMIT = 1u << 22;
+constexpr int SL_LDP = 176;            // row stride of the linear2 partials
+constexpr int SL_KSLICES = 8;          // K ranges of linear2 per row block
+
+struct SlFwdParams {
+    bbbp_enc_sliced_fwd_args a;
+    int S, NRB;
+    unsigned* bar;                     // [0] grid counter, [1 + rb] row-block counters, [SL_ABORT] abort word
+    const unsigned long long* seed_base;
+};
+constexpr int SL_ABORT = 63;
+
+__device__ __forceinline__ void sl_barrier(unsigned* ctr, unsigned target, unsigned* abort_word) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the fence's write-back has completed before the arrival is visible
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > SL_SPIN_LIMIT) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+// rows of a matrix with leading dimension ldg -> LDS rows (zero beyond F up to ldz columns and beyond the block's last valid row)
+__device__ __forceinline__ void rows_to_lds_ld(float* s, int ld, int ldz, const float* g, int ldg, int F, int nrows, int t) {
+    for (int idx = t; idx < ROWS * ldz; idx += NTH) {
+        const int r = idx / ldz, c = idx % ldz;
+        s[r * ld + c] = (r < nrows && c < F) ? g[(long)r * ldg + c] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(NTH) void enc_sliced_fwd_kernel(SlFwdParams P) {
+    BBBP_HIGH_PRIO();
+    __shared__ __attribute__((aligned(16))) float sA[ROWS * LD];          // x -> ctx -> y1 -> y2
+    __shared__ __attribute__((aligned(16))) float sB[ROWS * LD];          // Q rows -> dropped probabilities [key][16] -> z1 -> z2
+    __shared__ float sred[2][NW][16];
+    // every kernel argument used below is copied into a local first (scalars) or per layer (`Y`): a reference into the by-value
+    // argument block would make hipcc spill the whole 2 KB block to scratch
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane & 15, kq = lane >> 4;
+    const int S = P.S, rb = blockIdx.x / S, sl = blockIdx.x % S, G = gridDim.x;
+    const int B = P.a.B, F = P.a.F, DFF = P.a.DFF, L = P.a.L, F3 = 3 * F, ldz = (F + 15) & ~15, Bp = (B + 15) & ~15;
+    const float pdrop = P.a.p, scale = P.a.scale;
+    const float* const x0 = P.a.x0;
+    float* const part = P.a.part;
+    unsigned* const bar = P.bar;
+    const unsigned long long* const seed_base = P.seed_base;
+    const long row0 = (long)rb * ROWS;
+    const int nrows = min(ROWS, B - (int)row0);
+    const bool drop = pdrop > 0.f;
+    const float inv_keep = drop ? 1.f / (1.f - pdrop) : 1.f;
+    unsigned gphase = 0, rphase = 0;
+    auto grid_bar = [&]() { sl_barrier(bar, (++gphase) * (unsigned)G, bar + SL_ABORT); };
+    auto group_bar = [&]() { sl_barrier(bar + 1 + rb, (++rphase) * (unsigned)S, bar + SL_ABORT); };
+    auto my_tiles = [&](int n, int& tb, int& te) { const int nt = (n + 15) >> 4, tps = (nt + S - 1) / S; tb = sl * tps; te = min(nt, tb + tps); };
+    // the projection out[row][n] = act(rows(sA) W^T + b) of this slice's column tiles
+    auto project = [&](const float* W, const float* bias, int N, float* out, int ldo, bool relu) {
+        int tb, te; my_tiles(N, tb, te);
+        rb_gemm_nt<2>(ALds{sA, LD}, W, F, N, F, wave, lane, [&](int n0, int r, const f32x4& acc) {
+            if (r >= nrows) return;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + i;
+                if (n < N) { const float v = acc[i] + bias[n]; out[(row0 + r) * ldo + n] = relu ? fmaxf(v, 0.f) : v; }
+            }
+        }, tb, te);
+    };
+
+    // ---- in_proj of the first layer ----
+    rows_to_lds(sA, LD, ldz, x0 + row0 * F, F, nrows, t);
+    __syncthreads();
+    {
+        const float* w = P.a.lay[0].win; const float* bv = P.a.lay[0].bin; float* o = P.a.lay[0].qkv;
+        project(w, bv, F3, o, F3, false);
+    }
+    grid_bar();
+
+    const float* xin = x0;
+    for (int l = 0; l < L; ++l) {
+        const bbbp_enc_sliced_layer Y = P.a.lay[l];                // by value: scalar loads from the argument block
+        const uint64_t s0 = effective_seed(Y.seed0, seed_base), s1 = effective_seed(Y.seed1, seed_base),
+                       s2 = effective_seed(Y.seed2, seed_base), s3 = effective_seed(Y.seed3, seed_base);
+        // ================= attention of the block's 16 queries over all keys =================
+        rows_to_lds_ld(sB, LD, ldz, Y.qkv + row0 * F3, F3, F, nrows, t);              // Q rows (zero-padded columns)
+        __syncthreads();
+        // S^T tile of this wave: keys 16 wave .. + 15 (rows), the 16 queries (columns); lane (q, kq) register r <-> key 16 wave + 4 kq + r
+        const int kt = wave;
+        const bool tile_on = kt * 16 < Bp;
+        f32x4 st = {0.f, 0.f, 0.f, 0.f};
+        if (tile_on) {
+            const float* krow = Y.qkv + (long)min(kt * 16 + q, B - 1) * F3 + F + 4 * kq;      // K row of key (kt, lane & 15)
+            const int nch = ldz >> 4;                     // the K row is read up to 16 * nch <= F + 15 columns: still inside the [3F] row
+#pragma unroll 2
+            for (int c = 0; c < nch; ++c) {
+                const f32x4g kv = *reinterpret_cast<const f32x4g*>(krow + 16 * c);
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(sB + q * LD + 16 * c + 4 * kq);       // zero beyond F
+#pragma unroll
+                for (int j = 0; j < 4; ++j) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[j], qv[j], st, 0, 0, 0);
+            }
+        }
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            st[r] = (tile_on && kt * 16 + 4 * kq + r < B) ? st[r] * scale : -INFINITY;
+            mloc = fmaxf(mloc, st[r]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16)); mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        if (kq == 0) sred[0][wave][q] = mloc;
+        __syncthreads();                                  // every wave is done with the Q rows in sB, too
+        float M = sred[0][0][q];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) M = fmaxf(M, sred[0][w][q]);
+        float e[4], sloc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { e[r] = __expf(st[r] - M); sloc += e[r]; }        // exp(-inf) = 0 for masked keys
+        sloc += __shfl_xor(sloc, 16); sloc += __shfl_xor(sloc, 32);
+        if (kq == 0) sred[1][wave][q] = sloc;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += sred[1][w][q];
+        const float inv = 1.f / tot;
+        if (tile_on) {
+            const int query = (int)row0 + q, key0 = kt * 16 + 4 * kq;
+            float ks[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop) dropout_scale4(s0, ((uint64_t)min(query, B - 1)) * B + key0, pdrop, inv_keep, ks);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = e[r] * inv, pdv = pr * ks[r];
+                sB[(key0 + r) * 16 + q] = pdv;                                         // [key][query] for the P.V product
+                if (sl == 0 && q < nrows && key0 + r < B) {
+                    Y.prob[(long)query * B + key0 + r] = pr;
+                    if (Y.pd != Y.prob) Y.pd[(long)query * B + key0 + r] = pdv;
+                }
+            }
+        }
+        __syncthreads();
+        // ctx^T[d][query] = sum_key V^T[d][key] Pd^T[key][query]: wave w takes the d tiles w, w + NW; a step contracts 4 keys
+        for (int dt = wave; dt * 16 < ldz; dt += NW) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* vcol = Y.qkv + 2 * F + 16 * dt + q;                           // V[.][d = 16 dt + (lane & 15)]: inside the row (d < F + 15)
+#pragma unroll 4
+            for (int k4 = 0; k4 < Bp; k4 += 4) {
+                const float a = vcol[(long)min(k4 + kq, B - 1) * F3];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sB[(k4 + kq) * 16 + q], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = 16 * dt + 4 * kq + r;                                    // lane (query q, kq), register r
+                const float v = d < F ? acc[r] : 0.f;
+                sA[q * LD + d] = v;
+                if (sl == 0 && q < nrows && d < F) Y.ctx[(row0 + q) * F + d] = v;
+            }
+        }
+        __syncthreads();
+        // ================= z1 = dropout(ctx Wo^T + bo) + x : this slice's column tiles =================
+        {
+            int tb, te; my_tiles(F, tb, te);
+            rb_gemm_nt<1>(ALds{sA, LD}, Y.wo, F, F, F, wave, lane, [&](int n0, int r, const f32x4& acc) {
+                if (r >= nrows) return;
+                const long row = row0 + r;
+                float ks[4] = {1.f, 1.f, 1.f, 1.f};
+                if (drop) dropout_scale4(s1, (uint64_t)row * F + n0, pdrop, inv_keep, ks);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = n0 + i;
+                    if (n < F) Y.z1[row * F + n] = (acc[i] + Y.bo[n]) * ks[i] + xin[row * F + n];
+                }
+            }, tb, te);
+        }
+        group_bar();
+        // ================= LayerNorm1 of the block (every slice), then this slice's tiles of hff =================
+        rows_to_lds(sB, LD, ldz, Y.z1 + row0 * F, F, nrows, t);
+        __syncthreads();
+        ln_fwd_rows(sB, sA, LD, ldz, F, nrows, row0, Y.g1, Y.be1, Y.z1, Y.y1, Y.mean1, Y.rstd1, wave, lane, sl == 0);
+        __syncthreads();
+        {
+            int tb, te; my_tiles(DFF, tb, te);
+            rb_gemm_nt<2>(ALds{sA, LD}, Y.w1, F, DFF, F, wave, lane, [&](int n0, int r, const f32x4& acc) {
+                if (r >= nrows) return;
+                const long row = row0 + r;
+                float ks[4] = {1.f, 1.f, 1.f, 1.f};
+                if (drop) dropout_scale4(s2, (uint64_t)row * DFF + n0, pdrop, inv_keep, ks);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (n0 + i < DFF) Y.hff[row * DFF + n0 + i] = fmaxf(acc[i] + Y.b1[n0 + i], 0.f) * ks[i];
+            }, tb, te);
+        }
+        group_bar();
+        // ================= linear2: this slice's K range of every column tile -> partial sums =================
+        // at most SL_KSLICES slices take a K range (the others idle through this stage): the partials are re-read by EVERY slice of the
+        // row block, and 32 of them per element made that reduction the longest stage of the layer
+        const int nchunk = DFF >> 4, ksl = min(S, SL_KSLICES), cps = (nchunk + ksl - 1) / ksl, nact = (nchunk + cps - 1) / cps;
+        float* mypart = part + ((long)(rb * S + sl) * ROWS) * SL_LDP;
+        if (sl < nact) {
+            const int k0 = sl * cps * 16, klen = min(DFF - k0, cps * 16);
+            rb_gemm_nt<2>(AGlb{Y.hff + row0 * DFF + k0, DFF, nrows}, Y.w2 + k0, DFF, F, klen, wave, lane, [&](int n0, int r, const f32x4& acc) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (n0 + i < SL_LDP) mypart[r * SL_LDP + n0 + i] = acc[i];
+            });
+        }
+        group_bar();
+        // ================= z2 = dropout(sum of the partials + b2) + y1, LayerNorm2 (every slice) =================
+        for (int idx = t; idx < ROWS * ldz; idx += NTH) {
+            const int r = idx / ldz, n = idx % ldz;
+            float v = 0.f;
+            if (n < F) {
+                const float* pp = part + ((long)(rb * S) * ROWS + r) * SL_LDP + n;
+                float pv[SL_KSLICES];
+#pragma unroll
+                for (int s = 0; s < SL_KSLICES; ++s) pv[s] = pp[(long)min(s, nact - 1) * ROWS * SL_LDP];      // independent loads in flight
+#pragma unroll
+                for (int s = 0; s < SL_KSLICES; ++s) v += s < nact ? pv[s] : 0.f;                                 // added in slice order
+                const long row = row0 + min(r, nrows - 1);
+                v += Y.b2[n];
+                if (drop) v *= dropout_scale(s3, (uint64_t)row * F + n, pdrop, inv_keep);
+                v += sA[r * LD + n];
+            }
+            sB[r * LD + n] = v;
+        }
+        __syncthreads();
+        ln_fwd_rows(sB, sA, LD, ldz, F, nrows, row0, Y.g2, Y.be2, Y.z2, Y.y2, Y.mean2, Y.rstd2, wave, lane, sl == 0);
+        __syncthreads();
+        // ================= the next projection of these rows =================
+        xin = Y.y2;
+        if (l + 1 < L) {
+            const float* w = P.a.lay[l + 1].win; const float* bv = P.a.lay[l + 1].bin; float* o = P.a.lay[l + 1].qkv;
+            project(w, bv, F3, o, F3, false);
+            grid_bar();
+        } else if (P.a.wfc) {
+            const float* w = P.a.wfc; const float* bv = P.a.bfc; float* o = P.a.comb;
+            project(w, bv, P.a.nfc, o, P.a.ldcomb, true);
+        }
+    }
+}
+
 }  // namespace
 
 // ---- internal entry points (engine.hip) -----------------------------------------------------------------------------------------
@@ -504,5 +773,45 @@ int bbbp_ln_param_grad_multi(hipStream_t st, int n, const float* const* dy, cons
         hipLaunchKernelGGL(ln_param_grad_multi_kernel, dim3(cdiv(cols, LCW), m), dim3(LCW * LRL), 0, st, P);
         BBBP_CHECK_LAUNCH();
     }
+    return BBBP_OK;
+}
+
+// ---- sliced persistent forward ---------------------------------------------------------------------------------------------------
+bool bbbp_enc_sliced_supported(int B, int F, int nhead, int dff, int layers) {
+    return B >= 1 && B <= 16 * NW && nhead == 1 && F >= 16 && F <= MAXF - 16 && dff >= 16 && dff % 16 == 0 && layers >= 1 &&
+           layers <= BBBP_SLICED_MAX_LAYERS;
+}
+static int sliced_slices(int B) {
+    const int nrb = (B + ROWS - 1) / ROWS;
+    int s = 64 / nrb;
+    return s < 1 ? 1 : (s > 32 ? 32 : s);
+}
+size_t bbbp_enc_sliced_sync_bytes() { return 64 * sizeof(unsigned); }
+size_t bbbp_enc_sliced_part_bytes(int B, int F) {
+    (void)F;
+    const int nrb = (B + ROWS - 1) / ROWS;
+    return (size_t)nrb * sliced_slices(B) * ROWS * SL_LDP * sizeof(float);
+}
+int bbbp_enc_sliced_fwd(hipStream_t st, const bbbp_enc_sliced_fwd_args* a) {
+    BBBP_CHECK_ARG(a && a->sync && a->part && a->x0, "enc_sliced_fwd: null pointer");
+    BBBP_CHECK_ARG(bbbp_enc_sliced_supported(a->B, a->F, 1, a->DFF, a->L), "enc_sliced_fwd: B=%d F=%d dff=%d layers=%d not supported", a->B, a->F, a->DFF, a->L);
+    SlFwdParams P;
+    P.a = *a;
+    P.NRB = (a->B + ROWS - 1) / ROWS;
+    P.S = sliced_slices(a->B);
+    P.bar = static_cast<unsigned*>(a->sync);
+    P.seed_base = g_bbbp_seed_base;
+    BBBP_CHECK_ARG(P.NRB * P.S <= bbbp_num_cus(), "enc_sliced_fwd: the grid must be resident at once");
+    BBBP_CHECK_HIP(hipMemsetAsync(a->sync, 0, bbbp_enc_sliced_sync_bytes(), st));
+    hipLaunchKernelGGL(enc_sliced_fwd_kernel, dim3(P.NRB * P.S), dim3(NTH), 0, st, P);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+int bbbp_enc_sliced_aborted(hipStream_t st, const void* sync, int* aborted) {
+    BBBP_CHECK_ARG(sync && aborted, "enc_sliced_aborted: null pointer");
+    unsigned w = 0;
+    BBBP_CHECK_HIP(hipMemcpyAsync(&w, static_cast<const unsigned*>(sync) + SL_ABORT, sizeof(w), hipMemcpyDeviceToHost, st));
+    BBBP_CHECK_HIP(hipStreamSynchronize(st));
+    *aborted = w != 0;
     return BBBP_OK;
 }

@@ -7,6 +7,7 @@
 // tensor and batch_first=False (R:110-111), so self-attention runs ACROSS the mini-batch: S = B, N = 1.
 #include "common.h"
 #include "attention_b3.h"
+#include "encoder_sliced.h"
 #include <optional>
 #include "bbbp_hip.h"
 #include <mutex>
@@ -64,6 +65,7 @@ struct Plan {
     int B, F, NH, D, L, DFF;
     bool drop, concat, inference;
     bool flash;            // many heads of head_dim 8 / 16: fused attention (attention.hip), no [NH,B,B] probability tensors
+    size_t sl_sync, sl_part;   // sliced persistent forward: barrier counters, linear2 partials (allocated whenever the shape is supported)
     bool attn_b3;          // forward-only plan, wide head, >= 1024 rows: split-bf16 attention (attention_b3.hip)
     size_t attn_part, attn_part_bytes;
     LayerOff layer[32];
@@ -112,7 +114,9 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
         LayerOff& o = p->layer[l];
         // forward only: nothing is kept for a backward pass, every layer runs in layer 0's buffers (layer l reads its input
         // y2 before it writes y2 again: qkv <- y2, y1 <- LN(z1 + y2), y2 <- LN(z2 + y1))
-        if (p->inference && l > 0) { o = p->layer[0]; continue; }
+        // (not for batches the sliced persistent forward can take: its row blocks run layers out of step, so a layer's buffers must not be
+        // the previous layer's; at B <= 128 a layer's activations are < 2 MB)
+        if (p->inference && l > 0 && !bbbp_enc_sliced_supported(p->B, p->F, p->NH, p->DFF, p->L)) { o = p->layer[0]; continue; }
         o.qkv = b.f(B * 3 * F); o.prob = p->flash ? 0 : b.f(NH * B * B); o.ctx = b.f(B * F);
         // dropped attention weights are KEPT per layer (1 MB at B = 512, one head) rather than recomputed in backward:
         // every launch on the encoder's chain costs more than the bytes
@@ -126,6 +130,12 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
         }
         o.z1 = b.f(B * F); o.y1 = b.f(B * F); o.hff = b.f(B * DFF); o.z2 = b.f(B * F); o.y2 = b.f(B * F);
         o.mean1 = b.f(B); o.rstd1 = b.f(B); o.mean2 = b.f(B); o.rstd2 = b.f(B);
+    }
+    if (p->L > 0 && bbbp_enc_sliced_supported(p->B, p->F, p->NH, p->DFF, p->L)) {
+        p->sl_sync = b.take(bbbp_enc_sliced_sync_bytes());
+        p->sl_part = b.take(bbbp_enc_sliced_part_bytes(p->B, p->F));
+    } else {
+        p->sl_sync = p->sl_part = 0;
     }
     p->attn_part_bytes = p->attn_b3 ? bbbp_attn_b3_workspace_bytes(p->B, p->NH, p->D) : 0;
     p->attn_part = p->attn_part_bytes ? b.take(p->attn_part_bytes) : 0;
@@ -214,10 +224,17 @@ int g_fused_head_bwd = -1;
 // bbbp_set_fused_encoder(1).  Correct (tests compare the two schedules) but OFF by default: a 16-row work-group streams a whole
 // layer's weights by itself (3.2 MB forward) through ONE wave per SIMD, which is bound by load latency -- 176 / 289 us per
 // forward / backward launch against ~50 us for the launch-per-op chain whose GEMMs spread over all CUs.
-int g_fused_encoder = -1;
+int g_fused_encoder = -1;              // bit 0: row-fused kernels (opt-in); bit 1: sliced persistent forward for small batches
+int fused_encoder_mode() {
+    if (g_fused_encoder < 0) { const char* e = getenv("BBBP_FUSED_ENCODER"); g_fused_encoder = e ? atoi(e) & 3 : 0; }
+    return g_fused_encoder;
+}
 bool fused_encoder(const Plan& p) {
-    if (g_fused_encoder < 0) { const char* e = getenv("BBBP_FUSED_ENCODER"); g_fused_encoder = e ? atoi(e) != 0 : 0; }
-    return g_fused_encoder == 1 && p.L > 0 && !p.flash && bbbp_enc_rows_supported(p.F, p.NH, p.DFF);
+    return (fused_encoder_mode() & 1) && p.L > 0 && !p.flash && bbbp_enc_rows_supported(p.F, p.NH, p.DFF);
+}
+// the whole forward chain of a small batch as one persistent launch (encoder.hip: enc_sliced_fwd_kernel)
+bool sliced_encoder(const Plan& p) {
+    return (fused_encoder_mode() & 2) && p.L > 0 && !p.flash && bbbp_enc_sliced_supported(p.B, p.F, p.NH, p.DFF, p.L);
 }
 bool overlap_enabled() {
     if (g_overlap < 0) { const char* e = getenv("BBBP_SINGLE_STREAM"); g_overlap = (e && e[0] == '1') ? 0 : 1; }
@@ -453,9 +470,9 @@ extern "C" int bbbp_set_fused_head_bwd(int on) {
     return prev;
 }
 
-extern "C" int bbbp_set_fused_encoder(int on) {
-    const int prev = g_fused_encoder > 0 ? 1 : 0;
-    g_fused_encoder = on ? 1 : 0;
+extern "C" int bbbp_set_fused_encoder(int mode) {
+    const int prev = fused_encoder_mode();
+    g_fused_encoder = mode & 3;
     return prev;
 }
 
@@ -568,7 +585,27 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
     const float* x = fingerprint;
     std::optional<Section> sec_enc;
     sec_enc.emplace(ce.st, SEC_ENCODER_FWD);
-    const bool fused_rows = fused_encoder(plan);
+    const bool sliced = sliced_encoder(plan) && plan.sl_sync;
+    if (sliced) {
+        bbbp_enc_sliced_fwd_args a;
+        memset(&a, 0, sizeof(a));
+        a.x0 = fingerprint; a.L = plan.L; a.B = B; a.F = F; a.DFF = DFF; a.p = p_drop; a.scale = scale;
+        a.wfc = P[ix.fpfc_w()]; a.bfc = P[ix.fpfc_b()]; a.comb = comb; a.nfc = FC; a.ldcomb = COMB;
+        a.sync = c.u8(plan.sl_sync); a.part = c.f(plan.sl_part);
+        for (int l = 0; l < plan.L; ++l) {
+            const LayerOff& o = plan.layer[l];
+            bbbp_enc_sliced_layer& y = a.lay[l];
+            y.win = P[ix.layer(l, L_INW)]; y.bin = P[ix.layer(l, L_INB)]; y.wo = P[ix.layer(l, L_OUTW)]; y.bo = P[ix.layer(l, L_OUTB)];
+            y.g1 = P[ix.layer(l, L_N1W)]; y.be1 = P[ix.layer(l, L_N1B)]; y.w1 = P[ix.layer(l, L_W1)]; y.b1 = P[ix.layer(l, L_B1)];
+            y.w2 = P[ix.layer(l, L_W2)]; y.b2 = P[ix.layer(l, L_B2)]; y.g2 = P[ix.layer(l, L_N2W)]; y.be2 = P[ix.layer(l, L_N2B)];
+            y.qkv = c.f(o.qkv); y.prob = c.f(o.prob); y.pd = c.f(o.pd); y.ctx = c.f(o.ctx); y.z1 = c.f(o.z1); y.y1 = c.f(o.y1);
+            y.hff = c.f(o.hff); y.z2 = c.f(o.z2); y.y2 = c.f(o.y2); y.mean1 = c.f(o.mean1); y.rstd1 = c.f(o.rstd1);
+            y.mean2 = c.f(o.mean2); y.rstd2 = c.f(o.rstd2);
+            y.seed0 = site_seed(d->seed, l, 0); y.seed1 = site_seed(d->seed, l, 1); y.seed2 = site_seed(d->seed, l, 2); y.seed3 = site_seed(d->seed, l, 3);
+        }
+        TRY(bbbp_enc_sliced_fwd(ce.st, &a));
+    }
+    const bool fused_rows = !sliced && fused_encoder(plan);
     if (fused_rows) {
         // in_proj of layer 0; every later in_proj (and fingerprint_fc) is the tail of the previous layer's row kernel
         TRY(linear_fwd(ce, x, F, P[ix.layer(0, L_INW)], P[ix.layer(0, L_INB)], c.f(plan.layer[0].qkv), 3 * F, B, 3 * F, F, 0));
@@ -596,7 +633,7 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
             x = c.f(o.y2);
         }
     }
-    for (int l = 0; l < (fused_rows ? 0 : plan.L); ++l) {
+    for (int l = 0; l < ((fused_rows || sliced) ? 0 : plan.L); ++l) {
         const LayerOff& o = plan.layer[l];
         float* qkv = c.f(o.qkv); float* prob = c.f(o.prob); float* ctx = c.f(o.ctx);
         {
@@ -665,7 +702,7 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         x = y2;
     }
     // fingerprint_fc (R:79-82, 112) -> combined[:, 0:128]
-    if (!fused_rows) TRY(linear_fwd(ce, x, F, P[ix.fpfc_w()], P[ix.fpfc_b()], comb, COMB, B, FC, F, BBBP_ACT_RELU));
+    if (!fused_rows && !sliced) TRY(linear_fwd(ce, x, F, P[ix.fpfc_w()], P[ix.fpfc_b()], comb, COMB, B, FC, F, BBBP_ACT_RELU));
     sec_enc.reset();
 
     if (ss) TRY(join_side(c.st, ss));        // fusion needs both halves of `combined`
