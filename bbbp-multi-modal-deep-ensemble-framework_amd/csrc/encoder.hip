@@ -16,6 +16,7 @@
 // Sized to run BESIDE the image branch's persistent conv work-groups: 4 waves (one per SIMD), <= 64 VGPRs, ~23 KB of LDS.
 #include "common.h"
 #include "bbbp_hip.h"
+#include <cstddef>
 #include "encoder_sliced.h"
 
 namespace {
@@ -136,11 +137,14 @@ __device__ __forceinline__ void rb_gemm_nt(const ASrc& A, const float* __restric
 // ---- out[16 x N] = A[16 x K] * W[K][N] (contraction over the weight's ROW index: the input gradient of a Linear).
 // A wave pass covers 16 * T consecutive columns; lane (q, kq) owns columns cb + T q .. + T - 1 (one T-wide load per k) of rows
 // 4 kq .. + 3.  epi(col0, row0, acc[T]) : acc[u][r] = out[row0 + r][col0 + u]; columns >= N must be skipped by the callee.
+// Column passes [pbeg, pend) only (pend < 0: all).
 template <int T, class ASrc, class Epi>
-__device__ __forceinline__ void rb_gemm_kmajor(const ASrc& A, const float* __restrict__ W, int ldw, int N, int K, int wave, int lane, Epi&& epi) {
+__device__ __forceinline__ void rb_gemm_kmajor(const ASrc& A, const float* __restrict__ W, int ldw, int N, int K, int wave, int lane, Epi&& epi,
+                                               int pbeg = 0, int pend = -1) {
     const int q = lane & 15, kq = lane >> 4;
-    const int npass = (N + 16 * T - 1) / (16 * T), nfull = K >> 4, tail = K & 15;
-    for (int ps = wave; ps < npass; ps += NW) {
+    const int nfull = K >> 4, tail = K & 15;
+    const int npass = pend < 0 ? (N + 16 * T - 1) / (16 * T) : min(pend, (N + 16 * T - 1) / (16 * T));
+    for (int ps = pbeg + wave; ps < npass; ps += NW) {
         const int col = ps * 16 * T + T * q;
         const bool edge = (ps + 1) * 16 * T > N;            // wave-uniform: the last pass may hang over the matrix
         f32x4 acc[T];
@@ -224,7 +228,7 @@ __device__ __forceinline__ void ln_fwd_rows(const float* zs, float* ys, int ld, 
 // dz -> `dzg` (global); its dropped copy (the gradient of the sublayer output) -> `ds` (LDS, zero-padded) and `dxg` (global).
 __device__ __forceinline__ void ln_bwd_rows(const float* dys, float* ds, int ld, int ldz, int F, int nrows, long row0, const float* zg,
                                             const float* gamma, const float* mean, const float* rstd, float* dzg, float* dxg, float p,
-                                            uint64_t seed, int wave, int lane) {
+                                            uint64_t seed, int wave, int lane, bool store = true) {
     const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
     for (int r = wave; r < ROWS; r += NW) {
         const bool live = r < nrows;
@@ -241,8 +245,10 @@ __device__ __forceinline__ void ln_bwd_rows(const float* dys, float* ds, int ld,
                 const float g = dy[c] * gamma[c];
                 v = rs * (g - s1 - (z[c] - mu) * rs * s2);
                 vd = p > 0.f ? v * dropout_scale(seed, (uint64_t)row * F + c, p, inv_keep) : v;
-                dzg[row * F + c] = v;
-                if (dxg != dzg) dxg[row * F + c] = vd;
+                if (store) {
+                    dzg[row * F + c] = v;
+                    if (dxg != dzg) dxg[row * F + c] = vd;
+                }
             }
             ds[r * ld + c] = vd;
         }
@@ -731,6 +737,273 @@ __global__ __launch_bounds__(NTH) void enc_sliced_fwd_kernel(SlFwdParams P) {
     }
 }
 
+
+// ==================================================================================================================================
+// Sliced persistent BACKWARD chain (round 3): the input-gradient chain of the encoder for a small batch as one launch, the mirror
+// image of enc_sliced_fwd_kernel.  Per layer, top to bottom, for (row block, slice):
+//   LayerNorm2 backward of the block's 16 rows (every slice; slice 0 stores dz2 / dff)
+//   dhff = (dff W2) (.) gate      : its column passes                                  | row-block barrier
+//   dy1  = dhff W1 + dz2          : its K range -> partials                            | row-block barrier, then reduce (every slice)
+//   LayerNorm1 backward (every slice; slice 0 stores dy1 / dz1 / dsa), dctx = dsa Wo (every slice, 16 x 167 x 167: redundant is cheaper
+//   than a barrier)
+//   attention backward of the block's 16 queries: dP = dctx V^T, dS = P (.) (dP (.) keep - rowsum) in registers (one 16-key tile per
+//   wave), dQ = scale dS K (row-local, slice 0 stores it); the block's SHARE of dK = scale dS^T Q and dV = Pd^T dctx for all keys: its
+//   (key tile, d tile) pairs -> kvpart[row block]                                      | GRID barrier
+//   dK | dV rows of the block = sum over row blocks, in block order: its element range | row-block barrier
+//   dyout of the layer below = dqkv Win + dz1 (every slice: 16 x 501 x 167)
+// Weight / bias / LayerNorm-parameter gradients are NOT computed here: they stay leaf launches over the buffers this kernel stores.
+struct SlBwdParams {
+    bbbp_enc_sliced_bwd_args a;
+    int S, NRB;
+    unsigned* bar;
+    const unsigned long long* seed_base;
+};
+
+__global__ __launch_bounds__(NTH) void enc_sliced_bwd_kernel(SlBwdParams P) {
+    BBBP_HIGH_PRIO();
+    __shared__ __attribute__((aligned(16))) float sA[ROWS * LD];          // dyout -> dff -> dsa -> (dropped probabilities^T) -> dyout of the layer below
+    __shared__ __attribute__((aligned(16))) float sB[ROWS * LD];          // dy1 -> dctx
+    __shared__ __attribute__((aligned(16))) float sS[16 * NW * 16];       // dS^T [key][16 queries]
+    __shared__ float sred[NW][16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane & 15, kq = lane >> 4;
+    const int S = P.S, NRB = P.NRB, rb = blockIdx.x / S, sl = blockIdx.x % S, G = gridDim.x;
+    const int B = P.a.B, F = P.a.F, DFF = P.a.DFF, L = P.a.L, F3 = 3 * F, ldz = (F + 15) & ~15, Bp = (B + 15) & ~15;
+    const float pdrop = P.a.p, scale = P.a.scale;
+    float* const part = P.a.part;
+    float* const kvpart = P.a.kvpart;
+    unsigned* const bar = P.bar;
+    const unsigned long long* const seed_base = P.seed_base;
+    const long row0 = (long)rb * ROWS;
+    const int nrows = min(ROWS, B - (int)row0);
+    const bool drop = pdrop > 0.f;
+    const float inv_keep = drop ? 1.f / (1.f - pdrop) : 1.f;
+    // the per-layer table stays in the kernel-argument segment and is read field by field with scalar loads where it is used: a by-value
+    // copy of one layer is 54 SGPRs held across every stage
+    typedef const __attribute__((address_space(4))) bbbp_enc_sliced_bwd_layer* LayerTable;
+    const LayerTable lay = (LayerTable)((const __attribute__((address_space(4))) char*)
+        __builtin_amdgcn_kernarg_segment_ptr() + offsetof(SlBwdParams, a) + offsetof(bbbp_enc_sliced_bwd_args, lay));
+    unsigned gphase = 0, rphase = 0;
+    auto grid_bar = [&]() { sl_barrier(bar, (++gphase) * (unsigned)G, bar + SL_ABORT); };
+    auto group_bar = [&]() { sl_barrier(bar + 1 + rb, (++rphase) * (unsigned)S, bar + SL_ABORT); };
+    float* sP = sA;                                                        // Pd^T [key][16 queries] while sA is free (attention stage)
+
+    // ---- dyout of the top layer = dcomb[:, :nfc] Wfc (every slice) ----
+    for (int idx = t; idx < ROWS * LD; idx += NTH) sA[idx] = 0.f;
+    __syncthreads();
+    {
+        const float* dcomb = P.a.dcomb; const float* wfc = P.a.wfc; const int ldc = P.a.ldcomb, nfc = P.a.nfc;
+        float* dy = lay[L - 1].dyout;
+        rb_gemm_kmajor<2>(AGlb{dcomb + row0 * ldc, ldc, nrows}, wfc, F, F, nfc, wave, lane, [&](int col0, int r0, const f32x4 (&acc)[2]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = r0 + r;
+                if (rr >= nrows) continue;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int n = col0 + u;
+                    if (n < F) { sA[rr * LD + n] = acc[u][r]; if (sl == 0) dy[(row0 + rr) * F + n] = acc[u][r]; }
+                }
+            }
+        });
+    }
+    __syncthreads();
+
+    for (int l = L - 1; l >= 0; --l) {
+#define Y lay[l]
+        const uint64_t s0 = effective_seed(Y.seed0, seed_base), s1 = effective_seed(Y.seed1, seed_base), s3 = effective_seed(Y.seed3, seed_base);
+        // ================= LayerNorm2 backward: dz2 (global) and its dropped copy dff (LDS + global) =================
+        ln_bwd_rows(sA, sA, LD, ldz, F, nrows, row0, Y.z2, Y.g2, Y.mean2, Y.rstd2, Y.dz2, Y.dff, pdrop, s3, wave, lane, sl == 0);
+        __syncthreads();
+        // ================= dhff = (dff W2) (.) [hff > 0] / keep : this slice's column passes =================
+        {
+            const int np = (DFF + 63) / 64, pps = (np + S - 1) / S, pb = sl * pps, pe = min(np, pb + pps);
+            rb_gemm_kmajor<4>(ALds{sA, LD}, Y.w2, DFF, DFF, F, wave, lane, [&](int col0, int r0, const f32x4 (&acc)[4]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = r0 + r;
+                    if (rr >= nrows) continue;
+                    const long o = (row0 + rr) * DFF + col0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (col0 + u < DFF) Y.dhff[o + u] = Y.hff[o + u] > 0.f ? acc[u][r] * inv_keep : 0.f;
+                }
+            }, pb, pe);
+        }
+        group_bar();
+        // ================= dy1 = dhff W1 + dz2 : this slice's K range -> partials; reduce after the barrier =================
+        const int nchunk = DFF >> 4, ksl = min(S, SL_KSLICES), cps = (nchunk + ksl - 1) / ksl, nact = (nchunk + cps - 1) / cps;
+        if (sl < nact) {
+            float* mypart = part + ((long)(rb * S + sl) * ROWS) * SL_LDP;
+            const int k0 = sl * cps * 16, klen = min(DFF - k0, cps * 16);
+            rb_gemm_kmajor<2>(AGlb{Y.dhff + row0 * DFF + k0, DFF, nrows}, Y.w1 + (long)k0 * F, F, F, klen, wave, lane,
+                              [&](int col0, int r0, const f32x4 (&acc)[2]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) if (col0 + u < SL_LDP) mypart[(r0 + r) * SL_LDP + col0 + u] = acc[u][r];
+            });
+        }
+        group_bar();
+        for (int idx = t; idx < ROWS * ldz; idx += NTH) {
+            const int r = idx / ldz, n = idx % ldz;
+            float v = 0.f;
+            if (n < F && r < nrows) {
+                const float* pp = part + ((long)(rb * S) * ROWS + r) * SL_LDP + n;
+                float pv[SL_KSLICES];
+#pragma unroll
+                for (int s = 0; s < SL_KSLICES; ++s) pv[s] = pp[(long)min(s, nact - 1) * ROWS * SL_LDP];
+#pragma unroll
+                for (int s = 0; s < SL_KSLICES; ++s) v += s < nact ? pv[s] : 0.f;
+                v += Y.dz2[(row0 + r) * F + n];
+                if (sl == 0) Y.dy1[(row0 + r) * F + n] = v;
+            }
+            sB[r * LD + n] = v;
+        }
+        __syncthreads();
+        // ================= LayerNorm1 backward: dz1 (global), dsa = dropped copy (LDS + global) =================
+        ln_bwd_rows(sB, sA, LD, ldz, F, nrows, row0, Y.z1, Y.g1, Y.mean1, Y.rstd1, Y.dz1, Y.dsa, pdrop, s1, wave, lane, sl == 0);
+        __syncthreads();
+        // ================= dctx = dsa Wo (every slice) -> sB =================
+        rb_gemm_kmajor<2>(ALds{sA, LD}, Y.wo, F, F, F, wave, lane, [&](int col0, int r0, const f32x4 (&acc)[2]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) if (col0 + u < ldz) sB[(r0 + r) * LD + col0 + u] = (col0 + u < F && r0 + r < nrows) ? acc[u][r] : 0.f;
+        });
+        __syncthreads();
+        // ================= attention backward of the block's 16 queries =================
+        // dPd^T tile of this wave: keys 16 wave .. + 15 (rows) x 16 queries: sum_d V[key][d] dctx[query][d]
+        const int kt = wave;
+        const bool tile_on = kt * 16 < Bp;
+        f32x4 dpt = {0.f, 0.f, 0.f, 0.f};
+        if (tile_on) {
+            const float* vrow = Y.qkv + (long)min(kt * 16 + q, B - 1) * F3 + 2 * F + 4 * kq;
+            const int nch = ldz >> 4;
+#pragma unroll 2
+            for (int c = 0; c < nch; ++c) {
+                const int dcol = 16 * c + 4 * kq;
+                f32x4 vv;
+                if (dcol + 3 < F) { const f32x4g x = *reinterpret_cast<const f32x4g*>(vrow + 16 * c); vv = f32x4{x[0], x[1], x[2], x[3]}; }
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) vv[j] = dcol + j < F ? vrow[16 * c + j] : 0.f;        // the V row ends the [3F] row: no overrun
+                }
+                const f32x4 dv = *reinterpret_cast<const f32x4*>(sB + q * LD + 16 * c + 4 * kq);        // dctx, zero beyond F
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dpt = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[j], dv[j], dpt, 0, 0, 0);
+            }
+        }
+        // lane (q, kq) register r <-> key 16 wave + 4 kq + r, query row0 + q
+        const int query = (int)row0 + q, key0 = kt * 16 + 4 * kq;
+        float pr[4] = {0.f, 0.f, 0.f, 0.f}, ks[4] = {1.f, 1.f, 1.f, 1.f}, dp[4];
+        if (tile_on && q < nrows) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pr[r] = key0 + r < B ? Y.prob[(long)query * B + key0 + r] : 0.f;
+        }
+        if (drop && tile_on) dropout_scale4(s0, ((uint64_t)min(query, B - 1)) * B + key0, pdrop, inv_keep, ks);
+        float dot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dp[r] = dpt[r] * ks[r]; dot += dp[r] * pr[r]; }
+        dot += __shfl_xor(dot, 16); dot += __shfl_xor(dot, 32);
+        if (kq == 0) sred[wave][q] = dot;
+        __syncthreads();                                   // also: every wave is done with dsa in sA (its Wo product) -> sP may be written
+        float rowdot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) rowdot += sred[w][q];
+        if (tile_on) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dsv = pr[r] * (dp[r] - rowdot);                   // dS[query][key]
+                sS[(key0 + r) * 16 + q] = dsv;
+                sP[(key0 + r) * 16 + q] = pr[r] * ks[r];                       // Pd[query][key] (what the forward stored as pd)
+            }
+        }
+        __syncthreads();
+        // ---- dQ^T[d][query] = scale sum_key K^T[d][key] dS^T[key][query]: wave w takes d tiles w, w + NW; slice 0 stores ----
+        if (sl == 0) {
+            for (int dt = wave; dt * 16 < ldz; dt += NW) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const float* kcol = Y.qkv + F + min(16 * dt + q, F - 1);
+#pragma unroll 4
+                for (int k4 = 0; k4 < Bp; k4 += 4) {
+                    const float a = kcol[(long)min(k4 + kq, B - 1) * F3];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sS[(k4 + kq) * 16 + q], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = 16 * dt + 4 * kq + r;
+                    if (q < nrows && d < F) Y.dqkv[(row0 + q) * F3 + d] = acc[r] * scale;
+                }
+            }
+        }
+        // ---- this block's share of dK[key][d] = scale sum_q dS[q][key] Q[q][d] and dV[key][d] = sum_q Pd[q][key] dctx[q][d]:
+        //      (key tile, d tile, which) triples dealt over the slices and waves; a product contracts the 16 queries in 4 MFMAs ----
+        {
+            const int nkt = Bp >> 4, ndt = ldz >> 4, ntrip = nkt * ndt * 2;
+            float* kvp = kvpart + ((long)(l & 1) * NRB + rb) * B * 2 * F;     // [B][2F]: dK | dV share of row block rb; two copies by
+                                                                               // layer parity (a block may run one layer ahead of its readers)
+            for (int tr = sl * NW + wave; tr < ntrip; tr += S * NW) {
+                const int which = tr % 2, dt2 = (tr / 2) % ndt, kt2 = tr / (2 * ndt);
+                const float* lhs = which ? sP : sS;                            // [key][16 q]
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int qq = 4 * s4 + kq;                                // contraction index: query
+                    const float a = lhs[(kt2 * 16 + q) * 16 + qq];            // A[i = key (lane & 15)][k = query]
+                    float bv;
+                    if (which) bv = sB[qq * LD + 16 * dt2 + q];                // dctx[query][d = 16 dt + (lane & 15)]
+                    else { const int d = 16 * dt2 + q; bv = (qq < nrows && d < F) ? Y.qkv[(row0 + qq) * F3 + d] : 0.f; }        // Q[query][d]
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
+                }
+                // lane (col = d, kq), register r <-> key 16 kt + 4 kq + r
+                const int d = 16 * dt2 + q;
+                if (d < F) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt2 * 16 + 4 * kq + r;
+                        if (key < B) kvp[(long)key * 2 * F + which * F + d] = which ? acc[r] : acc[r] * scale;
+                    }
+                }
+            }
+        }
+        grid_bar();
+        // ================= dK | dV rows of this block: sum of every row block's share, in block order =================
+        {
+            const int nel = nrows * 2 * F, eps = (nel + S - 1) / S, eb = sl * eps, ee = min(nel, eb + eps);
+            for (int e = eb + t; e < ee; e += NTH) {
+                const int r = e / (2 * F), c = e % (2 * F);
+                float v = 0.f;
+                for (int b2 = 0; b2 < NRB; ++b2) v += kvpart[(((long)(l & 1) * NRB + b2) * B + row0 + r) * 2 * F + c];
+                Y.dqkv[(row0 + r) * F3 + F + c] = v;
+            }
+        }
+        group_bar();
+        // ================= dyout of the layer below = dqkv Win + dz1 (every slice) -> sA =================
+        if (l > 0) {
+            float* dylow = lay[l - 1].dyout;
+            for (int idx = t; idx < ROWS * LD; idx += NTH) sA[idx] = 0.f;
+            __syncthreads();
+            rb_gemm_kmajor<2>(AGlb{Y.dqkv + row0 * F3, F3, nrows}, Y.win, F, F, F3, wave, lane, [&](int col0, int r0, const f32x4 (&acc)[2]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = r0 + r;
+                    if (rr >= nrows) continue;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int n = col0 + u;
+                        if (n < F) {
+                            const float v = acc[u][r] + Y.dz1[(row0 + rr) * F + n];
+                            sA[rr * LD + n] = v;
+                            if (sl == 0) dylow[(row0 + rr) * F + n] = v;
+                        }
+                    }
+                }
+            });
+            __syncthreads();
+        }
+    }
+#undef Y
+}
+
 }  // namespace
 
 // ---- internal entry points (engine.hip) -----------------------------------------------------------------------------------------
@@ -813,5 +1086,25 @@ int bbbp_enc_sliced_aborted(hipStream_t st, const void* sync, int* aborted) {
     BBBP_CHECK_HIP(hipMemcpyAsync(&w, static_cast<const unsigned*>(sync) + SL_ABORT, sizeof(w), hipMemcpyDeviceToHost, st));
     BBBP_CHECK_HIP(hipStreamSynchronize(st));
     *aborted = w != 0;
+    return BBBP_OK;
+}
+
+size_t bbbp_enc_sliced_kvpart_bytes(int B, int F) {
+    const int nrb = (B + ROWS - 1) / ROWS;
+    return (size_t)2 * nrb * B * 2 * F * sizeof(float);
+}
+int bbbp_enc_sliced_bwd(hipStream_t st, const bbbp_enc_sliced_bwd_args* a) {
+    BBBP_CHECK_ARG(a && a->sync && a->part && a->kvpart && a->dcomb && a->wfc, "enc_sliced_bwd: null pointer");
+    BBBP_CHECK_ARG(bbbp_enc_sliced_supported(a->B, a->F, 1, a->DFF, a->L), "enc_sliced_bwd: B=%d F=%d dff=%d layers=%d not supported", a->B, a->F, a->DFF, a->L);
+    SlBwdParams P;
+    P.a = *a;
+    P.NRB = (a->B + ROWS - 1) / ROWS;
+    P.S = sliced_slices(a->B);
+    P.bar = static_cast<unsigned*>(a->sync);
+    P.seed_base = g_bbbp_seed_base;
+    BBBP_CHECK_ARG(P.NRB * P.S <= bbbp_num_cus(), "enc_sliced_bwd: the grid must be resident at once");
+    BBBP_CHECK_HIP(hipMemsetAsync(a->sync, 0, bbbp_enc_sliced_sync_bytes(), st));
+    hipLaunchKernelGGL(enc_sliced_bwd_kernel, dim3(P.NRB * P.S), dim3(NTH), 0, st, P);
+    BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }

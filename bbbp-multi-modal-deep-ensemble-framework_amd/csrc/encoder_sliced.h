@@ -23,6 +23,26 @@ struct bbbp_enc_sliced_fwd_args {
     void* sync;                                 // bbbp_enc_sliced_sync_bytes(): barrier counters, zeroed by the launcher
     float* part;                                // bbbp_enc_sliced_part_bytes(B, F): split-K partials of linear2
 };
+// backward chain (input gradients) of the same encoder as one persistent launch; the weight / bias / LayerNorm parameter gradients
+// stay leaf launches that read the per-layer gradient buffers this kernel fills (dyout, dz2, dff, dhff, dy1, dz1, dsa, dqkv)
+struct bbbp_enc_sliced_bwd_layer {
+    const float *win, *wo, *g1, *w1, *w2, *g2;
+    const float *qkv, *prob, *pd, *z1, *hff, *z2, *mean1, *rstd1, *mean2, *rstd2;
+    float *dyout, *dz2, *dff, *dhff, *dy1, *dz1, *dsa, *dqkv;
+    uint64_t seed0, seed1, seed3;
+};
+struct bbbp_enc_sliced_bwd_args {
+    const float* dcomb; int ldcomb, nfc; const float* wfc;      // gradient of combined[:, :nfc] (ReLU mask applied), fingerprint_fc weight [nfc][F]
+    bbbp_enc_sliced_bwd_layer lay[BBBP_SLICED_MAX_LAYERS];
+    int L;
+    int B, F, DFF;
+    float p, scale;
+    void* sync;
+    float* part;                                // bbbp_enc_sliced_part_bytes(B, F) -- split-K partials of linear1's input gradient
+    float* kvpart;                              // bbbp_enc_sliced_kvpart_bytes(B, F): per row block, its queries' share of dK | dV
+};
+size_t bbbp_enc_sliced_kvpart_bytes(int B, int F);
+int bbbp_enc_sliced_bwd(hipStream_t st, const bbbp_enc_sliced_bwd_args* a);
 bool bbbp_enc_sliced_supported(int B, int F, int nhead, int dff, int layers);
 size_t bbbp_enc_sliced_sync_bytes();
 size_t bbbp_enc_sliced_part_bytes(int B, int F);

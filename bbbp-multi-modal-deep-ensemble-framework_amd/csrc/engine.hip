@@ -66,6 +66,7 @@ struct Plan {
     bool drop, concat, inference;
     bool flash;            // many heads of head_dim 8 / 16: fused attention (attention.hip), no [NH,B,B] probability tensors
     size_t sl_sync, sl_part;   // sliced persistent forward: barrier counters, linear2 partials (allocated whenever the shape is supported)
+    size_t sl_kvpart;          // sliced persistent backward: every row block's share of dK | dV (training plans only)
     bool attn_b3;          // forward-only plan, wide head, >= 1024 rows: split-bf16 attention (attention_b3.hip)
     size_t attn_part, attn_part_bytes;
     LayerOff layer[32];
@@ -134,8 +135,9 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     if (p->L > 0 && bbbp_enc_sliced_supported(p->B, p->F, p->NH, p->DFF, p->L)) {
         p->sl_sync = b.take(bbbp_enc_sliced_sync_bytes());
         p->sl_part = b.take(bbbp_enc_sliced_part_bytes(p->B, p->F));
+        p->sl_kvpart = p->inference ? 0 : b.take(bbbp_enc_sliced_kvpart_bytes(p->B, p->F));
     } else {
-        p->sl_sync = p->sl_part = 0;
+        p->sl_sync = p->sl_part = p->sl_kvpart = 0;
     }
     p->attn_part_bytes = p->attn_b3 ? bbbp_attn_b3_workspace_bytes(p->B, p->NH, p->D) : 0;
     p->attn_part = p->attn_part_bytes ? b.take(p->attn_part_bytes) : 0;
@@ -224,17 +226,17 @@ int g_fused_head_bwd = -1;
 // bbbp_set_fused_encoder(1).  Correct (tests compare the two schedules) but OFF by default: a 16-row work-group streams a whole
 // layer's weights by itself (3.2 MB forward) through ONE wave per SIMD, which is bound by load latency -- 176 / 289 us per
 // forward / backward launch against ~50 us for the launch-per-op chain whose GEMMs spread over all CUs.
-int g_fused_encoder = -1;              // bit 0: row-fused kernels (opt-in); bit 1: sliced persistent forward for small batches
+int g_fused_encoder = -1;              // bit 0: row-fused kernels (opt-in); bits 1 / 2: sliced persistent forward / backward for small batches
 int fused_encoder_mode() {
-    if (g_fused_encoder < 0) { const char* e = getenv("BBBP_FUSED_ENCODER"); g_fused_encoder = e ? atoi(e) & 3 : 0; }
+    if (g_fused_encoder < 0) { const char* e = getenv("BBBP_FUSED_ENCODER"); g_fused_encoder = e ? atoi(e) & 7 : 0; }
     return g_fused_encoder;
 }
 bool fused_encoder(const Plan& p) {
     return (fused_encoder_mode() & 1) && p.L > 0 && !p.flash && bbbp_enc_rows_supported(p.F, p.NH, p.DFF);
 }
 // the whole forward chain of a small batch as one persistent launch (encoder.hip: enc_sliced_fwd_kernel)
-bool sliced_encoder(const Plan& p) {
-    return (fused_encoder_mode() & 2) && p.L > 0 && !p.flash && bbbp_enc_sliced_supported(p.B, p.F, p.NH, p.DFF, p.L);
+bool sliced_encoder(const Plan& p, int bit = 2) {
+    return (fused_encoder_mode() & bit) && p.L > 0 && !p.flash && bbbp_enc_sliced_supported(p.B, p.F, p.NH, p.DFF, p.L);
 }
 bool overlap_enabled() {
     if (g_overlap < 0) { const char* e = getenv("BBBP_SINGLE_STREAM"); g_overlap = (e && e[0] == '1') ? 0 : 1; }
@@ -472,7 +474,7 @@ extern "C" int bbbp_set_fused_head_bwd(int on) {
 
 extern "C" int bbbp_set_fused_encoder(int mode) {
     const int prev = fused_encoder_mode();
-    g_fused_encoder = mode & 3;
+    g_fused_encoder = mode & 7;
     return prev;
 }
 
@@ -927,9 +929,42 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
     const float* enc_out = plan.L > 0 ? c.f(plan.layer[plan.L - 1].y2) : fingerprint;
     TRY(linear_bwd_weight_bias(cl, dcomb, COMB, enc_out, F, G[ix.fpfc_w()], G[ix.fpfc_b()], B, FC, F));
     float* dy = plan.L > 0 ? c.f(plan.lgrad[plan.L - 1].dyout) : c.f(plan.dA);
-    if (plan.L > 0 || d->need_input_grad) TRY(linear_bwd_input(ce, dcomb, COMB, P[ix.fpfc_w()], dy, F, B, FC, F));
+    const bool sliced = sliced_encoder(plan, 4) && plan.sl_sync && plan.sl_kvpart;
+    if (!sliced && (plan.L > 0 || d->need_input_grad)) TRY(linear_bwd_input(ce, dcomb, COMB, P[ix.fpfc_w()], dy, F, B, FC, F));
     float* dprob = c.f(plan.dprob); float* dctx = c.f(plan.dctx);
-    const bool fused_rows = fused_encoder(plan);
+    if (sliced) {
+        // the whole input-gradient chain in one persistent launch; every weight gradient is a leaf of its buffers afterwards
+        bbbp_enc_sliced_bwd_args a;
+        memset(&a, 0, sizeof(a));
+        a.dcomb = dcomb; a.ldcomb = COMB; a.nfc = FC; a.wfc = P[ix.fpfc_w()];
+        a.L = plan.L; a.B = B; a.F = F; a.DFF = DFF; a.p = p_drop; a.scale = scale;
+        a.sync = c.u8(plan.sl_sync); a.part = c.f(plan.sl_part); a.kvpart = c.f(plan.sl_kvpart);
+        for (int l = 0; l < plan.L; ++l) {
+            const LayerOff& o = plan.layer[l]; const LayerGrad& g = plan.lgrad[l];
+            bbbp_enc_sliced_bwd_layer& y = a.lay[l];
+            y.win = P[ix.layer(l, L_INW)]; y.wo = P[ix.layer(l, L_OUTW)]; y.g1 = P[ix.layer(l, L_N1W)];
+            y.w1 = P[ix.layer(l, L_W1)]; y.w2 = P[ix.layer(l, L_W2)]; y.g2 = P[ix.layer(l, L_N2W)];
+            y.qkv = c.f(o.qkv); y.prob = c.f(o.prob); y.pd = c.f(o.pd); y.z1 = c.f(o.z1); y.hff = c.f(o.hff); y.z2 = c.f(o.z2);
+            y.mean1 = c.f(o.mean1); y.rstd1 = c.f(o.rstd1); y.mean2 = c.f(o.mean2); y.rstd2 = c.f(o.rstd2);
+            y.dyout = c.f(g.dyout); y.dz2 = c.f(g.dz2); y.dff = c.f(g.dz2d); y.dhff = c.f(g.dhff); y.dy1 = c.f(g.dy1);
+            y.dz1 = c.f(g.dz1); y.dsa = c.f(g.dz1d); y.dqkv = c.f(g.dqkv);
+            y.seed0 = site_seed(d->seed, l, 0); y.seed1 = site_seed(d->seed, l, 1); y.seed3 = site_seed(d->seed, l, 3);
+        }
+        TRY(bbbp_enc_sliced_bwd(ce.st, &a));
+        if (d->need_input_grad)
+            TRY(linear_bwd_input(ce, c.f(plan.lgrad[0].dqkv), 3 * F, P[ix.layer(0, L_INW)], c.f(plan.dA), F, B, 3 * F, F, c.f(plan.lgrad[0].dz1), F));
+        TRY(leaf_after(ce));
+        for (int l = plan.L - 1; l >= 0; --l) {
+            const LayerOff& o = plan.layer[l]; const LayerGrad& g = plan.lgrad[l];
+            const float* xin = l > 0 ? c.f(plan.layer[l - 1].y2) : fingerprint;
+            TRY(linear_bwd_weight_bias(cl, c.f(g.dz2d), F, c.f(o.hff), DFF, G[ix.layer(l, L_W2)], G[ix.layer(l, L_B2)], B, F, DFF));
+            TRY(linear_bwd_weight_bias(cl, c.f(g.dhff), DFF, c.f(o.y1), F, G[ix.layer(l, L_W1)], G[ix.layer(l, L_B1)], B, DFF, F));
+            TRY(linear_bwd_weight_bias(cl, c.f(g.dz1d), F, c.f(o.ctx), F, G[ix.layer(l, L_OUTW)], G[ix.layer(l, L_OUTB)], B, F, F));
+            TRY(linear_bwd_weight_bias(cl, c.f(g.dqkv), 3 * F, xin, F, G[ix.layer(l, L_INW)], G[ix.layer(l, L_INB)], B, 3 * F, F));
+            TRY(layer_norm_leaves(l));
+        }
+    }
+    const bool fused_rows = !sliced && fused_encoder(plan);
     for (int l = fused_rows ? plan.L - 1 : -1; l >= 0; --l) {
         const LayerOff& o = plan.layer[l];
         const LayerGrad& g = plan.lgrad[l];
@@ -973,7 +1008,7 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         if (l == 0 && d->need_input_grad)
             TRY(linear_bwd_input(ce, dqkv, 3 * F, P[ix.layer(0, L_INW)], c.f(plan.dA), F, B, 3 * F, F, c.f(g.dz1), F));
     }
-    for (int l = fused_rows ? -1 : plan.L - 1; l >= 0; --l) {
+    for (int l = (fused_rows || sliced) ? -1 : plan.L - 1; l >= 0; --l) {
         const LayerOff& o = plan.layer[l];
         const LayerGrad& g = plan.lgrad[l];
         const float* xin = l > 0 ? c.f(plan.layer[l - 1].y2) : fingerprint;

@@ -413,7 +413,8 @@ def test_fused_encoder_rows_match_the_launch_per_op_schedule(dev, F, B, training
 
 @pytest.mark.parametrize("B,training", [(32, True), (7, True), (64, True), (37, True), (128, True), (100, False), (16, False), (1, False)])
 def test_sliced_persistent_forward_matches_the_launch_per_op_schedule(dev, B, training):
-    """csrc/encoder.hip: enc_sliced_fwd_kernel (bbbp_set_fused_encoder bit 1) runs the whole forward chain of the encoder for a small
+    """csrc/encoder.hip: enc_sliced_fwd_kernel / enc_sliced_bwd_kernel (bbbp_set_fused_encoder bits 1 / 2; modes 2, 4 and 6 = forward only,
+    backward only, both) run the whole forward chain / the whole input-gradient chain of the encoder for a small
     batch as ONE persistent launch -- every 16-row block shared by S work-groups that split the columns of each product, row-block and
     grid barriers through counters in device memory -- and leaves exactly the activations the launch-per-op schedule leaves.  Same
     Philox streams: with dropout ON both schedules draw identical masks, so outputs AND every gradient (the backward pass is the
@@ -426,7 +427,7 @@ def test_sliced_persistent_forward_matches_the_launch_per_op_schedule(dev, B, tr
     fp, img, y = fp[:B], img[:B], y[:B]
     m = build(F, 37, dev).train(training)
     res = []
-    for mode in (0, 2):
+    for mode in (0, 2, 4, 6) if training else (0, 2):
         old = L.bbbp_set_fused_encoder(mode)
         try:
             m.zero_grad(set_to_none=True)
@@ -444,20 +445,23 @@ def test_sliced_persistent_forward_matches_the_launch_per_op_schedule(dev, B, tr
             res.append((out.detach().cpu().double(), grads))
         finally:
             L.bbbp_set_fused_encoder(old)
-    (o0, g0), (o1, g1) = res
-    assert torch.isfinite(o1).all()
-    assert float((o0 - o1).abs().max()) <= 2e-5 * float(o0.abs().max()) + 1e-7, float((o0 - o1).abs().max())
-    for k in g0:
-        if k.startswith("attention_fusion."):
-            continue
-        # the two schedules add linear2's K range (32 slices vs one chain) and the softmax sums in different orders: now and then a
-        # ReLU / dropout gate at a pre-activation within rounding of zero falls differently (see test_gpu_parity_sizes.py), which
-        # moves one row of linear1's weight gradient and everything upstream by a few 1e-4 of the tensor maximum -- bound the whole
-        # tensor (relative L2) tightly and any single element loosely
-        err = float((g0[k] - g1[k]).abs().max())
-        if err > 1e-4 * float(g0[k].abs().max()) + 1e-12:
-            rel = float((g0[k] - g1[k]).norm() / g0[k].norm().clamp_min(1e-30))
-            assert rel <= 3e-3 and err <= 5e-2 * float(g0[k].abs().max()), (k, rel, err, float(g0[k].abs().max()))
+    (o0, g0) = res[0]
+    for mode, (o1, g1) in zip((2, 4, 6), res[1:]):
+        assert torch.isfinite(o1).all()
+        assert float((o0 - o1).abs().max()) <= 2e-5 * float(o0.abs().max()) + 1e-7, (mode, float((o0 - o1).abs().max()))
+        assert set(g1) == set(g0)
+        for k in g0:
+            if k.startswith("attention_fusion."):
+                continue
+            assert torch.isfinite(g1[k]).all(), (mode, k)
+            # the schedules add linear2's K range (slices vs one chain), the softmax sums and the keys' dK / dV shares in different
+            # orders: now and then a ReLU / dropout gate at a pre-activation within rounding of zero falls differently (see
+            # test_gpu_parity_sizes.py), which moves one row of linear1's weight gradient and everything upstream by a few 1e-4 of
+            # the tensor maximum -- bound the whole tensor (relative L2) tightly and any single element loosely
+            err = float((g0[k] - g1[k]).abs().max())
+            if err > 1e-4 * float(g0[k].abs().max()) + 1e-12:
+                rel = float((g0[k] - g1[k]).norm() / g0[k].norm().clamp_min(1e-30))
+                assert rel <= 3e-3 and err <= 5e-2 * float(g0[k].abs().max()), (mode, k, rel, err, float(g0[k].abs().max()))
 
 
 @pytest.mark.parametrize("F,B,training", [(64, 37, True), (128, 16, True), (64, 512, True), (2048, 24, True), (128, 33, False),
