@@ -66,6 +66,7 @@ _SIGNATURES = {
     "bbbp_set_fused_encoder": (c_int, [c_int]),
     "bbbp_set_flash_attention": (c_int, [c_int]),
     "bbbp_set_gemm_split_bf16": (c_int, [c_int]),
+    "bbbp_set_gemm_fold_reduce": (c_int, [c_int]),
     "bbbp_gemm_split_bf16_phases": (c_int, [POINTER(c_uint64)]),
     "bbbp_gbt_predict": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                          c_void_p, c_void_p]),

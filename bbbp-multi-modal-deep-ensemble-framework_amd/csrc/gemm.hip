@@ -20,6 +20,8 @@
 // work-group.  bbbp_gemm_f32 picks the path; results of both agree to rounding (different summation order).
 #include "common.h"
 #include "bbbp_hip.h"
+#include <mutex>
+#include <unordered_map>
 
 #define TRY_RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
@@ -44,6 +46,7 @@ struct GemmParams {
     int act;                 // 0 none, 1 relu, 2 tanh
     int splits, kchunk;      // split-K: K range per split (multiple of BK)
     float* slab;             // [batch][split][M][N] when splits > 1
+    unsigned* arrivals;      // split-bf16 kernel only: one counter per output tile; the LAST K range to arrive sums the tile's slabs itself
     int vecA, vecB;          // 16-byte global loads allowed
     int short_k;             // 128 x 128 tiles with 16-deep stages
     const float* gate; int ldg; long sG; float gate_scale;      // optional: result *= gate > 0 ? gate_scale : 0
@@ -477,9 +480,60 @@ __device__ __forceinline__ void gemm_b3_body(const GemmParams& p) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int m = m0 + wm * 64 + i * 32 + mfma_row(q, lane);
-                    if (m < p.M && n < p.N) S[(long)m * p.N + n] = acc[i][j][q];
+                    if (m < p.M && n < p.N) {
+                        // with the in-kernel reduction the slab goes straight to the coherence point (agent-scope relaxed store = sc1 write-through)
+                        if (p.arrivals) __hip_atomic_store(&S[(long)m * p.N + n], acc[i][j][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else S[(long)m * p.N + n] = acc[i][j][q];
+                    }
                 }
             }
+        if (!p.arrivals) return;                     // the reduce kernel follows
+        // The K range that arrives LAST at this tile sums the tile's slabs -- in split order, from memory, its own included, so the
+        // result does not depend on who was last and equals gemm_splitk_reduce_kernel's bit for bit -- and applies the epilogue: no
+        // second launch (round 3; at F = 2048 the 42 reduce launches of a step are 0.6 ms).  OPT-IN: measured slower.  The slabs of the other K ranges were
+        // written through other XCDs' L2s: every slab store and load of this path is an agent-scope relaxed atomic (sc1: written through
+        // to / read from the coherence point), ordered by s_waitcnt vmcnt(0) before the arrival counter is bumped.  NOT by
+        // __threadfence(): an agent-scope release / acquire is a write-back / invalidate of the whole L2 of the XCD, which every
+        // kernel running beside this one pays for (measured: F = 2048 step 8.4 -> 12.5 ms with fences; 9.85 ms with the sc1 accesses,
+        // whose 4-byte write-through stores and uncached loads cost more than the 15 us launch they replace).
+        __shared__ int s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) {
+            unsigned* cnt = p.arrivals + ((long)batch * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (old == (unsigned)p.splits - 1u) ? 1 : 0;
+            if (s_last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this stream
+        }
+        __syncthreads();
+        if (!s_last) return;
+        const long mn = (long)p.M * p.N;
+        const float* S0 = p.slab + (long)batch * p.splits * mn;
+        float* Cf = p.C + (long)batch * p.sC;
+        const float* Rf = p.R ? p.R + (long)batch * p.sR : nullptr;
+        const int tw = min(128, p.N - n0), th = min(128, p.M - m0);
+        for (int e = t; e < th * 128; e += 256) {
+            const int lm = e >> 7, ln = e & 127;
+            if (ln >= tw) continue;
+            const int m = m0 + lm, n = n0 + ln;
+            const float* sp = S0 + (long)m * p.N + n;
+            float sum = 0.f;
+            int k = 0;
+            for (; k + 8 <= p.splits; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = __hip_atomic_load(sp + (long)(k + u) * mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum += v[u];
+            }
+            for (; k < p.splits; ++k) sum += __hip_atomic_load(sp + (long)k * mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float v = apply_act(p.alpha * sum + (p.bias ? p.bias[n] : 0.f), p.act);
+            const float gsel = p.gate ? (p.gate[(long)batch * p.sG + (long)m * p.ldg + n] > 0.f ? p.gate_scale : 0.f) : 1.f;
+            if (!p.gate_after) v *= gsel;
+            if (Rf) v += Rf[(long)m * p.ldr + n];
+            if (p.gate_after) v *= gsel;
+            Cf[(long)m * p.ldc + n] = v;
+        }
         return;
     }
     float* C = p.C + (long)batch * p.sC;
@@ -994,6 +1048,40 @@ int gemm_b3_on() {
     if (g_gemm_b3 < 0) { const char* e = getenv("BBBP_GEMM_SPLIT_BF16"); g_gemm_b3 = e ? (atoi(e) != 0) : 1; }
     return g_gemm_b3;
 }
+// Arrival counters of the split-bf16 kernel's in-kernel split-K reduction: one zeroed region per (device, stream) -- launches on one
+// stream run one after another and every launch leaves its counters at zero, launches on different streams never share a region.
+constexpr int ARRIVAL_REGION = 8192, ARRIVAL_REGIONS = 32;
+int g_gemm_fold_reduce = -1;
+int gemm_fold_reduce_on() {
+    if (g_gemm_fold_reduce < 0) { const char* e = getenv("BBBP_GEMM_FOLD_REDUCE"); g_gemm_fold_reduce = e ? (atoi(e) != 0) : 0; }      // default off: measured slower, see DESIGN.md section 3
+    return g_gemm_fold_reduce;
+}
+unsigned* arrival_counters(hipStream_t st, long tiles) {
+    if (!gemm_fold_reduce_on() || tiles > ARRIVAL_REGION) return nullptr;
+    static std::mutex mu;
+    static unsigned* base[64] = {};
+    static std::unordered_map<hipStream_t, int> region[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!base[dev]) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        if (cap != hipStreamCaptureStatusNone) return nullptr;          // no allocation inside a capture: this launch keeps the reduce kernel
+        unsigned* ptr = nullptr;
+        const size_t bytes = (size_t)ARRIVAL_REGION * ARRIVAL_REGIONS * sizeof(unsigned);
+        if (hipMalloc(&ptr, bytes) != hipSuccess) return nullptr;
+        if (hipMemset(ptr, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(ptr); return nullptr; }
+        base[dev] = ptr;
+    }
+    auto it = region[dev].find(st);
+    if (it == region[dev].end()) {
+        if ((int)region[dev].size() >= ARRIVAL_REGIONS) return nullptr;
+        it = region[dev].emplace(st, (int)region[dev].size()).first;
+    }
+    return base[dev] + (size_t)it->second * ARRIVAL_REGION;
+}
+
 // the split-bf16 form serves 128 x 128 plans whose operands can be read in aligned-extent quads
 bool b3_eligible(const GemmParams& p, int layout) {
     if (!gemm_b3_on() || p.K < 32) return false;          // any K >= 32: a partial last stage is handled by B3Loader::load_tail
@@ -1154,12 +1242,14 @@ int gemm_run(hipStream_t st, const bbbp_gemm_desc& g, void* workspace, size_t wo
                  (long)cdiv(M, 128) * cdiv(N, 128) * batch >= (long)short_k_tiles * bbbp_num_cus()) ? 1 : 0;
     dim3 grid(cdiv(N, tile), cdiv(M, tile), batch * p.splits);
     BBBP_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
+    p.arrivals = nullptr;
     if (tile == 128 && b3_eligible(p, layout)) {
+        if (p.splits > 1) p.arrivals = arrival_counters(st, (long)grid.x * grid.y * batch);
         TRY_RC(layout == 0 ? launch_b3_one<0>(p, grid, st) : layout == 1 ? launch_b3_one<1>(p, grid, st) : launch_b3_one<2>(p, grid, st));
     } else if (tile == 128) launch_tile<128, 128>(p, layout, grid, st);
     else launch_tile<64, 64>(p, layout, grid, st);
     BBBP_CHECK_LAUNCH();
-    if (p.splits > 1) {
+    if (p.splits > 1 && !p.arrivals) {
         long mn = (long)M * N;
         int gx = (int)((mn + 255) / 256);
         if (gx > 4096) gx = 4096;
@@ -1208,6 +1298,12 @@ extern "C" int bbbp_gemm_f32_grouped(void* stream, const bbbp_gemm_desc* problem
         ++i;
     }
     return BBBP_OK;
+}
+
+extern "C" int bbbp_set_gemm_fold_reduce(int on) {
+    const int prev = gemm_fold_reduce_on();
+    g_gemm_fold_reduce = on ? 1 : 0;
+    return prev;
 }
 
 extern "C" int bbbp_set_gemm_split_bf16(int on) {

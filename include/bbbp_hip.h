@@ -290,10 +290,16 @@ int bbbp_set_partition(int reserved_cus, size_t small_lds_pad);   /* CU partitio
 /* The head / fusion-block input-gradient chain of bbbp_mixed_backward as two fused launches instead of ten (default on since
  * round 2: 3.32 -> 3.27 ms per step at B = 512).  Returns the previous setting.  Initial value: BBBP_FUSED_HEAD_BWD. */
 int bbbp_set_fused_head_bwd(int on);
-/* The row-local stretches of an encoder layer (out_proj .. LayerNorm2 + the next in_proj forward; LayerNorm2 backward ..
- * out_proj input gradient backward) as ONE launch each (csrc/encoder.hip) instead of 6 + 6, for d_model <= 192 (default OFF:
- * measured slower, see csrc/engine.hip; initial value BBBP_FUSED_ENCODER).  Returns the previous setting.  Both schedules fill the same workspace. */
-int bbbp_set_fused_encoder(int on);
+/* Alternative schedules of the fingerprint encoder, a bit mask (default 0: every one measured slower than the launch-per-op chain, see
+ * DESIGN.md section 3; initial value BBBP_FUSED_ENCODER).  All of them fill the same workspace and draw the same dropout masks.
+ * bit 0: the row-local stretches of a layer (out_proj .. LayerNorm2 + the next in_proj forward; LayerNorm2 backward .. out_proj input
+ *        gradient backward) as ONE launch each (csrc/encoder.hip: enc_row_*_kernel) instead of 6 + 6, for d_model <= 192;
+ * bit 1: batches of at most 128 molecules, one head, d_model <= 176: the whole FORWARD chain of the encoder (all layers + fingerprint_fc)
+ *        as one persistent launch (enc_sliced_fwd_kernel: 16-row blocks shared by column-slicing work-groups, barriers through counters
+ *        in the workspace);
+ * bit 2: the same for the BACKWARD input-gradient chain (enc_sliced_bwd_kernel); the weight gradients stay leaf launches.
+ * Returns the previous mask. */
+int bbbp_set_fused_encoder(int mode);
 /* Fused flash-style self-attention (csrc/attention.hip, csrc/attention_b3.hip), a bit mask (default 13, initial value BBBP_FLASH_ATTENTION):
  * bit 0: many heads of head_dim 8 / 16 (F = 2048: 256 x 8), one work-group per head, scores in registers, no [nhead, B, B] tensors;
  * bit 1: one wide head of 161 .. 176 columns (F = 167, nhead = 1), operands straight from global memory, everywhere -- correct but
@@ -309,6 +315,11 @@ int bbbp_set_flash_attention(int on);
  * BBBP_GEMM_SPLIT_BF16) runs them on the bf16 matrix pipe with every float32 operand split into three bf16 pieces (six MFMAs per
  * k-step, f32 accumulate, float32 accuracy; csrc/gemm.hip: gemm_b3_kernel), 0 on the f32 MFMA.  Returns the previous setting. */
 int bbbp_set_gemm_split_bf16(int on);
+/* Split-K launches of the split-bf16 GEMM: 1 lets the K range that arrives last at an output tile sum the tile's slabs in split order
+ * and apply the epilogue inside the GEMM launch (per-tile arrival counters, slabs written through to the coherence point), 0 (default;
+ * initial value BBBP_GEMM_FOLD_REDUCE) runs the separate reduce kernel.  Both produce the same bits; the in-kernel form is measured
+ * slower on MI355X.  Returns the previous setting. */
+int bbbp_set_gemm_fold_reduce(int on);
 /* Debug: shader cycles of work-group 0 / wave 0 of the last split-bf16 GEMM launched with BBBP_GEMM_B3_PROBE=1 in the environment:
  * [0] global-load issue, [1] LDS reads + MFMA block, [2] barrier after it, [3] split + LDS writes, [4] barrier after them, [5] all shader
  * cycles of that wave's K loop and [6] the same span in 100 MHz wall ticks (their ratio is the sustained shader clock). */

@@ -59,6 +59,37 @@ def test_gemm_layouts(dev, M, N, K, layout, gemm_form):
     assert (err <= 2e-6 * scale + 1e-30).all(), f"max err ratio {(err / (scale + 1e-30)).max():.3e}"
 
 
+@pytest.mark.parametrize("M,N,K,layout", [(512, 2048, 2048, "nt"), (512, 2048, 2048, "nn"), (512, 167, 65536, "nt"), (130, 300, 4100, "nt"),
+                                          (2048, 2048, 512, "tn")])
+def test_split_k_reduction_inside_the_gemm_launch_equals_the_reduce_kernel(dev, M, N, K, layout):
+    """csrc/gemm.hip (GemmParams.arrivals): the K range that arrives last at an output tile sums the tile's slabs in split order and
+    applies the epilogue (bias, ReLU, residual) itself.  Same summation order as gemm_splitk_reduce_kernel => the same bits, whoever
+    arrives last; three launches in a row reuse the self-resetting counters.  Shapes: the F = 2048 encoder's linear1 and its input
+    gradient at B = 512 (8 K ranges), the image FC forward (K = 65536), ragged tiles with a K tail, and an unsplit weight gradient."""
+    L = _lib.lib()
+    a = rnd(M, K, seed=M + K); b = rnd(K, N, seed=N + 7)
+    bias = rnd(N, seed=3).to(dev); res = rnd(M, N, seed=4).to(dev)
+    def run():
+        kw = dict(bias=bias, residual=res, act="relu")
+        if layout == "nt":
+            return ops.gemm(a.to(dev), b.t().contiguous().to(dev), trans_b=True, **kw)
+        if layout == "nn":
+            return ops.gemm(a.to(dev), b.to(dev), **kw)
+        return ops.gemm(a.t().contiguous().to(dev), b.to(dev), trans_a=True, **kw)
+    old = L.bbbp_set_gemm_fold_reduce(0)
+    try:
+        want = run()
+        L.bbbp_set_gemm_fold_reduce(1)
+        for _ in range(3):
+            got = run()
+            assert torch.equal(got, want)
+    finally:
+        L.bbbp_set_gemm_fold_reduce(old)
+    ref = torch.relu(a.double() @ b.double() + bias.cpu().double()) + res.cpu().double()
+    scale = a.abs().double() @ b.abs().double() + 1.0
+    assert ((got.cpu().double() - ref).abs() <= 2e-6 * scale).all()
+
+
 def test_gemm_epilogues_and_slices(dev):
     M, N, K = 100, 70, 50
     a, w, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
