@@ -21,7 +21,12 @@ class MixedDesc(Structure):
     """bbbp_mixed_desc (include/bbbp_hip.h)."""
     _fields_ = [("batch", c_int), ("fingerprint_size", c_int), ("nhead", c_int), ("num_layers", c_int),
                 ("dim_feedforward", c_int), ("training", c_int), ("dropout_p", c_float), ("seed", c_uint64),
-                ("need_input_grad", c_int), ("fusion", c_int), ("inference", c_int)]
+                ("need_input_grad", c_int), ("fusion", c_int), ("inference", c_int),
+                ("world", c_int), ("rank", c_int), ("collective", c_void_p), ("collective_ctx", c_void_p)]
+
+
+# bbbp_collective_fn (include/bbbp_hip.h): ctx, op, what, layer, send_off, recv_off, count, stream
+CollectiveFn = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_int, c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, c_void_p)
 
 
 class GemmDesc(Structure):

@@ -8,6 +8,7 @@
 #include "common.h"
 #include "attention_b3.h"
 #include "encoder_sliced.h"
+#include "head_sync.h"
 #include <optional>
 #include "bbbp_hip.h"
 #include <mutex>
@@ -56,7 +57,7 @@ struct Bump {
     size_t f(size_t n) { return take(n * sizeof(float)); }
 };
 
-struct LayerOff { size_t qkv, prob, pd, ctx, z1, y1, hff, z2, y2, mean1, rstd1, mean2, rstd2, lse, keep; };      // keep: 0 = none
+struct LayerOff { size_t qkv, prob, pd, ctx, z1, y1, hff, z2, y2, mean1, rstd1, mean2, rstd2, lse, keep, kvg; };      // keep: 0 = none; kvg: exact-global-batch mode only
 // per-layer gradient buffers: weight-gradient kernels read them on a third stream while the dependency
 // chain moves on to the next layer, so they must not be recycled within one backward pass
 struct LayerGrad { size_t dyout, dz2, dz2d, dhff, dy1, dz1, dz1d, dqkv; };
@@ -67,6 +68,9 @@ struct Plan {
     bool flash;            // many heads of head_dim 8 / 16: fused attention (attention.hip), no [NH,B,B] probability tensors
     size_t sl_sync, sl_part;   // sliced persistent forward: barrier counters, linear2 partials (allocated whenever the shape is supported)
     size_t sl_kvpart;          // sliced persistent backward: every row block's share of dK | dV (training plans only)
+    // exact-global-batch mode (bbbp_mixed_desc.collective): B is this rank's shard, keys / values / BatchNorm statistics span Bg = world * B rows
+    bool exact; int world, rank; size_t Bg;
+    size_t dkvg, dkvl;         // this rank's queries' share of dK | dV for all Bg keys; the reduce-scattered rows of this rank
     bool attn_b3;          // forward-only plan, wide head, >= 1024 rows: split-bf16 attention (attention_b3.hip)
     size_t attn_part, attn_part_bytes;
     LayerOff layer[32];
@@ -98,17 +102,22 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     p->B = d->batch; p->F = d->fingerprint_size; p->NH = d->nhead; p->D = p->F / p->NH; p->L = d->num_layers;
     p->DFF = d->dim_feedforward;
     p->drop = d->training && d->dropout_p > 0.f;
+    p->exact = d->collective != nullptr;
+    BBBP_CHECK_ARG(p->exact || d->world <= 1, "world = %d needs a collective callback", d->world);
+    p->world = p->exact && d->world > 1 ? d->world : 1; p->rank = p->exact ? d->rank : 0;
+    BBBP_CHECK_ARG(p->rank >= 0 && p->rank < p->world, "rank %d of %d", d->rank, p->world);
+    p->Bg = (size_t)p->B * p->world;
     if (g_flash_attention < 0) { const char* e = getenv("BBBP_FLASH_ATTENTION"); g_flash_attention = e ? atoi(e) & 31 : 13; }
     // bit 3 (round 3): forward-only plans of 2048 rows and more with a wide head run the split-bf16 attention kernel (attention_b3.hip);
     // bit 4: that kernel from 256 rows on (tests; below ~2048 rows its 128-query work-groups leave most CUs idle)
     p->attn_b3 = (g_flash_attention & 8) && p->inference && p->L > 0 && p->B >= ((g_flash_attention & 16) ? 256 : 2048) &&
-                 bbbp_attn_b3_supported(p->B, p->NH, p->D);
+                 bbbp_attn_b3_supported(p->B, p->NH, p->D) && !p->exact;
     // bit 2: the wide-head kernel where it wins -- forward-only plans of 2048 rows and more (256+ work-groups fill the chip and the
     // [B, B] probability tensor, 67 MB per layer at B = 4096, is never written): config 5 8.28 -> 7.84 ms per 4096 molecules
     const bool wide = (g_flash_attention & 2) || ((g_flash_attention & 4) && p->inference && p->B >= 2048);
-    p->flash = p->L > 0 && (p->attn_b3 || ((g_flash_attention & 1) && bbbp_attn_small_supported(p->B, p->NH, p->D)) ||
+    p->flash = p->L > 0 && !p->exact && (p->attn_b3 || ((g_flash_attention & 1) && bbbp_attn_small_supported(p->B, p->NH, p->D)) ||
                             (wide && bbbp_attn_wide_supported(p->B, p->NH, p->D)));
-    const size_t B = p->B, F = p->F, NH = p->NH, DFF = p->DFF;
+    const size_t B = p->B, F = p->F, NH = p->NH, DFF = p->DFF, Bg = p->Bg;
     Bump b;
     p->seed_slot = b.take(256);
     for (int l = 0; l < p->L; ++l) {
@@ -118,10 +127,11 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
         // (not for batches the sliced persistent forward can take: its row blocks run layers out of step, so a layer's buffers must not be
         // the previous layer's; at B <= 128 a layer's activations are < 2 MB)
         if (p->inference && l > 0 && !bbbp_enc_sliced_supported(p->B, p->F, p->NH, p->DFF, p->L)) { o = p->layer[0]; continue; }
-        o.qkv = b.f(B * 3 * F); o.prob = p->flash ? 0 : b.f(NH * B * B); o.ctx = b.f(B * F);
+        o.qkv = b.f(B * 3 * F); o.prob = p->flash ? 0 : b.f(NH * B * Bg); o.ctx = b.f(B * F);
+        o.kvg = p->exact ? b.f(Bg * 2 * F) : 0;          // K | V of every rank's rows, kept for the backward pass
         // dropped attention weights are KEPT per layer (1 MB at B = 512, one head) rather than recomputed in backward:
         // every launch on the encoder's chain costs more than the bytes
-        o.pd = (p->drop && !p->flash) ? b.f(NH * B * B) : o.prob;
+        o.pd = (p->drop && !p->flash) ? b.f(NH * B * Bg) : o.prob;
         o.lse = b.f(NH * B);
         // fused small-head attention with dropout: the forward pass leaves its keep decisions (one byte per lane and tile pair, 17 MB
         // per layer at F = 2048, B = 512) for the backward pass, whose dominant cost was drawing them again
@@ -146,7 +156,7 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     p->combined = b.f(B * COMB); p->hid = b.f(NHEADS_FUSION * B * FUS_HID); p->attn = b.f(B * NHEADS_FUSION);
     p->fused = p->concat ? p->combined : b.f(B * COMB); p->h = b.f(B * H1); p->hb = b.f(B * H1); p->bn_mean = b.f(H1); p->bn_rstd = b.f(H1);
     p->h2 = b.f(B * H2); p->h3 = b.f(B * H3);
-    p->head_partial = b.f(((B + 15) / 16) * 2 * H1);
+    p->head_partial = b.f((size_t)p->world * ((B + 15) / 16) * 2 * H1);
     size_t cw = bbbp_conv3x3_workspace_bytes(p->B, 32, 64, 64, 64);
     size_t cw1 = bbbp_conv3x3_workspace_bytes(p->B, 3, 32, 128, 128);
     size_t sb = cw > cw1 ? cw : cw1;
@@ -167,12 +177,31 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     }
     p->scratch3_bytes = (size_t)32 << 20;
     p->scratch3 = b.take(p->scratch3_bytes);
-    p->dA = b.f(B * F); p->dB = b.f(B * F); p->dqkv = b.f(B * 3 * F); p->dprob = p->flash ? 0 : b.f(NH * B * B); p->dctx = b.f(B * F);
+    p->dA = b.f(B * F); p->dB = b.f(B * F); p->dqkv = b.f(B * 3 * F); p->dprob = p->flash ? 0 : b.f(NH * B * Bg); p->dctx = b.f(B * F);
+    p->dkvg = p->exact ? b.f(Bg * 2 * F) : 0; p->dkvl = p->exact ? b.f(B * 2 * F) : 0;
     p->dhff = b.f(B * DFF); p->dpool2 = b.f(B * IMG_FLAT); p->dpool1 = b.f(B * C1 * (IMG / 2) * (IMG / 2));
     p->dcomb = b.f(B * COMB); p->dfused = b.f(B * COMB); p->dlogit = b.f(NHEADS_FUSION * B);
     p->dpre = b.f(NHEADS_FUSION * B * FUS_HID); p->dh = b.f(B * H1); p->dhb = b.f(B * H1); p->dh2 = b.f(B * H2);
     p->dh3 = b.f(B * H3);
     p->total = b.off;
+    return BBBP_OK;
+}
+
+// exact-global-batch mode: K | V of this rank's rows into its slot of the gathered buffer, and the reduce-scattered dK | dV back into dqkv
+__global__ __launch_bounds__(256) void kv_pack_kernel(const float* __restrict__ qkv, float* __restrict__ kv, long n, int F) {
+    BBBP_HIGH_PRIO();
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const long r = i / (2 * F); const int c = (int)(i % (2 * F)); kv[i] = qkv[r * 3 * F + F + c]; }
+}
+__global__ __launch_bounds__(256) void kv_unpack_kernel(const float* __restrict__ dkv, float* __restrict__ dqkv, long n, int F) {
+    BBBP_HIGH_PRIO();
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const long r = i / (2 * F); const int c = (int)(i % (2 * F)); dqkv[r * 3 * F + F + c] = dkv[i]; }
+}
+int run_collective(const bbbp_mixed_desc* d, int op, int what, int layer, size_t send_off, size_t recv_off, size_t count, hipStream_t st) {
+    BBBP_CHECK_ARG(d->collective, "no collective callback");
+    const int rc = d->collective(d->collective_ctx, op, what, layer, send_off, recv_off, count, st);
+    if (rc) { bbbp_set_error("collective callback (op %d, what %d, layer %d) returned %d", op, what, layer, rc); return BBBP_ERR_ARG; }
     return BBBP_OK;
 }
 
@@ -232,11 +261,11 @@ int fused_encoder_mode() {
     return g_fused_encoder;
 }
 bool fused_encoder(const Plan& p) {
-    return (fused_encoder_mode() & 1) && p.L > 0 && !p.flash && bbbp_enc_rows_supported(p.F, p.NH, p.DFF);
+    return (fused_encoder_mode() & 1) && p.L > 0 && !p.flash && !p.exact && bbbp_enc_rows_supported(p.F, p.NH, p.DFF);
 }
 // the whole forward chain of a small batch as one persistent launch (encoder.hip: enc_sliced_fwd_kernel)
 bool sliced_encoder(const Plan& p, int bit = 2) {
-    return (fused_encoder_mode() & bit) && p.L > 0 && !p.flash && bbbp_enc_sliced_supported(p.B, p.F, p.NH, p.DFF, p.L);
+    return (fused_encoder_mode() & bit) && p.L > 0 && !p.flash && !p.exact && bbbp_enc_sliced_supported(p.B, p.F, p.NH, p.DFF, p.L);
 }
 bool overlap_enabled() {
     if (g_overlap < 0) { const char* e = getenv("BBBP_SINGLE_STREAM"); g_overlap = (e && e[0] == '1') ? 0 : 1; }
@@ -543,6 +572,7 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
     Ctx c{static_cast<hipStream_t>(stream), static_cast<char*>(workspace), &plan};
     const PIdx ix(d);
     const int B = plan.B, F = plan.F, NH = plan.NH, D = plan.D, DFF = plan.DFF;
+    const int Bk = (int)plan.Bg;            // attention keys: this rank's rows, or every rank's in exact-global-batch mode
     const float p_drop = plan.drop ? d->dropout_p : 0.f;
     const float scale = 1.0f / sqrtf((float)D);
 
@@ -649,13 +679,24 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         } else if (plan.flash) {
             TRY(bbbp_attn_small_fwd(ce.st, qkv, ctx, c.f(o.lse), B, F, NH, scale, p_drop, site_seed(d->seed, l, 0), o.keep ? c.u8(o.keep) : nullptr));
         } else {
+        // keys and values: this rank's rows of qkv, or (exact-global-batch mode) the rows of every rank, gathered once per layer
+        const float* kmat = qkv + F; const float* vmat = qkv + 2 * F; int ldkv = 3 * F;
+        if (plan.exact) {
+            float* kvg = c.f(o.kvg);
+            const long n = (long)B * 2 * F;
+            hipLaunchKernelGGL(kv_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), g_bbbp_small_lds_pad, ce.st, qkv,
+                               kvg + (size_t)plan.rank * n, n, F);
+            BBBP_CHECK_LAUNCH();
+            TRY(run_collective(d, BBBP_COLL_ALLGATHER, BBBP_COLL_KV, l, o.kvg + (size_t)plan.rank * n * sizeof(float), o.kvg, (size_t)n, ce.st));
+            kmat = kvg; vmat = kvg + F; ldkv = 2 * F;
+        }
         // scores_h = scale * Q_h K_h^T
-        TRY(bbbp_gemm_f32(ce.st, 0, 1, B, B, D, scale, qkv, 3 * F, qkv + F, 3 * F, prob, B, nullptr, nullptr, 0, 0, NH, D, D,
-                          (long)B * B, 0, ce.scratch(), ce.scratch_bytes()));
+        TRY(bbbp_gemm_f32(ce.st, 0, 1, B, Bk, D, scale, qkv, 3 * F, kmat, ldkv, prob, Bk, nullptr, nullptr, 0, 0, NH, D, D,
+                          (long)B * Bk, 0, ce.scratch(), ce.scratch_bytes()));
         float* pd = c.f(o.pd);
-        TRY(bbbp_softmax_fwd(ce.st, prob, pd, (long)NH * B, B, p_drop, site_seed(d->seed, l, 0)));
+        TRY(bbbp_softmax_fwd(ce.st, prob, pd, (long)NH * B, Bk, p_drop, site_seed(d->seed, l, 0)));
         // ctx_h = Pd_h V_h
-        TRY(bbbp_gemm_f32(ce.st, 0, 0, B, D, B, 1.f, pd, B, qkv + 2 * F, 3 * F, ctx, F, nullptr, nullptr, 0, 0, NH, (long)B * B,
+        TRY(bbbp_gemm_f32(ce.st, 0, 0, B, D, Bk, 1.f, pd, Bk, vmat, ldkv, ctx, F, nullptr, nullptr, 0, 0, NH, (long)B * Bk,
                           D, D, 0, ce.scratch(), ce.scratch_bytes()));
         }
         sec_attn.reset();
@@ -712,16 +753,26 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
     Section sec_head(c.st, SEC_HEAD_FWD);
 
     static const int fused_head = [] { const char* e = getenv("BBBP_FUSED_HEAD"); return e ? atoi(e) : 1; }();
+    BBBP_CHECK_ARG(!plan.exact || (fused_head && NHEADS_FUSION == 4), "the exact-global-batch mode needs the fused head (BBBP_FUSED_HEAD=1)");
     if (fused_head && NHEADS_FUSION == 4) {
         // fusion block + head in two launches (head.hip); with torch.cat fusion the first launch starts at fc.0
         const float *fw1[4] = {}, *fb1[4] = {}, *fw2[4] = {}, *fb2[4] = {};
         if (!plan.concat)
             for (int h = 0; h < 4; ++h) { fw1[h] = P[ix.fus(h, 0)]; fb1[h] = P[ix.fus(h, 1)]; fw2[h] = P[ix.fus(h, 2)]; fb2[h] = P[ix.fus(h, 3)]; }
-        return bbbp_head_forward_fused(c.st, comb, fw1, fb1, fw2, fb2, P[ix.fc0_w()], P[ix.fc0_b()], P[ix.bn_w()], P[ix.bn_b()],
-                                       bn_running[0], bn_running[1], P[ix.fc3_w()], P[ix.fc3_b()], P[ix.fc5_w()], P[ix.fc5_b()],
-                                       P[ix.fc7_w()], P[ix.fc7_b()], c.f(plan.hid), c.f(plan.attn), c.f(plan.fused), c.f(plan.h),
-                                       c.f(plan.hb), c.f(plan.bn_mean), c.f(plan.bn_rstd), c.f(plan.h2), c.f(plan.h3), out,
-                                       c.f(plan.head_partial), B, d->training, plan.concat ? 1 : 0);
+        // exact-global-batch mode: the (mean, M2) blocks of every rank are gathered between the two launches
+        bbbp_head_sync sync;
+        sync.world = plan.world; sync.rank = plan.rank;
+        const size_t pcount = (size_t)((B + 15) / 16) * 2 * H1;
+        if (plan.exact)
+            sync.between = [&]() -> int {
+                return run_collective(d, BBBP_COLL_ALLGATHER, BBBP_COLL_BN_FWD, -1, plan.head_partial + (size_t)plan.rank * pcount * sizeof(float),
+                                      plan.head_partial, pcount, c.st);
+            };
+        return bbbp_head_forward_fused_sync(c.st, comb, fw1, fb1, fw2, fb2, P[ix.fc0_w()], P[ix.fc0_b()], P[ix.bn_w()], P[ix.bn_b()],
+                                            bn_running[0], bn_running[1], P[ix.fc3_w()], P[ix.fc3_b()], P[ix.fc5_w()], P[ix.fc5_b()],
+                                            P[ix.fc7_w()], P[ix.fc7_b()], c.f(plan.hid), c.f(plan.attn), c.f(plan.fused), c.f(plan.h),
+                                            c.f(plan.hb), c.f(plan.bn_mean), c.f(plan.bn_rstd), c.f(plan.h2), c.f(plan.h3), out,
+                                            c.f(plan.head_partial), B, d->training, plan.concat ? 1 : 0, plan.exact ? &sync : nullptr);
     }
     // ---- attention fusion (R:60-65, 117) -------------------------------------------------------
     float* hid = c.f(plan.hid);
@@ -787,6 +838,7 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
     };
     const PIdx ix(d);
     const int B = plan.B, F = plan.F, NH = plan.NH, D = plan.D, DFF = plan.DFF;
+    const int Bk = (int)plan.Bg;            // attention keys: this rank's rows, or every rank's in exact-global-batch mode
     const float p_drop = plan.drop ? d->dropout_p : 0.f;
     const float inv_keep = plan.drop ? 1.f / (1.f - p_drop) : 1.f;
     const float scale = 1.0f / sqrtf((float)D);
@@ -822,14 +874,25 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         TRY(bbbp_bias_act_bwd(cl.st, dcomb + FC, COMB, nullptr, 0, G[ix.ifc_b()], B, FC, 0, 1.f));
         return BBBP_OK;
     };
+    BBBP_CHECK_ARG(!plan.exact || fused_head_bwd, "the exact-global-batch mode needs the fused head backward (bbbp_set_fused_head_bwd(1))");
     if (fused_head_bwd) {
         // the whole input-gradient chain of the head and the fusion block in two launches (head.hip); every weight / bias
         // gradient below is a leaf that reads what those wrote
         const float* fw1[NHEADS_FUSION]; const float* fw2[NHEADS_FUSION];
         for (int hh = 0; hh < NHEADS_FUSION; ++hh) { fw1[hh] = P[ix.fus(hh, 0)]; fw2[hh] = P[ix.fus(hh, 2)]; }
-        TRY(bbbp_head_backward_fused(c.st, dout, comb, hid, c.f(plan.attn), h, h2, h3, c.f(plan.bn_mean), c.f(plan.bn_rstd),
-                                     P[ix.bn_w()], fw1, fw2, P[ix.fc0_w()], P[ix.fc3_w()], P[ix.fc5_w()], P[ix.fc7_w()], dh3, dh2, dhb,
-                                     dh, dlogit, dpre, dcomb, G[ix.bn_w()], G[ix.bn_b()], c.f(plan.head_partial), B, d->training));
+        // exact-global-batch mode: the BatchNorm's two backward sums span every rank's rows
+        bbbp_head_sync sync;
+        sync.world = plan.world; sync.rank = plan.rank;
+        const size_t pcount = (size_t)((B + 15) / 16) * 2 * H1;
+        if (plan.exact)
+            sync.between = [&]() -> int {
+                return run_collective(d, BBBP_COLL_ALLGATHER, BBBP_COLL_BN_BWD, -1, plan.head_partial + (size_t)plan.rank * pcount * sizeof(float),
+                                      plan.head_partial, pcount, c.st);
+            };
+        TRY(bbbp_head_backward_fused_sync(c.st, dout, comb, hid, c.f(plan.attn), h, h2, h3, c.f(plan.bn_mean), c.f(plan.bn_rstd),
+                                          P[ix.bn_w()], fw1, fw2, P[ix.fc0_w()], P[ix.fc3_w()], P[ix.fc5_w()], P[ix.fc7_w()], dh3, dh2, dhb,
+                                          dh, dlogit, dpre, dcomb, G[ix.bn_w()], G[ix.bn_b()], c.f(plan.head_partial), B, d->training,
+                                          plan.exact ? &sync : nullptr));
         TRY(leaf_after(c));
         head_leaves_pending = true;          // enqueued after the image branch's kernels: the host reaches those sooner
     } else {
@@ -1065,19 +1128,30 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
             TRY(bbbp_attn_small_bwd(ce.st, qkv, ctx, c.f(o.lse), dctx, dqkv, B, F, NH, scale, p_drop, site_seed(d->seed, l, 0),
                                     o.keep ? c.u8(o.keep) : nullptr));
         } else {
+        // exact-global-batch mode: keys / values are the gathered rows of every rank; dK | dV of ALL keys (this rank's queries' share)
+        // go to dkvg and come back reduce-scattered
+        const float* kmat = plan.exact ? c.f(o.kvg) : qkv + F; const float* vmat = plan.exact ? c.f(o.kvg) + F : qkv + 2 * F;
+        const int ldkv = plan.exact ? 2 * F : 3 * F;
+        float* dkmat = plan.exact ? c.f(plan.dkvg) : dqkv + F; float* dvmat = plan.exact ? c.f(plan.dkvg) + F : dqkv + 2 * F;
         {
             bbbp_gemm_desc g[2] = {
-                gemm_desc(1, 0, B, D, B, 1.f, pdp, B, dctx, F, dqkv + 2 * F, 3 * F, NH, (long)B * B, D, D),
-                gemm_desc(0, 1, B, B, D, 1.f, dctx, F, qkv + 2 * F, 3 * F, dprob, B, NH, D, D, (long)B * B)};
+                gemm_desc(1, 0, Bk, D, B, 1.f, pdp, Bk, dctx, F, dvmat, ldkv, NH, (long)B * Bk, D, D),
+                gemm_desc(0, 1, B, Bk, D, 1.f, dctx, F, vmat, ldkv, dprob, Bk, NH, D, D, (long)B * Bk)};
             TRY(bbbp_gemm_f32_grouped(ce.st, g, 2, ce.scratch(), ce.scratch_bytes()));
         }
-        TRY(bbbp_softmax_bwd(ce.st, dprob, prob, (long)NH * B, B, p_drop, site_seed(d->seed, l, 0)));
+        TRY(bbbp_softmax_bwd(ce.st, dprob, prob, (long)NH * B, Bk, p_drop, site_seed(d->seed, l, 0)));
         //   dQ_h = scale dS_h K_h   |   dK_h = scale dS_h^T Q_h
         {
             bbbp_gemm_desc g[2] = {
-                gemm_desc(0, 0, B, D, B, scale, dprob, B, qkv + F, 3 * F, dqkv, 3 * F, NH, (long)B * B, D, D),
-                gemm_desc(1, 0, B, D, B, scale, dprob, B, qkv, 3 * F, dqkv + F, 3 * F, NH, (long)B * B, D, D)};
+                gemm_desc(0, 0, B, D, Bk, scale, dprob, Bk, kmat, ldkv, dqkv, 3 * F, NH, (long)B * Bk, D, D),
+                gemm_desc(1, 0, Bk, D, B, scale, dprob, Bk, qkv, 3 * F, dkmat, ldkv, NH, (long)B * Bk, D, D)};
             TRY(bbbp_gemm_f32_grouped(ce.st, g, 2, ce.scratch(), ce.scratch_bytes()));
+        }
+        if (plan.exact) {
+            const long n = (long)B * 2 * F;
+            TRY(run_collective(d, BBBP_COLL_REDUCE_SCATTER, BBBP_COLL_DKV, l, plan.dkvg, plan.dkvl, (size_t)n, ce.st));
+            hipLaunchKernelGGL(kv_unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), g_bbbp_small_lds_pad, ce.st, c.f(plan.dkvl), dqkv, n, F);
+            BBBP_CHECK_LAUNCH();
         }
         }
         sec_attn.reset();
@@ -1256,6 +1330,8 @@ extern "C" int bbbp_mixed_forward(void* stream, const bbbp_mixed_desc* d, const 
     uint64_t h = hash_ptrs(reinterpret_cast<const void* const*>(P), np);
     h = hash_ptrs(reinterpret_cast<const void* const*>(bn_running), 2, h);
     const GraphKey key = make_key(0, d, fingerprint, image, out, workspace, h);
+    if (d->collective)              // host callbacks between the launches: nothing to capture
+        return forward_enqueue(st, d, P, bn_running, fingerprint, image, out, workspace, workspace_bytes);
     return run_or_replay(key, st, [&](hipStream_t s) {
         return forward_enqueue(s, d, P, bn_running, fingerprint, image, out, workspace, workspace_bytes);
     });
@@ -1277,6 +1353,8 @@ extern "C" int bbbp_mixed_backward(void* stream, const bbbp_mixed_desc* d, const
     uint64_t h = hash_ptrs(reinterpret_cast<const void* const*>(P), np);
     h = hash_ptrs(reinterpret_cast<const void* const*>(G), np, h);
     const GraphKey key = make_key(1, d, fingerprint, image, dout, workspace, h);
+    if (d->collective)
+        return backward_enqueue(st, d, P, G, fingerprint, image, dout, workspace, workspace_bytes);
     return run_or_replay(key, st, [&](hipStream_t s) {
         return backward_enqueue(s, d, P, G, fingerprint, image, dout, workspace, workspace_bytes);
     });

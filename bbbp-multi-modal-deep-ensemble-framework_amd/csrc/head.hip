@@ -14,6 +14,7 @@
 // Every intermediate the backward pass reads (hid, attn, fused, h, hb, BN mean / rstd, h2, h3) is still written.
 #include "common.h"
 #include "bbbp_hip.h"
+#include "head_sync.h"
 
 namespace {
 
@@ -38,6 +39,7 @@ struct HeadParams {
     int B, training;
     float eps, momentum;
     int concat;                                          // 1: fused = combined (torch.cat fusion), the fusion block is skipped
+    int world, rank;                                     // batch sharded over `world` ranks (B = this rank's rows): partial is [world][blocks][2][256]
 };
 
 // B fragments of one 16-column tile: W rows n = 16 * tile + (lane & 15), k = 16c + 4 (lane >> 4) .. +3
@@ -178,8 +180,9 @@ __global__ __launch_bounds__(NTH) void head_a_kernel(HeadParams p) {
         for (int r = 0; r < 4; ++r) if (4 * kq + r < nrows) { const float d = v[r] - mean; m2 += d * d; }
         m2 += __shfl_xor(m2, 16); m2 += __shfl_xor(m2, 32);
         if (kq == 0) {
-            p.partial[((long)blockIdx.x * 2 + 0) * H1 + n0] = mean;
-            p.partial[((long)blockIdx.x * 2 + 1) * H1 + n0] = m2;
+            const long slot = (long)p.rank * gridDim.x + blockIdx.x;
+            p.partial[(slot * 2 + 0) * H1 + n0] = mean;
+            p.partial[(slot * 2 + 1) * H1 + n0] = m2;
         }
     }
 }
@@ -202,19 +205,20 @@ __global__ __launch_bounds__(NTH) void head_b_kernel(HeadParams p) {
         float mean, rstd;
         if (p.training) {
             float na = 0.f, ma = 0.f, m2a = 0.f;
-            for (int b = 0; b < nblocks; ++b) {
-                const float nb = (float)min(ROWS, p.B - b * ROWS);
+            for (int b = 0; b < nblocks * p.world; ++b) {          // rank by rank, block by block: the same order on every rank
+                const float nb = (float)min(ROWS, p.B - (b % nblocks) * ROWS);
                 const float mb = p.partial[((long)b * 2 + 0) * H1 + c], m2b = p.partial[((long)b * 2 + 1) * H1 + c];
                 const float d = mb - ma, n = na + nb;
                 ma += d * (nb / n);
                 m2a += m2b + d * d * (na * nb / n);
                 na = n;
             }
-            const float var = m2a / (float)p.B;
+            const float nall = (float)p.B * (float)p.world;
+            const float var = m2a / nall;
             mean = ma; rstd = rsqrtf(var + p.eps);
             if (blockIdx.x == 0) {
                 p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * mean;
-                p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * var * ((float)p.B / (float)(p.B - 1));
+                p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * var * (nall / (nall - 1.f));
             }
         } else {
             mean = p.running_mean[c]; rstd = rsqrtf(p.running_var[c] + p.eps);
@@ -298,8 +302,9 @@ struct HeadBwdParams {
     const float* w0; const float* w3; const float* w5; const float* w7;
     float* dh3; float* dh2; float* dhb; float* dh; float* dlogit; float* dpre; float* dcomb;
     float* dgamma; float* dbeta;
-    float* partial;                                      // [blocks][2][256]: per-block sums of dhb * xhat and dhb
+    float* partial;                                      // [world][blocks][2][256]: per-block sums of dhb * xhat and dhb
     int B, training;
+    int world, rank;
 };
 
 typedef float f32x2g __attribute__((ext_vector_type(2), aligned(4)));
@@ -387,8 +392,9 @@ __global__ __launch_bounds__(NTH) void head_bwd_a_kernel(HeadBwdParams p) {
     }
     __syncthreads();
     if (t < H1) {
-        p.partial[((long)blockIdx.x * 2 + 0) * H1 + t] = ((sPa[0][t] + sPa[1][t]) + sPa[2][t]) + sPa[3][t];       // fixed order
-        p.partial[((long)blockIdx.x * 2 + 1) * H1 + t] = ((sPb[0][t] + sPb[1][t]) + sPb[2][t]) + sPb[3][t];
+        const long slot = (long)p.rank * gridDim.x + blockIdx.x;
+        p.partial[(slot * 2 + 0) * H1 + t] = ((sPa[0][t] + sPa[1][t]) + sPa[2][t]) + sPa[3][t];       // fixed order
+        p.partial[(slot * 2 + 1) * H1 + t] = ((sPb[0][t] + sPb[1][t]) + sPb[2][t]) + sPb[3][t];
     }
 }
 
@@ -402,10 +408,16 @@ __global__ __launch_bounds__(NTH) void head_bwd_c_kernel(HeadBwdParams p) {
     const int nblocks = (p.B + ROWS - 1) / ROWS;
     // ---- BatchNorm: sums over the batch, blocks merged in block order ----
     if (t < H1) {
-        float sa = 0.f, sb = 0.f;
-        for (int b = 0; b < nblocks; ++b) { sa += p.partial[((long)b * 2 + 0) * H1 + t]; sb += p.partial[((long)b * 2 + 1) * H1 + t]; }
+        // the sums over the WHOLE (global) batch feed the input gradient; dgamma / dbeta are this rank's rows only (the ranks' parameter
+        // gradients are summed / averaged by the caller like every other one)
+        float sa = 0.f, sb = 0.f, la = 0.f, lb = 0.f;
+        for (int b = 0; b < nblocks * p.world; ++b) {
+            const float va = p.partial[((long)b * 2 + 0) * H1 + t], vb = p.partial[((long)b * 2 + 1) * H1 + t];
+            sa += va; sb += vb;
+            if (b / nblocks == p.rank) { la += va; lb += vb; }
+        }
         sSa[t] = sa; sSb[t] = sb;
-        if (blockIdx.x == 0) { p.dgamma[t] = sa; p.dbeta[t] = sb; }
+        if (blockIdx.x == 0) { p.dgamma[t] = la; p.dbeta[t] = lb; }
     }
     __syncthreads();
     // ---- dh = BatchNorm backward of dhb, masked by fc.0's ReLU output h ----
@@ -415,7 +427,8 @@ __global__ __launch_bounds__(NTH) void head_bwd_c_kernel(HeadBwdParams p) {
         if (r < nrows) {
             const float d = p.dhb[(long)(r0 + r) * H1 + c], xv = p.h[(long)(r0 + r) * H1 + c];
             const float g = p.gamma[c], mu = p.bn_mean[c], rs = p.bn_rstd[c];
-            v = p.training ? g * rs * (d - sSb[c] / p.B - (xv - mu) * rs * (sSa[c] / p.B)) : d * g * rs;
+            const float nall = (float)p.B * (float)p.world;
+            v = p.training ? g * rs * (d - sSb[c] / nall - (xv - mu) * rs * (sSa[c] / nall)) : d * g * rs;
             v = xv > 0.f ? v : 0.f;
             p.dh[(long)(r0 + r) * H1 + c] = v;
         }
@@ -494,8 +507,20 @@ int bbbp_head_forward_fused(hipStream_t st, const float* comb, const float* cons
                             const float* w5, const float* b5, const float* w7, const float* b7, float* hid, float* attn, float* fused,
                             float* h, float* hb, float* bn_mean, float* bn_rstd, float* h2, float* h3, float* out, float* partial,
                             int B, int training, int concat) {
+    return bbbp_head_forward_fused_sync(st, comb, fw1, fb1, fw2, fb2, w0, b0, gamma, beta, running_mean, running_var, w3, b3, w5, b5, w7, b7,
+                                        hid, attn, fused, h, hb, bn_mean, bn_rstd, h2, h3, out, partial, B, training, concat, nullptr);
+}
+
+int bbbp_head_forward_fused_sync(hipStream_t st, const float* comb, const float* const* fw1, const float* const* fb1,
+                                 const float* const* fw2, const float* const* fb2, const float* w0, const float* b0, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var, const float* w3, const float* b3,
+                                 const float* w5, const float* b5, const float* w7, const float* b7, float* hid, float* attn, float* fused,
+                                 float* h, float* hb, float* bn_mean, float* bn_rstd, float* h2, float* h3, float* out, float* partial,
+                                 int B, int training, int concat, const bbbp_head_sync* sync) {
+    const int world = sync ? sync->world : 1, rank = sync ? sync->rank : 0;
     BBBP_CHECK_ARG(B >= 1, "head: empty batch");
-    BBBP_CHECK_ARG(!(training && B <= 1), "Expected more than 1 value per channel when training, got input size [%d, %d]", B, H1);
+    BBBP_CHECK_ARG(world >= 1 && rank >= 0 && rank < world, "head: rank %d of %d", rank, world);
+    BBBP_CHECK_ARG(!(training && (long)B * world <= 1), "Expected more than 1 value per channel when training, got input size [%d, %d]", B, H1);
     HeadParams p;
     p.comb = comb;
     for (int i = 0; i < NHEADS; ++i) { p.fw1[i] = fw1[i]; p.fb1[i] = fb1[i]; p.fw2[i] = fw2[i]; p.fb2[i] = fb2[i]; }
@@ -503,9 +528,11 @@ int bbbp_head_forward_fused(hipStream_t st, const float* comb, const float* cons
     p.w3 = w3; p.b3 = b3; p.w5 = w5; p.b5 = b5; p.w7 = w7; p.b7 = b7;
     p.hid = hid; p.attn = attn; p.fused = fused; p.h = h; p.hb = hb; p.bn_mean = bn_mean; p.bn_rstd = bn_rstd; p.h2 = h2; p.h3 = h3;
     p.out = out; p.partial = partial; p.B = B; p.training = training; p.eps = 1e-5f; p.momentum = 0.1f; p.concat = concat;
+    p.world = world; p.rank = rank;
     const int blocks = cdiv(B, ROWS);
     hipLaunchKernelGGL(head_a_kernel, dim3(blocks), dim3(NTH), 0, st, p);
     BBBP_CHECK_LAUNCH();
+    if (sync && sync->between && training) { const int rc = sync->between(); if (rc) return rc; }
     hipLaunchKernelGGL(head_b_kernel, dim3(blocks), dim3(NTH), 0, st, p);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
@@ -519,6 +546,17 @@ int bbbp_head_backward_fused(hipStream_t st, const float* dout, const float* com
                              const float* const* fw1, const float* const* fw2, const float* w0, const float* w3, const float* w5,
                              const float* w7, float* dh3, float* dh2, float* dhb, float* dh, float* dlogit, float* dpre, float* dcomb,
                              float* dgamma, float* dbeta, float* partial, int B, int training) {
+    return bbbp_head_backward_fused_sync(st, dout, comb, hid, attn, h, h2, h3, bn_mean, bn_rstd, gamma, fw1, fw2, w0, w3, w5, w7, dh3, dh2, dhb, dh,
+                                         dlogit, dpre, dcomb, dgamma, dbeta, partial, B, training, nullptr);
+}
+
+int bbbp_head_backward_fused_sync(hipStream_t st, const float* dout, const float* comb, const float* hid, const float* attn, const float* h,
+                                  const float* h2, const float* h3, const float* bn_mean, const float* bn_rstd, const float* gamma,
+                                  const float* const* fw1, const float* const* fw2, const float* w0, const float* w3, const float* w5,
+                                  const float* w7, float* dh3, float* dh2, float* dhb, float* dh, float* dlogit, float* dpre, float* dcomb,
+                                  float* dgamma, float* dbeta, float* partial, int B, int training, const bbbp_head_sync* sync) {
+    const int world = sync ? sync->world : 1, rank = sync ? sync->rank : 0;
+    BBBP_CHECK_ARG(world >= 1 && rank >= 0 && rank < world, "head backward: rank %d of %d", rank, world);
     BBBP_CHECK_ARG(B >= 1, "head backward: empty batch");
     HeadBwdParams p;
     p.dout = dout; p.comb = comb; p.hid = hid; p.attn = attn; p.h = h; p.h2 = h2; p.h3 = h3;
@@ -527,9 +565,11 @@ int bbbp_head_backward_fused(hipStream_t st, const float* dout, const float* com
     p.w0 = w0; p.w3 = w3; p.w5 = w5; p.w7 = w7;
     p.dh3 = dh3; p.dh2 = dh2; p.dhb = dhb; p.dh = dh; p.dlogit = dlogit; p.dpre = dpre; p.dcomb = dcomb;
     p.dgamma = dgamma; p.dbeta = dbeta; p.partial = partial; p.B = B; p.training = training;
+    p.world = world; p.rank = rank;
     const int blocks = cdiv(B, ROWS);
     hipLaunchKernelGGL(head_bwd_a_kernel, dim3(blocks), dim3(NTH), 0, st, p);
     BBBP_CHECK_LAUNCH();
+    if (sync && sync->between && training) { const int rc = sync->between(); if (rc) return rc; }
     hipLaunchKernelGGL(head_bwd_c_kernel, dim3(blocks), dim3(NTH), 0, st, p);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;

@@ -112,6 +112,59 @@ _PTR_CACHE = weakref.WeakKeyDictionary()
 _LAST_WS = weakref.WeakKeyDictionary()
 
 
+def _exact_batch_group(model):
+    """(group, world, rank) of a model in exact-global-batch mode (``model.exact_batch``): its own group when given, else the default
+    group of an initialised ``torch.distributed``; a single process is world 1 -- the same engine path with no-op collectives."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None, 1, 0
+    group = getattr(model, "group", None)
+    group = group if group is not None else dist.group.WORLD
+    return group, dist.get_world_size(group), dist.get_rank(group)
+
+
+def _make_collective(ws, group, world, rank, errors, force=False):
+    """bbbp_collective_fn (include/bbbp_hip.h) over torch.distributed: the engine names its buffers as byte offsets into the call's
+    workspace ``ws``; the collective is issued under the engine's stream, so it is ordered after the launches that produced its input
+    and before the ones that read its output.  RCCL ("nccl") takes the tensor forms; gloo (rehearsal: ranks sharing one GPU, CPU-side
+    transport) has neither an in-place all-gather nor a reduce-scatter, so it gathers into chunks / all-reduces and slices.
+    ``force``: issue the library calls at world size 1 too (tests: the RCCL path on a one-GPU box)."""
+    import torch.distributed as dist
+
+    def f32(off, n):
+        return ws[off:off + 4 * n].view(torch.float32)
+
+    def cb(_ctx, op, what, layer, send_off, recv_off, count, stream):
+        try:
+            st = torch.cuda.ExternalStream(int(stream), device=ws.device) if stream else torch.cuda.default_stream(ws.device)
+            with torch.cuda.stream(st):
+                if op == 0:                                   # BBBP_COLL_ALLGATHER, in place
+                    if world > 1 or (force and group is not None):
+                        buf = f32(recv_off, count * world)
+                        mine = buf[rank * count:(rank + 1) * count]
+                        if dist.get_backend(group) == "gloo":
+                            dist.all_gather(list(buf.chunk(world)), mine.clone(), group=group)
+                        else:
+                            dist.all_gather_into_tensor(buf, mine, group=group)
+                elif op == 1:                                 # BBBP_COLL_REDUCE_SCATTER
+                    send, recv = f32(send_off, count * world), f32(recv_off, count)
+                    if world == 1 and not (force and group is not None):
+                        recv.copy_(send)
+                    elif dist.get_backend(group) == "gloo":
+                        dist.all_reduce(send, group=group)
+                        recv.copy_(send[rank * count:(rank + 1) * count])
+                    else:
+                        dist.reduce_scatter_tensor(recv, send, group=group)
+                else:
+                    raise RuntimeError(f"unknown collective op {op}")
+            return 0
+        except BaseException as e:        # noqa: BLE001 -- an exception must not unwind through the C frames
+            errors.append(e)
+            return 1
+
+    return _lib.CollectiveFn(cb)
+
+
 class _MixedFn(torch.autograd.Function):
     """One autograd node for the whole model: forward and backward are single C-ABI calls."""
 
@@ -125,6 +178,12 @@ class _MixedFn(torch.autograd.Function):
             _lib.check(1, "bbbp_mixed_workspace_bytes")
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=fingerprint.device)
         out = torch.empty((B, 1), dtype=torch.float32, device=fingerprint.device)
+        ctx.collective, ctx.errors = None, []
+        if getattr(model, "exact_batch", False):
+            group, world, rank = _exact_batch_group(model)
+            ctx.collective = _make_collective(ws, group, world, rank, ctx.errors,      # kept alive as long as the descriptor is used
+                                              force=getattr(model, "exact_force_collectives", False))
+            desc.collective = ctypes.cast(ctx.collective, ctypes.c_void_p).value
         if not params or any(p.dtype != torch.float32 or p.device != fingerprint.device for p in params):
             raise RuntimeError("the HIP kernels are float32-only: every parameter must be float32 on the inputs' device "
                                f"({fingerprint.device}); undo .half()/.double() or move the model")
@@ -133,8 +192,11 @@ class _MixedFn(torch.autograd.Function):
         if any(b.dtype != torch.float32 or b.device != fingerprint.device for b in (bn.running_mean, bn.running_var)):
             raise RuntimeError("BatchNorm running statistics must be float32 on the inputs' device")
         bnp = _cached_ptrs(model, "_bnp", (bn.running_mean, bn.running_var))
-        _lib.check(L.bbbp_mixed_forward(ops._stream(), ctypes.byref(desc), pp, bnp, fingerprint.data_ptr(), image.data_ptr(),
-                                        out.data_ptr(), ws.data_ptr(), ws_bytes), "bbbp_mixed_forward")
+        rc = L.bbbp_mixed_forward(ops._stream(), ctypes.byref(desc), pp, bnp, fingerprint.data_ptr(), image.data_ptr(),
+                                  out.data_ptr(), ws.data_ptr(), ws_bytes)
+        if rc and ctx.errors:
+            raise RuntimeError("bbbp_mixed_forward: collective failed") from ctx.errors[0]
+        _lib.check(rc, "bbbp_mixed_forward")
         ctx.desc, ctx.ws, ctx.ws_bytes, ctx.pp = desc, ws, ws_bytes, pp
         if getattr(model, "keep_workspace", False):
             _LAST_WS[model] = (desc, ws)
@@ -156,9 +218,11 @@ class _MixedFn(torch.autograd.Function):
         for i, p in enumerate(params):
             gp[i] = base + 4 * off
             off += p.numel()
-        _lib.check(L.bbbp_mixed_backward(ops._stream(), ctypes.byref(ctx.desc), ctx.pp, gp, fingerprint.data_ptr(),
-                                         image.data_ptr(), dout.data_ptr(), ctx.ws.data_ptr(), ctx.ws_bytes),
-                   "bbbp_mixed_backward")
+        rc = L.bbbp_mixed_backward(ops._stream(), ctypes.byref(ctx.desc), ctx.pp, gp, fingerprint.data_ptr(),
+                                   image.data_ptr(), dout.data_ptr(), ctx.ws.data_ptr(), ctx.ws_bytes)
+        if rc and ctx.errors:
+            raise RuntimeError("bbbp_mixed_backward: collective failed") from ctx.errors[0]
+        _lib.check(rc, "bbbp_mixed_backward")
         return (None, None, None, None, *grads)
 
 
@@ -220,9 +284,13 @@ class MixedInputModel(nn.Module):
                 raise RuntimeError("attention dropout must equal the layer dropout")
         training = bool(self.training)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (training and p > 0 and draw_seed) else 0
+        world, rank = 0, 0
+        if getattr(self, "exact_batch", False):
+            _, world, rank = _exact_batch_group(self)
         return _lib.MixedDesc(batch=batch, fingerprint_size=self.fingerprint_size, nhead=self.nhead, num_layers=layers,
                               dim_feedforward=dff, training=int(training), dropout_p=p, seed=seed, need_input_grad=0,
-                              fusion=0 if self.FUSION == "attention" else 1, inference=int(inference and not training))
+                              fusion=0 if self.FUSION == "attention" else 1, inference=int(inference and not training),
+                              world=world, rank=rank)
 
     def debug_ffn_gates(self):
         """Test hook: per encoder layer, the [B, dim_feedforward] uint8 ReLU decisions of ``linear1`` in the most recent

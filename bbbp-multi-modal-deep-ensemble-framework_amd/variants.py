@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from .functional import run_sequential
+from .models import MixedInputModel as _FusedMixedInputModel
 from .models import MultiHeadAttentionFusion, flatten_parameters
 
 
@@ -213,14 +214,32 @@ class WideDeepMixedInputModel(nn.Module):
         return run_sequential(self.fc, self.attention_fusion(fp_out, img_out))
 
 
-class ExactBatchMixedInputModel(nn.Module):
+class ExactBatchMixedInputModel(_FusedMixedInputModel):
     """The flagship ``MixedInputModel`` (Models/multi_input_data_regression_opt_transformer_cnn_20250113.py:68-119, same
     parameters and ``state_dict``) for EXACT-global-batch data parallelism (SURVEY.md 8e mode 2): every rank holds B/N
     molecules, and the two places where the reference's function couples the molecules of a mini-batch are made global --
     the encoder attends over the keys/values of ALL ranks (one all-gather of K|V per layer forward, one reduce-scatter of
     dK|dV backward) and the head's BatchNorm1d uses global batch statistics.  With gradients averaged over ranks
     (``distributed.allreduce_gradients``) an N-rank step equals the single-GPU step at batch B up to rounding.
-    Composed from per-op autograd nodes on the HIP ops (the fused engine covers the replica mode)."""
+    Round 3: runs on the FUSED engine (one C call per direction, three streams, the fused head) -- the engine calls back for its
+    collectives (``bbbp_mixed_desc.collective``, models._make_collective) between the launches that produce and consume them.
+    Attention dropout draws its mask per LOCAL row, so with dropout on an N-rank step is a different (equally valid) sample than the
+    single-process step."""
+
+    def __init__(self, fingerprint_size, image_feature_size, group=None):
+        super().__init__(fingerprint_size, image_feature_size)
+        self.group = group
+        self.exact_batch = True
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["group"] = None                     # process groups do not pickle; a restored model joins the default group
+        return state
+
+
+class PerOpExactBatchMixedInputModel(nn.Module):
+    """The same mode composed from per-op autograd nodes on the HIP ops (rounds 1-2; 2.4x slower than the fused engine at one rank):
+    kept as the independent cross-check of the fused exact-global-batch engine (tests/test_gpu_exact_batch.py)."""
 
     def __init__(self, fingerprint_size, image_feature_size, group=None):
         super().__init__()

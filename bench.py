@@ -447,6 +447,8 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
         kf = kernel_flops[dom]
         achieved = kf / (cand[dom] * 1e-3) / 1e12
         traffic, tsrc = traffic_for(cfg_id, dom)
+        if traffic is not None and BATCH != cfg["batch"]:          # the PMC pass ran the configuration's own batch: not this launch's bytes
+            traffic, tsrc = None, f"PMC pass of config {cfg_id} was collected at batch {cfg['batch']}, this run is at {BATCH} per GPU"
         # The split-bf16 kernels run on the bf16 matrix pipe and execute SIX bf16 MFMA flops per algorithmic (float32) flop: the ceiling
         # of that form is the dense bf16 peak / 6.  `achieved` stays the algorithmic rate of SURVEY.md 8(d); `peak` is the ceiling of the
         # pipe the kernel actually issues to (f32 MFMA peak for the f32 kernels).

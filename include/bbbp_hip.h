@@ -204,6 +204,17 @@ int bbbp_standardize_chunk(void* stream, const uint8_t* fingerprint_u8, const fl
  * config 2, the two-branch MACCS-Linear + image-CNN + concat + BatchNorm-head model.
  * grads[]: same order, written (not accumulated).  bn_running: {running_mean, running_var} of fc.2.
  * The workspace carries the saved activations from forward to backward. */
+/* Collective hook of the exact-global-batch mode.  Called on the HOST while bbbp_mixed_forward / _backward enqueue their work; the
+ * callee must enqueue the collective so that it is ordered after everything enqueued on `stream` so far and before anything enqueued on
+ * it later (e.g. torch.distributed under torch.cuda.stream(ExternalStream(stream))).  Buffers are byte offsets into the call's
+ * workspace; `count` is in floats PER RANK.  Return 0 on success.
+ *   BBBP_COLL_ALLGATHER        recv_off: [world][count] floats, this rank's slot (= send_off) already filled: all-gather in place
+ *   BBBP_COLL_REDUCE_SCATTER   send_off: [world][count] floats; recv_off: [count] floats = sum over ranks of their slot `rank`
+ * `what`: BBBP_COLL_KV / _DKV (layer = encoder layer) or BBBP_COLL_BN_FWD / _BN_BWD (layer = -1). */
+enum { BBBP_COLL_ALLGATHER = 0, BBBP_COLL_REDUCE_SCATTER = 1 };
+enum { BBBP_COLL_KV = 0, BBBP_COLL_DKV = 1, BBBP_COLL_BN_FWD = 2, BBBP_COLL_BN_BWD = 3 };
+typedef int (*bbbp_collective_fn)(void* ctx, int op, int what, int layer, size_t send_off, size_t recv_off, size_t count, void* stream);
+
 typedef struct {
     int batch;            /* B (also the attention sequence length: R:110-111, batch_first=False) */
     int fingerprint_size; /* F = d_model */
@@ -219,6 +230,17 @@ typedef struct {
                              attention_fusion.* entries are then absent from params[] / grads[] */
     int inference;        /* 1: forward only (torch.no_grad()): the workspace omits every backward temporary and the encoder
                              layers share one set of activation buffers; bbbp_mixed_backward refuses such a workspace */
+    /* Exact-global-batch data parallelism (SURVEY 8e mode 2; round 3): `batch` is THIS rank's shard of a mini-batch of world * batch
+     * molecules.  The two places where the reference couples the molecules of a mini-batch are made global through `collective`:
+     * every encoder layer attends over the keys / values of all ranks (the engine packs K | V of its rows into its slot of a
+     * [world][batch][2F] buffer and asks for an in-place all-gather; backward, its queries' share of dK | dV for ALL keys is
+     * reduce-scattered), and the head's BatchNorm1d merges the per-16-row (mean, M2) blocks / backward sums of all ranks (all-gather of
+     * [blocks][2][256] floats).  With gradients averaged over ranks an N-rank step equals the single-GPU step at world * batch.
+     * collective == NULL (and world <= 1): the replica engine, nothing changes. */
+    int world;            /* ranks sharing the mini-batch (0 / 1 with a callback: the same code path with no-op collectives) */
+    int rank;             /* this rank's position: its rows are global rows rank * batch .. */
+    bbbp_collective_fn collective;
+    void* collective_ctx;
 } bbbp_mixed_desc;
 
 int bbbp_mixed_num_params(const bbbp_mixed_desc* d);

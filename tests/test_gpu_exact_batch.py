@@ -69,3 +69,88 @@ def _worker(rank, world, port):
 def test_two_ranks_equal_single_process_full_batch(dev):
     from helpers import run_ranks
     assert run_ranks(_worker, 2, timeout=300) == ["ok", "ok"]
+
+
+def _worker_f167(rank, world, port):
+    """The headline width (one 167-wide head, 6 layers, dff 2048) over 2 ranks x 40 rows (ragged 16-row BatchNorm blocks on every rank),
+    eval-mode dropout, against the single-process replica engine at 80 rows; and the per-op composition of rounds 1-2 against the fused
+    engine on the same shards (two independent implementations of the mode)."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import bbbp_amd
+    from bbbp_amd import distributed as D
+    from bbbp_amd.variants import ExactBatchMixedInputModel, PerOpExactBatchMixedInputModel
+    from helpers import synth_inputs
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    F, B = 167, 80
+    fp, img, y = synth_inputs(123, B, F, 49152)
+    sl = D.shard_batch(B, rank, world)
+    res = {}
+    for name, cls in (("fused", ExactBatchMixedInputModel), ("per_op", PerOpExactBatchMixedInputModel), ("single", bbbp_amd.MixedInputModel)):
+        torch.manual_seed(29)
+        m = cls(F, 128).to(dev)
+        _zero_dropout(m); m.train()
+        rows = slice(0, B) if name == "single" else sl
+        out = m(fp[rows].to(dev), img[rows].to(dev))
+        torch.nn.MSELoss()(out.squeeze(), y[rows].to(dev)).backward()
+        if name != "single":
+            D.allreduce_gradients(m, average=True)
+            out = D.gather_predictions(out.detach().reshape(-1))
+        res[name] = (out.detach().reshape(-1).cpu().double(), {k: p.grad.detach().cpu().double() for k, p in m.named_parameters()},
+                     {k: m.state_dict()[k].cpu().double() for k in ("fc.2.running_mean", "fc.2.running_var")})
+    def close(a, b, what, rtol=2e-4, afrac=1e-4):
+        tol = rtol * b.abs() + afrac * b.abs().max() + 1e-30
+        assert bool(((a - b).abs() <= tol).all()), f"rank {rank} {what}: max err {float((a - b).abs().max()):.3e} scale {float(b.abs().max()):.3e}"
+    for other in ("single", "per_op"):
+        close(res["fused"][0], res[other][0], f"outputs vs {other}")
+        for k in res["fused"][1]:
+            if not k.startswith("attention_fusion."):
+                close(res["fused"][1][k], res[other][1][k], f"{k} vs {other}")
+        for k in res["fused"][2]:
+            close(res["fused"][2][k], res[other][2][k], f"{k} vs {other}", rtol=1e-4)
+    dist.barrier()
+    dist.destroy_process_group()
+    return "ok"
+
+
+def test_two_ranks_headline_width_fused_engine_vs_single_process_and_per_op(dev):
+    from helpers import run_ranks
+    assert run_ranks(_worker_f167, 2, timeout=400) == ["ok", "ok"]
+
+
+@pytest.mark.parametrize("F,B,training", [(167, 37, True), (64, 24, True), (167, 512, True), (167, 100, False)])
+def test_one_rank_exact_engine_equals_the_replica_engine(dev, F, B, training):
+    """No process group: the exact-global-batch engine (callbacks at every layer, gathered K | V buffer, materialised rectangular
+    attention, BatchNorm partials through the rank slot) computes the replica engine's function.  Dropout ON in training: both paths
+    draw the attention mask from the same Philox stream at world size 1 (row = local row)."""
+    import bbbp_amd
+    from bbbp_amd.variants import ExactBatchMixedInputModel
+    from helpers import synth_inputs
+    fp, img, y = synth_inputs(7 + B, B, F, 49152)
+    res = []
+    for cls in (bbbp_amd.MixedInputModel, ExactBatchMixedInputModel):
+        torch.manual_seed(5)
+        m = cls(F, 128).to(dev).train(training)
+        torch.manual_seed(6)
+        if training:
+            out = m(fp.to(dev), img.to(dev))
+            torch.nn.MSELoss()(out.squeeze(), y.to(dev)).backward()
+            grads = {k: p.grad.detach().cpu().double() for k, p in m.named_parameters()}
+        else:
+            with torch.no_grad():
+                out = m(fp.to(dev), img.to(dev))
+            grads = {}
+        res.append((out.detach().cpu().double(), grads, m.state_dict()["fc.2.running_var"].cpu().double()))
+    (o0, g0, v0), (o1, g1, v1) = res
+    assert float((o0 - o1).abs().max()) <= 2e-5 * float(o0.abs().max()) + 1e-7
+    assert float((v0 - v1).abs().max()) <= 1e-6 * float(v0.abs().max())
+    for k in g0:
+        if k.startswith("attention_fusion."):
+            continue
+        err = float((g0[k] - g1[k]).abs().max())
+        if err > 1e-4 * float(g0[k].abs().max()) + 1e-12:           # a ReLU / dropout gate within rounding of zero fell differently
+            rel = float((g0[k] - g1[k]).norm() / g0[k].norm().clamp_min(1e-30))
+            assert rel <= 3e-3 and err <= 5e-2 * float(g0[k].abs().max()), (k, rel, err)

@@ -52,6 +52,21 @@ def _worker(rank, world, port):
     dist.all_reduce(flat)
     D.broadcast_parameters(m, src=0)
     assert D.gather_predictions(torch.arange(4.0, device=dev)).shape == (4,)
+    # the exact-global-batch engine's collectives (in-place all-gather of K | V and of the BatchNorm blocks, reduce-scatter of dK | dV)
+    # through RCCL itself, issued from the engine's callback under its side streams: at world size 1 they are identities, so the step
+    # must equal the same engine's step without the library calls
+    from bbbp_amd.variants import ExactBatchMixedInputModel
+    res = []
+    for force in (False, True):
+        torch.manual_seed(3)
+        m = ExactBatchMixedInputModel(F, 128).to(dev).train()
+        m.exact_force_collectives = force
+        torch.manual_seed(11)
+        o = m(fp, img)
+        bbbp_amd.MSELoss()(o.squeeze(), y).backward()
+        torch.cuda.synchronize()
+        res.append((o.detach().cpu(), torch.cat([p.grad.flatten() for p in m.parameters()]).cpu()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     dist.barrier()
     dist.destroy_process_group()
     return "ok"

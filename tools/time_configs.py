@@ -49,4 +49,5 @@ if os.environ.get("BBBP_TIME_VARIANTS", "1") != "0":
     run_variant("wide/deep (12-layer encoder, 3-stage CNN)", lambda: variants.WideDeepMixedInputModel(167, 128), 256)
     # exact-global-batch mode at world size 1 (no process group: the collectives are identities): what the per-op composition costs
     # against the fused engine on the same arithmetic
-    run_variant("exact-global-batch mode, one rank (per-op autograd)", lambda: variants.ExactBatchMixedInputModel(167, 128), 512)
+    run_variant("exact-global-batch mode, one rank (fused engine, round 3)", lambda: variants.ExactBatchMixedInputModel(167, 128), 512)
+    run_variant("exact-global-batch mode, one rank (per-op autograd, rounds 1-2)", lambda: variants.PerOpExactBatchMixedInputModel(167, 128), 512)
