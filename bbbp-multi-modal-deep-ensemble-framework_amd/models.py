@@ -123,23 +123,53 @@ def _exact_batch_group(model):
     return group, dist.get_world_size(group), dist.get_rank(group)
 
 
-def _make_collective(ws, group, world, rank, errors, force=False):
+class _CollectiveCall:
+    """What one forward / backward pair of the exact-global-batch engine needs in its collective callback."""
+    __slots__ = ("ws", "group", "world", "rank", "errors", "force")
+
+    def __init__(self, group, world, rank, force):
+        self.ws, self.group, self.world, self.rank, self.errors, self.force = None, group, world, rank, [], force
+
+
+_COLLECTIVE_CALLS = {}          # handle (bbbp_mixed_desc.collective_ctx) -> _CollectiveCall; dropped after the backward call
+_COLLECTIVE_NEXT = [1]
+_COLLECTIVE_FN = []             # ONE ctypes thunk for the process: a thunk per call is a reference cycle that keeps its workspace alive until a GC
+
+
+def _collective_register(call):
+    handle = _COLLECTIVE_NEXT[0]
+    _COLLECTIVE_NEXT[0] += 1
+    _COLLECTIVE_CALLS[handle] = call
+    while len(_COLLECTIVE_CALLS) > 16:            # forward calls whose backward never came (evaluation under autograd): oldest first
+        _COLLECTIVE_CALLS.pop(next(iter(_COLLECTIVE_CALLS)))
+    return handle
+
+
+def _collective_fn():
     """bbbp_collective_fn (include/bbbp_hip.h) over torch.distributed: the engine names its buffers as byte offsets into the call's
-    workspace ``ws``; the collective is issued under the engine's stream, so it is ordered after the launches that produced its input
-    and before the ones that read its output.  RCCL ("nccl") takes the tensor forms; gloo (rehearsal: ranks sharing one GPU, CPU-side
+    workspace; the collective is issued under the engine's stream, so it is ordered after the launches that produced its input and
+    before the ones that read its output.  RCCL ("nccl") takes the tensor forms; gloo (rehearsal: ranks sharing one GPU, CPU-side
     transport) has neither an in-place all-gather nor a reduce-scatter, so it gathers into chunks / all-reduces and slices.
-    ``force``: issue the library calls at world size 1 too (tests: the RCCL path on a one-GPU box)."""
+    ``force`` (tests): issue the library calls at world size 1 too (the RCCL path on a one-GPU box)."""
+    if _COLLECTIVE_FN:
+        return _COLLECTIVE_FN[0]
     import torch.distributed as dist
 
-    def f32(off, n):
-        return ws[off:off + 4 * n].view(torch.float32)
-
-    def cb(_ctx, op, what, layer, send_off, recv_off, count, stream):
+    def cb(handle, op, what, layer, send_off, recv_off, count, stream):
+        call = _COLLECTIVE_CALLS.get(handle)
+        if call is None:
+            return 2
         try:
+            ws, group, world, rank = call.ws, call.group, call.world, call.rank
+            real = world > 1 or (call.force and group is not None)
+
+            def f32(off, n):
+                return ws[off:off + 4 * n].view(torch.float32)
+
             st = torch.cuda.ExternalStream(int(stream), device=ws.device) if stream else torch.cuda.default_stream(ws.device)
             with torch.cuda.stream(st):
                 if op == 0:                                   # BBBP_COLL_ALLGATHER, in place
-                    if world > 1 or (force and group is not None):
+                    if real:
                         buf = f32(recv_off, count * world)
                         mine = buf[rank * count:(rank + 1) * count]
                         if dist.get_backend(group) == "gloo":
@@ -148,7 +178,7 @@ def _make_collective(ws, group, world, rank, errors, force=False):
                             dist.all_gather_into_tensor(buf, mine, group=group)
                 elif op == 1:                                 # BBBP_COLL_REDUCE_SCATTER
                     send, recv = f32(send_off, count * world), f32(recv_off, count)
-                    if world == 1 and not (force and group is not None):
+                    if not real:
                         recv.copy_(send)
                     elif dist.get_backend(group) == "gloo":
                         dist.all_reduce(send, group=group)
@@ -159,10 +189,11 @@ def _make_collective(ws, group, world, rank, errors, force=False):
                     raise RuntimeError(f"unknown collective op {op}")
             return 0
         except BaseException as e:        # noqa: BLE001 -- an exception must not unwind through the C frames
-            errors.append(e)
+            call.errors.append(e)
             return 1
 
-    return _lib.CollectiveFn(cb)
+    _COLLECTIVE_FN.append(_lib.CollectiveFn(cb))
+    return _COLLECTIVE_FN[0]
 
 
 class _MixedFn(torch.autograd.Function):
@@ -173,17 +204,20 @@ class _MixedFn(torch.autograd.Function):
         L = _lib.lib()
         B = fingerprint.shape[0]
         desc = model._descriptor(B, inference)
+        ctx.call, ctx.handle = None, 0
+        if getattr(model, "exact_batch", False):
+            group, world, rank = _exact_batch_group(model)
+            ctx.call = _CollectiveCall(group, world, rank, getattr(model, "exact_force_collectives", False))
+            ctx.handle = _collective_register(ctx.call)
+            desc.collective = ctypes.cast(_collective_fn(), ctypes.c_void_p).value
+            desc.collective_ctx = ctx.handle
         ws_bytes = L.bbbp_mixed_workspace_bytes(ctypes.byref(desc))
         if ws_bytes == 0:
             _lib.check(1, "bbbp_mixed_workspace_bytes")
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=fingerprint.device)
+        if ctx.call is not None:
+            ctx.call.ws = ws
         out = torch.empty((B, 1), dtype=torch.float32, device=fingerprint.device)
-        ctx.collective, ctx.errors = None, []
-        if getattr(model, "exact_batch", False):
-            group, world, rank = _exact_batch_group(model)
-            ctx.collective = _make_collective(ws, group, world, rank, ctx.errors,      # kept alive as long as the descriptor is used
-                                              force=getattr(model, "exact_force_collectives", False))
-            desc.collective = ctypes.cast(ctx.collective, ctypes.c_void_p).value
         if not params or any(p.dtype != torch.float32 or p.device != fingerprint.device for p in params):
             raise RuntimeError("the HIP kernels are float32-only: every parameter must be float32 on the inputs' device "
                                f"({fingerprint.device}); undo .half()/.double() or move the model")
@@ -194,8 +228,10 @@ class _MixedFn(torch.autograd.Function):
         bnp = _cached_ptrs(model, "_bnp", (bn.running_mean, bn.running_var))
         rc = L.bbbp_mixed_forward(ops._stream(), ctypes.byref(desc), pp, bnp, fingerprint.data_ptr(), image.data_ptr(),
                                   out.data_ptr(), ws.data_ptr(), ws_bytes)
-        if rc and ctx.errors:
-            raise RuntimeError("bbbp_mixed_forward: collective failed") from ctx.errors[0]
+        if ctx.call is not None and (inference or rc):
+            _COLLECTIVE_CALLS.pop(ctx.handle, None)                  # no backward call will follow
+        if rc and ctx.call is not None and ctx.call.errors:
+            raise RuntimeError("bbbp_mixed_forward: collective failed") from ctx.call.errors[0]
         _lib.check(rc, "bbbp_mixed_forward")
         ctx.desc, ctx.ws, ctx.ws_bytes, ctx.pp = desc, ws, ws_bytes, pp
         if getattr(model, "keep_workspace", False):
@@ -220,8 +256,10 @@ class _MixedFn(torch.autograd.Function):
             off += p.numel()
         rc = L.bbbp_mixed_backward(ops._stream(), ctypes.byref(ctx.desc), ctx.pp, gp, fingerprint.data_ptr(),
                                    image.data_ptr(), dout.data_ptr(), ctx.ws.data_ptr(), ctx.ws_bytes)
-        if rc and ctx.errors:
-            raise RuntimeError("bbbp_mixed_backward: collective failed") from ctx.errors[0]
+        if ctx.call is not None:
+            _COLLECTIVE_CALLS.pop(ctx.handle, None)
+        if rc and ctx.call is not None and ctx.call.errors:
+            raise RuntimeError("bbbp_mixed_backward: collective failed") from ctx.call.errors[0]
         _lib.check(rc, "bbbp_mixed_backward")
         return (None, None, None, None, *grads)
 

@@ -108,7 +108,9 @@ def _worker_f167(rank, world, port):
         close(res["fused"][0], res[other][0], f"outputs vs {other}")
         for k in res["fused"][1]:
             if not k.startswith("attention_fusion."):
-                close(res["fused"][1][k], res[other][1][k], f"{k} vs {other}")
+                # conv weight gradients sum 1e4..1e5 products behind max-pools: different conv forms / slab orders differ by up to a few
+                # 1e-3 of the tensor maximum (tests/test_gpu_model.py: grad_atol); the fused engine meets the single-process step at 1e-4
+                close(res["fused"][1][k], res[other][1][k], f"{k} vs {other}", afrac=1e-2 if k.startswith(("image_cnn.0.", "image_cnn.3.")) else 1e-4)
         for k in res["fused"][2]:
             close(res["fused"][2][k], res[other][2][k], f"{k} vs {other}", rtol=1e-4)
     dist.barrier()

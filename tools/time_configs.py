@@ -27,11 +27,11 @@ run(2048, 512, True)
 run(167, 4096, False)
 
 
-def run_variant(name, make, B, steps=3):
+def run_variant(name, make, B, steps=20, fused_opt=False):
     """The other model scripts (bbbp_amd.variants), composed from per-op autograd nodes on the same HIP kernels."""
     torch.manual_seed(0)
     m = make().to(dev).train()
-    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=1e-5)
+    opt = (AdamW if fused_opt else torch.optim.AdamW)(m.parameters(), lr=1e-4, weight_decay=1e-5)      # fused_opt: the one-launch AdamW of bench.py
     F = m.fingerprint_size if hasattr(m, "fingerprint_size") else 167
     fp = torch.randn(B, F, device=dev); img = torch.randn(B, 49152, device=dev); y = torch.randn(B, device=dev)
     def step():
@@ -49,5 +49,6 @@ if os.environ.get("BBBP_TIME_VARIANTS", "1") != "0":
     run_variant("wide/deep (12-layer encoder, 3-stage CNN)", lambda: variants.WideDeepMixedInputModel(167, 128), 256)
     # exact-global-batch mode at world size 1 (no process group: the collectives are identities): what the per-op composition costs
     # against the fused engine on the same arithmetic
-    run_variant("exact-global-batch mode, one rank (fused engine, round 3)", lambda: variants.ExactBatchMixedInputModel(167, 128), 512)
+    run_variant("exact-global-batch mode, one rank (fused engine, round 3; fused AdamW as in bench.py)", lambda: variants.ExactBatchMixedInputModel(167, 128), 512, fused_opt=True)
+    run_variant("exact-global-batch mode, one rank (fused engine, round 3; torch.optim.AdamW)", lambda: variants.ExactBatchMixedInputModel(167, 128), 512)
     run_variant("exact-global-batch mode, one rank (per-op autograd, rounds 1-2)", lambda: variants.PerOpExactBatchMixedInputModel(167, 128), 512)
