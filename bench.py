@@ -259,6 +259,10 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
     cfg = CONFIGS[cfg_id]
     F, train = cfg["F"], cfg["train"]
     global_batch = args.batch or cfg["batch"]
+    if args.exact_batch:
+        if cfg["model"] != "MixedInputModel" or not train:
+            raise SystemExit("--exact-batch applies to the training configurations of MixedInputModel (3 and 4)")
+        args.scaling = "strong"               # the mode's point: the global batch stays the configuration's
     if args.scaling == "strong":
         if global_batch % world:
             raise SystemExit(f"strong scaling: global batch {global_batch} is not divisible by {world} ranks")
@@ -266,7 +270,11 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
     else:
         BATCH = global_batch
     torch.manual_seed(20250113)           # same initial weights on every rank
-    model = getattr(bbbp_amd, cfg["model"])(F, 128).to(dev).train(train)
+    if args.exact_batch:
+        from bbbp_amd.variants import ExactBatchMixedInputModel
+        model = ExactBatchMixedInputModel(F, 128).to(dev).train(train)
+    else:
+        model = getattr(bbbp_amd, cfg["model"])(F, 128).to(dev).train(train)
     opt = AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5) if train else None
     crit = bbbp_amd.MSELoss()             # nn.MSELoss semantics, value + gradient in one kernel
     params = list(model.parameters())
@@ -383,7 +391,9 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
         elapsed = float(t.item())
     L.bbbp_profile_select(0)
     # outside the timed region: every section with the overlap on (where the step goes) ...
-    if rank == 0:
+    # (rank 0 only -- except in exact-global-batch mode, where every step holds the engine's own collectives and all ranks must take it)
+    all_ranks_step = bool(args.exact_batch) and world > 1
+    if rank == 0 or all_ranks_step:
         L.bbbp_profile_enable(1)
         time_opt[0] = train
         for i in range(5):
@@ -397,7 +407,7 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
                 sections[names[i]] = ms_sum[i] / cnt[i]
     # ... and the same kernels with the branch overlap off, i.e. each kernel alone on the GPU
     isolated, clock = {}, {}
-    if rank == 0 and not args.no_isolated:
+    if (rank == 0 or all_ranks_step) and not args.no_isolated:
         old = L.bbbp_set_overlap(0)
         for i in range(2):
             step(i, collective=False)
@@ -417,7 +427,9 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
             clock = dict(cycles=int(cyc.value), ghz=(cyc.value / (ticks.value * 10.0)) if ticks.value else None)
     if world > 1:
         dist.barrier()
-    comm = comm_report(world, dev, dist, n_coll[0])
+    # exact-global-batch mode: + the engine's own collectives (per encoder layer one all-gather forward and one reduce-scatter backward,
+    # two all-gathers of BatchNorm blocks)
+    comm = comm_report(world, dev, dist, n_coll[0] + ((2 * cfg.get("layers", 6) + 2) if args.exact_batch else 0))
     if rank != 0:
         return None
 
@@ -518,7 +530,9 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["workload"], "baseline_config": cfg_id, "global_batch": BATCH * world, "per_gpu_batch": BATCH,
-                   "parallelism": f"dp{world}", "gflop_per_step_per_gpu": round(total_flops / 1e9, 1),
+                   "parallelism": (f"exact-global-batch x{world} (K|V all-gather + dK|dV reduce-scatter per layer, global BatchNorm)"
+                                   if args.exact_batch else f"dp{world}"),
+                   "gflop_per_step_per_gpu": round(total_flops / 1e9, 1),
                    "input": "host-fed (pinned, double-buffered copy stream)" if args.host_fed else "device-resident"},
         "model_tflops_per_gpu": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
         "roofline": roofline,
@@ -638,6 +652,10 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=(1, 2, 3, 4, 5), help="BASELINE.json configuration (default 3, the headline)")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
     ap.add_argument("--batch", type=int, default=None, help="override the configuration's (global) batch size")
+    ap.add_argument("--exact-batch", action="store_true",
+                    help="exact-global-batch data parallelism (configs 3 / 4): the configuration's GLOBAL batch is sharded over the ranks, every "
+                         "encoder layer attends over all ranks' keys / values and the head's BatchNorm uses global statistics (fused engine with "
+                         "collective callbacks); an N-rank step then equals the single-GPU step at the full batch")
     ap.add_argument("--host-fed", action="store_true", help="feed batches from pinned host memory through the double-buffered loader")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-isolated", action="store_true",
