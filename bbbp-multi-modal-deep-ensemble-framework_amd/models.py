@@ -13,6 +13,7 @@ autograd node per model call (``bbbp_mixed_forward`` / ``bbbp_mixed_backward``).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import weakref
 from typing import List
@@ -166,8 +167,12 @@ def _collective_fn():
             def f32(off, n):
                 return ws[off:off + 4 * n].view(torch.float32)
 
-            st = torch.cuda.ExternalStream(int(stream), device=ws.device) if stream else torch.cuda.default_stream(ws.device)
-            with torch.cuda.stream(st):
+            if ws.is_cuda:
+                scope = torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=ws.device) if stream
+                                          else torch.cuda.default_stream(ws.device))
+            else:                                             # host buffers: the CPU rehearsal of the protocol (tests/test_distributed_cpu.py)
+                scope = contextlib.nullcontext()
+            with scope:
                 if op == 0:                                   # BBBP_COLL_ALLGATHER, in place
                     if real:
                         buf = f32(recv_off, count * world)

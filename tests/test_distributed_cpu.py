@@ -66,6 +66,68 @@ def test_gloo_world2_matches_full_batch(flat):
         torch.testing.assert_close(preds, out.detach(), rtol=1e-6, atol=1e-7)
 
 
+def _exact_protocol_worker(rank, world, port):
+    """The exact-global-batch engine's collective protocol on HOST buffers: the ctypes callback the engine would call
+    (models._collective_fn: byte offsets into the call's workspace, floats per rank) moves K | V and dK | dV between two gloo ranks,
+    the attention arithmetic in between is plain torch.  csrc/engine.hip does exactly these steps around its HIP launches."""
+    import ctypes
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bbbp_amd import distributed as D
+    from bbbp_amd import models
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    D.init("gloo")
+    Bg, F = 10, 6
+    Bl = Bg // world
+    g = torch.Generator().manual_seed(3)
+    q, k, v, dctx = (torch.randn(Bg, F, generator=g) for _ in range(4))
+    sl = D.shard_batch(Bg, rank, world)
+    n = Bl * 2 * F                                        # floats per rank in the K | V exchange
+    off_kvg, off_dkvg, off_dkvl = 64, 64 + 4 * n * world, 64 + 8 * n * world
+    ws = torch.zeros(off_dkvl + 4 * n, dtype=torch.uint8)
+    f32 = lambda off, cnt: ws[off:off + 4 * cnt].view(torch.float32)
+    call = models._CollectiveCall(dist.group.WORLD, world, rank, False)
+    call.ws = ws
+    handle = models._collective_register(call)
+    fn = models._collective_fn()
+    # forward: pack this rank's K | V rows into its slot, all-gather in place
+    f32(off_kvg + 4 * n * rank, n).view(Bl, 2 * F).copy_(torch.cat([k[sl], v[sl]], dim=1))
+    assert fn(handle, 0, 0, 0, off_kvg + 4 * n * rank, off_kvg, n, None) == 0
+    kvg = f32(off_kvg, n * world).view(Bg, 2 * F)
+    assert torch.equal(kvg, torch.cat([k, v], dim=1))
+    # this rank's queries against ALL keys; backward of ctx = softmax(q k^T) v for the local rows
+    scale = F ** -0.5
+    p = torch.softmax(scale * q[sl] @ kvg[:, :F].t(), dim=1)
+    dv_all = p.t() @ dctx[sl]
+    dp = dctx[sl] @ kvg[:, F:].t()
+    ds = p * (dp - (dp * p).sum(dim=1, keepdim=True))
+    dq = scale * ds @ kvg[:, :F]
+    dk_all = scale * ds.t() @ q[sl]
+    f32(off_dkvg, n * world).view(Bg, 2 * F).copy_(torch.cat([dk_all, dv_all], dim=1))
+    assert fn(handle, 1, 1, 0, off_dkvg, off_dkvl, n, None) == 0
+    dkv_local = f32(off_dkvl, n).view(Bl, 2 * F).clone()
+    assert fn(handle + 1000, 0, 0, 0, 0, 0, 1, None) == 2      # unknown handle: refused, nothing touched
+    models._COLLECTIVE_CALLS.pop(handle)
+    dist.barrier()
+    dist.destroy_process_group()
+    return rank, dq, dkv_local
+
+
+def test_exact_batch_collective_protocol_on_gloo_world2():
+    from helpers import run_ranks
+    res = run_ranks(_exact_protocol_worker, 2, timeout=120)
+    Bg, F = 10, 6
+    g = torch.Generator().manual_seed(3)
+    q, k, v, dctx = (torch.randn(Bg, F, generator=g).requires_grad_(True) for _ in range(4))
+    ctx = torch.softmax(F ** -0.5 * q @ k.t(), dim=1) @ v
+    ctx.backward(dctx.detach())
+    for rank, dq, dkv in res:
+        rows = slice(rank * 5, rank * 5 + 5)
+        torch.testing.assert_close(dq, q.grad[rows], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(dkv[:, :F], k.grad[rows], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(dkv[:, F:], v.grad[rows], rtol=1e-5, atol=1e-6)
+
+
 def test_shard_batch_edges():
     from bbbp_amd.distributed import shard_batch
     assert [shard_batch(10, r, 4) for r in range(4)] == [slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 10)]
