@@ -24,7 +24,7 @@ def step(i):
 L = _lib.lib()
 for i in range(30): step(i)
 torch.cuda.synchronize()
-L.bbbp_profile_select(0); L.bbbp_profile_enable(1)
+L.bbbp_profile_select((1 << 11) - 1); L.bbbp_profile_enable(1)      # the eleven top-level sections only: per-layer sections (round 3) add ~200 event pairs per step
 NSTEP = 4
 for i in range(NSTEP): step(i)
 torch.cuda.synchronize()
