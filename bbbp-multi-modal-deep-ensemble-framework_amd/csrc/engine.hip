@@ -229,6 +229,7 @@ SideStream g_side[64];
 // final, i.e. after the first GEMM of the image branch's backward: a data-parallel caller can start reducing that bucket
 // while the remaining ~2 ms of the backward pass run (bbbp_mixed_backward_wait_bucket)
 hipEvent_t g_bucket_event[64];
+hipEvent_t g_bucket0_released[64];      // recorded after the last READ of the image-FC weight in a backward pass
 bool g_bucket_recorded[64];
 // bucket 1: everything except the image-FC weight and the four conv tensors -- final when the fingerprint branch's chain
 // and all weight-gradient leaves are done (~0.25 ms before the image branch's last kernel); recorded on the leaf stream
@@ -975,6 +976,15 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         }
     }
     TRY(linear_bwd_input(c, dcomb + FC, COMB, P[ix.ifc_w()], dpool2, IMG_FLAT, B, FC, IMG_FLAT));
+    {
+        // ... and from here on the image-FC weight itself is no longer read by this pass (bbbp_mixed_backward_wait_released, bucket 0)
+        int dev = 0;
+        BBBP_CHECK_HIP(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64 && g_bucket_recorded[dev]) {
+            if (!g_bucket0_released[dev]) BBBP_CHECK_HIP(hipEventCreateWithFlags(&g_bucket0_released[dev], hipEventDisableTiming));
+            BBBP_CHECK_HIP(hipEventRecord(g_bucket0_released[dev], c.st));
+        }
+    }
     next_section(SEC_CONV2_WGRAD);
     TRY(bbbp_conv3x3_relu_pool_bwd_weight(c.st, pool1, dpool2, c.u8(plan.mask2), G[ix.c2_w()], G[ix.c2_b()], B, C1, C2, IMG / 2,
                                           IMG / 2, c.scratch(), c.scratch_bytes()));
@@ -1254,6 +1264,23 @@ extern "C" int bbbp_mixed_backward_wait_bucket(void* stream, int bucket) {
     BBBP_CHECK_ARG(ev && ok, "wait_bucket: no event for bucket %d on device %d", bucket, dev);
     BBBP_CHECK_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), ev, 0));
     return BBBP_OK;
+}
+
+// Make `stream` wait until the PARAMETERS of gradient bucket `bucket` may be overwritten: its gradient slice is final and this backward
+// pass no longer reads those parameters (an optimizer step pipelined into the pass).  Bucket 0: after the image FC's input-gradient
+// GEMM.  Layer l >= 1 (bucket 2 + l): when layer l - 1's bucket is final -- its leaves read what layer l's last kernel (the in_proj
+// input gradient, the last reader of layer l's weights) wrote, and the leaf stream is in order, so layer l's own leaves are done too.
+// Layer 0 and bucket 1 (everything but the conv tensors): the end of the fingerprint branch and its leaves (bucket 1's event).
+extern "C" int bbbp_mixed_backward_wait_released(void* stream, int bucket) {
+    BBBP_CHECK_ARG(bucket >= 0 && bucket < 2 + 32, "wait_released: unknown bucket %d", bucket);
+    if (bucket == 0) {
+        int dev = 0;
+        BBBP_CHECK_HIP(hipGetDevice(&dev));
+        BBBP_CHECK_ARG(dev >= 0 && dev < 64 && g_bucket_recorded[dev] && g_bucket0_released[dev], "wait_released: no event for bucket 0 on device %d", dev);
+        BBBP_CHECK_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), g_bucket0_released[dev], 0));
+        return BBBP_OK;
+    }
+    return bbbp_mixed_backward_wait_bucket(stream, bucket >= 3 ? bucket - 1 : 1);
 }
 __global__ void positive_gate_kernel(const float* x, uint8_t* gate, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -214,6 +214,64 @@ class OverlappedGradAllReduce:
         return n
 
 
+def _pipelined_step(self, optimizer, params, grad_scale: float = 1.0) -> int:
+    """Gradient all-reduce AND the optimizer step, both pipelined into the backward pass (call right after ``loss.backward()``,
+    instead of ``reducer(params); optimizer.step(grad_scale=...)``).  For every early slice, on the communication stream: wait for
+    the slice's gradients (``bbbp_mixed_backward_wait_bucket``), all-reduce it (``world >= min_world`` only; a single process skips
+    the collectives and keeps the pipelining), wait until the pass no longer READS the slice's parameters
+    (``bbbp_mixed_backward_wait_released``) and apply fused AdamW to exactly that slice of the flat parameter / gradient / moment
+    buffers.  The image-FC weight (62 % of the optimizer's bytes at F = 167) is updated ~1.2 ms before the pass ends, encoder layer
+    l when layer l - 1's leaves are done; only the conv tensors (76 KB) are reduced and updated after the pass.  Element-wise
+    arithmetic: the parameters afterwards are bit-identical to ``optimizer.step()``'s.  Returns the number of collectives issued."""
+    from . import _lib, ops
+    if self._closed:
+        raise RuntimeError("OverlappedGradAllReduce: used after close()")
+    params = list(params)
+    if any(p.grad is None for p in params):
+        raise RuntimeError("OverlappedGradAllReduce.step: every parameter must have a gradient (call it right after backward())")
+    flat = optimizer.begin_flat_step()
+    if flat is None:
+        raise RuntimeError("OverlappedGradAllReduce.step needs bbbp_amd.optim.AdamW over the model's flat parameter buffer "
+                           "(one parameter group, gradients from the fused backward)")
+    pflat, gflat, m, v, step, hp = flat
+    if gflat.numel() != self.total or pflat.numel() != self.total or not gflat.is_cuda:
+        raise RuntimeError("OverlappedGradAllReduce.step: the optimizer's parameters are not this model's")
+    L = _lib.lib()
+    world = world_size(self.group)
+    reduce_ = world >= self.min_world and world > 1
+    if self.comm is None:
+        self.comm = torch.cuda.Stream(device=gflat.device)
+    n = 0
+
+    def update(lo, hi):
+        ops.adamw_step_(pflat[lo:hi], gflat[lo:hi], m[lo:hi], v[lo:hi], step, grad_scale=grad_scale, **hp)
+
+    with torch.cuda.stream(self.comm):
+        cs = self.comm.cuda_stream
+        for bucket, lo, hi in self.early + [(1, lo, hi) for lo, hi in self.rest]:
+            if hi <= lo:
+                continue
+            _lib.check(L.bbbp_mixed_backward_wait_bucket(cs, bucket), "bbbp_mixed_backward_wait_bucket")
+            if reduce_:
+                dist.all_reduce(gflat[lo:hi], group=self.group)          # on the communication stream, in schedule order
+                n += 1
+            _lib.check(L.bbbp_mixed_backward_wait_released(cs, bucket), "bbbp_mixed_backward_wait_released")
+            update(lo, hi)
+    lo, hi = self.late
+    if hi > lo:
+        if reduce_:
+            dist.all_reduce(gflat[lo:hi], group=self.group)              # conv tensors: after the whole pass, on the current stream
+            n += 1
+        update(lo, hi)
+    torch.cuda.current_stream(gflat.device).wait_stream(self.comm)
+    for t in (pflat, gflat, m, v):
+        t.record_stream(self.comm)
+    return n
+
+
+OverlappedGradAllReduce.step = _pipelined_step
+
+
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
     """Make every rank start from rank ``src``'s parameters and buffers (one collective when the parameters are flat)."""
     if world_size(group) == 1:

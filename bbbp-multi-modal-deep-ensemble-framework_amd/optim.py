@@ -67,6 +67,33 @@ class AdamW(torch.optim.Optimizer):
                 st["step"] = int(st["step"])
 
     @torch.no_grad()
+    def begin_flat_step(self):
+        """For a step applied slice by slice (distributed.OverlappedGradAllReduce.step): one parameter group whose parameters, gradients
+        and moments are flat buffers.  Counts the step and returns ``(params, grads, exp_avg, exp_avg_sq, step, hyper-parameters)``
+        -- the caller then runs ``ops.adamw_step_`` on matching slices of the four buffers (element-wise arithmetic: any slicing gives
+        the single launch's bits) -- or None when the layout is not flat (nothing is counted then: call ``step()``)."""
+        if len(self.param_groups) != 1:
+            return None
+        group = self.param_groups[0]
+        all_params = group["params"]
+        if not all_params or any(p.grad is None for p in all_params):
+            return None
+        pflat = flat_view_of(all_params)
+        gflat = flat_view_of([p.grad for p in all_params])
+        if pflat is None or gflat is None:
+            return None
+        if not self._state_is_flat(0, all_params):
+            self._init_group_state(0, list(all_params))
+        steps = {self.state[p]["step"] for p in all_params}
+        if len(steps) != 1:
+            return None
+        for p in all_params:
+            self.state[p]["step"] += 1
+        m, v = self._flat_state[0]
+        hp = dict(lr=group["lr"], betas=group["betas"], eps=group["eps"], weight_decay=group["weight_decay"])
+        return pflat, gflat, m, v, self.state[all_params[0]]["step"], hp
+
+    @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
         """``grad_scale`` multiplies every gradient on the fly (1/world_size after a summing all-reduce)."""
         loss = None

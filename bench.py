@@ -295,9 +295,15 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
         xgb_col = torch.randn(2 * BATCH, generator=g, dtype=torch.float64).to(dev)
     # N > 1: gradient buckets are all-reduced under the rest of the backward pass (distributed.OverlappedGradAllReduce);
     # BBBP_BENCH_PLAIN_ALLREDUCE=1 selects the single collective after the pass
+    # BBBP_BENCH_PIPELINED_STEP=1 (round 3, opt-in): the optimizer step pipelined into the pass as well -- AdamW on each slice as soon as its
+    # gradients are final (N > 1: all-reduced) and its parameters no longer read (OverlappedGradAllReduce.step).  Bit-identical, but measured
+    # SLOWER on one GPU (config 3: 2.83 -> 2.88 ms, config 4: 8.58 -> 9.66 ms: the HBM-bound AdamW slices take from the kernels they run
+    # beside more than the 65 us launch after the pass costs); default: reduce, then one AdamW launch after the pass
     reducer = None
-    if train and world > 1 and os.environ.get("BBBP_BENCH_PLAIN_ALLREDUCE", "0") != "1":
+    pipelined = train and os.environ.get("BBBP_BENCH_PIPELINED_STEP", "0") == "1" and hasattr(model, "_descriptor")
+    if train and (world > 1 or pipelined) and os.environ.get("BBBP_BENCH_PLAIN_ALLREDUCE", "0") != "1":
         reducer = D.OverlappedGradAllReduce(model)
+    pipelined = pipelined and reducer is not None
 
     opt_events = []                       # (start, end) around the optimizer step, only while `time_opt` is set (untimed pass)
     time_opt = [False]
@@ -325,6 +331,10 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
             opt.step(grad_scale=1.0 / world)
             e1.record()
             opt_events.append((e0, e1))
+            opt.zero_grad(set_to_none=True)
+            return loss
+        if pipelined and (collective or world == 1):
+            n_coll[0] = reducer.step(opt, params, grad_scale=1.0 / world)
             opt.zero_grad(set_to_none=True)
             return loss
         if world > 1 and collective:
@@ -543,6 +553,8 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
     if train:
         # the metric's "+ optimizer step reported separately": fused AdamW over the flat parameter buffer (one launch,
         # 16 B read + 12 B written per parameter), included in ms_per_step
+        result["optimizer"] = ("fused AdamW pipelined into the backward pass, slice by slice (distributed.OverlappedGradAllReduce.step)" if pipelined
+                               else "fused AdamW, one launch after the pass")
         result["optimizer_ms_per_step"] = round(sum(a.elapsed_time(b) for a, b in opt_events) / len(opt_events), 4) if opt_events else None
         result["final_loss"] = round(float(last.detach()), 5)
     if world == 1 and not args.no_cpu_baseline:

@@ -354,6 +354,11 @@ int bbbp_set_overlap(int on);   /* two/three-stream branch overlap inside bbbp_m
  * gradient except the four conv tensors: final when the fingerprint branch and all weight-gradient leaves are (the image
  * branch's last kernel is then still running); the conv tensors are final only at the end of the pass. */
 int bbbp_mixed_backward_wait_bucket(void* stream, int bucket);
+/* The same buckets for an OPTIMIZER step pipelined into the pass: `stream` waits until the bucket's gradient slice is final AND the
+ * bucket's parameters are no longer read by the most recent bbbp_mixed_backward (bucket 0: after the image FC's input-gradient GEMM;
+ * encoder layer l >= 1: when layer l - 1's bucket is final; layer 0 and bucket 1: the end of the fingerprint branch).  The four conv
+ * tensors have no bucket: conv2's weight is read by conv2's data gradient, update them after the pass. */
+int bbbp_mixed_backward_wait_released(void* stream, int bucket);
 /* Test hook: the ReLU decisions of encoder layer `layer`'s linear1 (R:75-78; nn.TransformerEncoderLayer.linear1 + ReLU) as
  * the forward pass that filled `workspace` took them -- gate[b * dim_feedforward + j] = 1 where the (post-dropout) hidden
  * activation is > 0.  Parity tests at B = 512 hand these to the float64 oracle: a pre-activation within float32 rounding of
