@@ -564,6 +564,206 @@ __global__ __launch_bounds__(256, 2) void gemm_b3_kernel(GemmParams p) { gemm_b3
 template <int LAYOUT>
 __global__ __launch_bounds__(256, 2) void gemm_b3_probe_kernel(GemmParams p) { gemm_b3_body<LAYOUT, true>(p); }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 64 x 64 tiles of the same split-bf16 form (round 3): products with a deep K whose output has too few 128 x 128 tiles to fill the chip
+// -- the F = 2048 encoder's in_proj at B = 512: 512 x 6144 outputs are 192 tiles of 128 x 128 (one pass on 192 of 256 CUs) -- run here as 768
+// work-groups that each walk the WHOLE K: no slabs, no second launch.  Four waves, each one 32 x 32 accumulator tile (two accumulators: even / odd piece products, so consecutive
+// MFMAs are independent); LDS [operand 2][plane 3][row 64][32 k + 8] bf16 = 30 KB, up to three work-groups per CU.  Per 16-deep k-step a
+// wave issues 6 ds_read_b128 for 6 MFMAs (the 128 x 128 tile: 12 for 24), so this tile is LDS-bound at about two thirds of the matrix
+// pipe -- still ahead of split-K plus reduce for these shapes.  Same loader idiom, pipeline (loads two stages ahead, the split of the next stage
+// under the MFMAs of this one, two barriers per stage), K tail and epilogue as gemm_b3_kernel.
+constexpr int B3S_T = 64;
+#ifndef BBBP_B3S_DEPTH_NT
+#define BBBP_B3S_DEPTH_NT 2
+#endif
+#ifndef BBBP_B3S_DEPTH_NN
+#define BBBP_B3S_DEPTH_NN 2
+#endif
+constexpr int B3S_DEPTH_NT = BBBP_B3S_DEPTH_NT, B3S_DEPTH_NN = BBBP_B3S_DEPTH_NN;
+constexpr int B3S_PLANE = B3S_T * B3_LD;
+constexpr size_t B3S_LDS = (size_t)6 * B3S_PLANE * sizeof(uint16_t);
+
+template <bool KMAJ, int SETS>
+struct B3SLoader {
+    static constexpr int NL = KMAJ ? 4 : 2;      // 16-byte loads per thread and stage (k-major: threads 0..127 only)
+    const float* ptr[NL];
+    const float* X0;
+    long step;
+    int kpos, kend;
+    int soff[NL];
+    bool live;
+    f32x4u raw[SETS][NL];
+    u32x2 pk[NL][3];
+    __device__ __forceinline__ void init(const float* X, int ld, int extent, int row0, int kbeg, int kend_, int t) {
+        const int kq = t & 7, rq = t >> 3;
+        X0 = X; kpos = kbeg + 4 * kq; kend = kend_;
+        if constexpr (KMAJ) {
+            live = rq < 16;                                           // 16 column quads x 8 k quads = 128 threads
+            const int cq = rq & 15;
+            const int col = min(row0 + 4 * cq, extent - 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ptr[j] = X + (long)(kbeg + 4 * kq + j) * ld + col; soff[j] = (4 * cq + j) * B3_LD + 4 * kq; }
+            step = (long)B3_BK * ld;
+        } else {
+            live = true;
+            const int a = rq & 3, b = rq >> 2;
+            const int row = (b >> 2) * 16 + (b & 3) + 4 * a;          // 0..31; the four rows of a half-wave are 4 apart
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ptr[i] = X + (long)min(row0 + row + 32 * i, extent - 1) * ld + kbeg + 4 * kq;
+                soff[i] = (row + 32 * i) * B3_LD + 4 * kq;
+            }
+            step = B3_BK;
+        }
+    }
+    __device__ __forceinline__ void load(int set) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) { raw[set][i] = *reinterpret_cast<const f32x4u*>(ptr[i]); ptr[i] += step; }
+        kpos += B3_BK;
+    }
+    __device__ __forceinline__ void load_tail(int set) {
+        if constexpr (KMAJ) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = kpos + j < kend;
+                const f32x4u v = *reinterpret_cast<const f32x4u*>(ok ? ptr[j] : X0);
+                raw[set][j] = ok ? v : f32x4u{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+            const int nv = kend - kpos;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float* q = nv > 0 ? ptr[i] : X0;
+                f32x4u v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float x = q[e < nv ? e : 0]; v[e] = e < nv ? x : 0.f; }
+                raw[set][i] = v;
+            }
+        }
+        kpos += B3_BK;
+    }
+    __device__ __forceinline__ void split(int set) {
+        if constexpr (KMAJ) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t h0, m0, l0, h1, m1, l1;
+                split2(raw[set][0][i], raw[set][1][i], h0, m0, l0);
+                split2(raw[set][2][i], raw[set][3][i], h1, m1, l1);
+                pk[i][0] = u32x2{h0, h1}; pk[i][1] = u32x2{m0, m1}; pk[i][2] = u32x2{l0, l1};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                uint32_t h0, m0, l0, h1, m1, l1;
+                split2(raw[set][i][0], raw[set][i][1], h0, m0, l0);
+                split2(raw[set][i][2], raw[set][i][3], h1, m1, l1);
+                pk[i][0] = u32x2{h0, h1}; pk[i][1] = u32x2{m0, m1}; pk[i][2] = u32x2{l0, l1};
+            }
+        }
+    }
+    __device__ __forceinline__ void store(uint16_t* dst) const {
+        if (!live) return;
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x2*>(dst + soff[i] + pl * B3S_PLANE) = pk[i][pl];
+    }
+};
+
+// D: stages of global loads in flight (float32 register sets; A/B builds: -DBBBP_B3S_DEPTH_NT=n).  Measured (config 4, B = 512): with ONE work-group
+// per CU (512 x 2048 outputs: 256 tiles) a stage takes ~2200 cycles for 384 cycles of MFMAs -- one wave per SIMD serialises its loads'
+// split, LDS writes, two barriers and LDS reads -- 67 us against 48 for the 128-tile split-K plan + reduce, and 6 stages of loads in
+// flight change nothing (69 us); with THREE per CU (512 x 6144: 768 tiles) the groups cover each other: 114 us against 130.  The plan
+// therefore only takes this tile when it puts at least 2.5 work-groups on every CU.
+template <int LAYOUT, int D>
+__global__ __launch_bounds__(256, (D <= 2 ? 3 : 2)) void gemm_b3s_kernel(GemmParams p) {
+    BBBP_HIGH_PRIO();
+    static_assert(LAYOUT == 0 || LAYOUT == 1, "NT and NN only: the weight gradients (TN) have 256+ tiles of 128 x 128");
+    constexpr bool B_KMAJ = (LAYOUT != 0);
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem16[];
+    uint16_t* As = smem16;
+    uint16_t* Bs = smem16 + 3 * B3S_PLANE;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int batch = blockIdx.z;
+    const int m0 = blockIdx.y * B3S_T, n0 = blockIdx.x * B3S_T;
+    const int nt = (p.K + B3_BK - 1) / B3_BK;
+    const int tail_stage = (p.K % B3_BK) ? nt - 1 : -1;
+
+    B3SLoader<false, D> la;
+    B3SLoader<B_KMAJ, D> lb;
+    la.init(p.A + (long)batch * p.sA, p.lda, p.M, m0, 0, p.K, t);
+    lb.init(p.B + (long)batch * p.sB, p.ldb, p.N, n0, 0, p.K, t);
+    auto load_stage = [&](int stage, int set) __attribute__((always_inline)) {
+        if (stage == tail_stage) { la.load_tail(set); lb.load_tail(set); }
+        else { la.load(set); lb.load(set); }
+    };
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc0[q] = 0.f; acc1[q] = 0.f; }
+    if (nt > 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (d < nt) load_stage(d, d);
+        la.split(0); lb.split(0);
+        la.store(As); lb.store(Bs);
+    }
+    __syncthreads();
+    const uint16_t* afrag = As + (wm * 32 + r) * B3_LD + 8 * h;
+    const uint16_t* bfrag = Bs + (wn * 32 + r) * B3_LD + 8 * h;
+    for (int it = 0; it < nt; it += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int cur = it + u;
+            if (cur >= nt) break;
+            // float32 set u held stage `cur` (split one stage ago): refill it with stage cur + D
+            if (cur + D < nt) load_stage(cur + D, u);
+#pragma unroll
+            for (int kk = 0; kk < B3_BK / 16; ++kk) {
+                bf16x8 a[3], b[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    a[pl] = *reinterpret_cast<const bf16x8*>(afrag + pl * B3S_PLANE + kk * 16);
+                    b[pl] = *reinterpret_cast<const bf16x8*>(bfrag + pl * B3S_PLANE + kk * 16);
+                }
+                // smallest piece products first, alternating accumulators
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc1, 0, 0, 0);
+            }
+            // stage cur + 1 (loaded D - 1 stages ago) -> bf16 pieces, in registers
+            la.split((u + 1) % D); lb.split((u + 1) % D);
+#pragma unroll
+            for (int g = 0; g < 12; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA ...
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);      // ... six VALU instructions of the split under it
+            }
+            __syncthreads();
+            if (cur + 1 < nt) { la.store(As); lb.store(Bs); }
+            __syncthreads();
+        }
+    }
+    float* C = p.C + (long)batch * p.sC;
+    const float* R = p.R ? p.R + (long)batch * p.sR : nullptr;
+    const int n = n0 + wn * 32 + r;
+    const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int m = m0 + wm * 32 + mfma_row(q, lane);
+        if (m < p.M && n < p.N) {
+            float v = apply_act(p.alpha * (acc0[q] + acc1[q]) + bv, p.act);
+            const float gsel = p.gate ? (p.gate[(long)batch * p.sG + (long)m * p.ldg + n] > 0.f ? p.gate_scale : 0.f) : 1.f;
+            if (!p.gate_after) v *= gsel;
+            if (R) v += R[(long)m * p.ldr + n];
+            if (p.gate_after) v *= gsel;
+            C[(long)m * p.ldc + n] = v;
+        }
+    }
+}
+
 // sums the split-K slabs in split order and applies the epilogue
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
     BBBP_HIGH_PRIO();
@@ -1089,6 +1289,15 @@ bool b3_eligible(const GemmParams& p, int layout) {
     const bool b_ok = layout == 0 || (p.N % 4 == 0 && p.N >= 4);
     return a_ok && b_ok;
 }
+// the 64 x 64 split-bf16 tile: the 128-tile grid would leave CUs idle (or split K) while 64-tiles fill the chip, and K is deep enough to
+// amortise the tile's prologue.  BBBP_GEMM_B3_SMALL=0 keeps the 128-tile plans.
+bool b3_small_tile(int M, int N, int K, int batch) {
+    static const int on = [] { const char* e = getenv("BBBP_GEMM_B3_SMALL"); return e ? atoi(e) : 1; }();
+    if (!on || K < 512) return false;
+    const long t128 = (long)cdiv(M, 128) * cdiv(N, 128) * batch, t64 = (long)cdiv(M, 64) * cdiv(N, 64) * batch;
+    const int ncu = bbbp_num_cus();
+    return t128 < ncu && t64 * 2 >= (long)ncu * 5;
+}
 template <int LAYOUT>
 int launch_b3_one(const GemmParams& p, dim3 grid, hipStream_t st) {
     { int rc_ = bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_b3_kernel<LAYOUT>), (size_t)B3_LDS); if (rc_) return rc_; }
@@ -1243,6 +1452,21 @@ int gemm_run(hipStream_t st, const bbbp_gemm_desc& g, void* workspace, size_t wo
     dim3 grid(cdiv(N, tile), cdiv(M, tile), batch * p.splits);
     BBBP_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
     p.arrivals = nullptr;
+    // few 128 x 128 tiles, many 64 x 64 ones, deep K: the small split-bf16 tile walks the whole K in one launch (gemm_b3s_kernel)
+    if (tile == 128 && layout != 2 && b3_eligible(p, layout) && b3_small_tile(M, N, K, batch)) {
+        p.splits = 1; p.kchunk = cdiv(K, B3_BK) * B3_BK; p.slab = nullptr;
+        dim3 gs(cdiv(N, B3S_T), cdiv(M, B3S_T), batch);
+        BBBP_CHECK_ARG(gs.y <= 65535 && gs.z <= 65535, "gemm: grid too large");
+        if (layout == 0) {
+            TRY_RC(bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_b3s_kernel<0, B3S_DEPTH_NT>), B3S_LDS));
+            hipLaunchKernelGGL((gemm_b3s_kernel<0, B3S_DEPTH_NT>), gs, dim3(256), B3S_LDS, st, p);
+        } else {
+            TRY_RC(bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_b3s_kernel<1, B3S_DEPTH_NN>), B3S_LDS));
+            hipLaunchKernelGGL((gemm_b3s_kernel<1, B3S_DEPTH_NN>), gs, dim3(256), B3S_LDS, st, p);
+        }
+        BBBP_CHECK_LAUNCH();
+        return BBBP_OK;
+    }
     if (tile == 128 && b3_eligible(p, layout)) {
         if (p.splits > 1) p.arrivals = arrival_counters(st, (long)grid.x * grid.y * batch);
         TRY_RC(layout == 0 ? launch_b3_one<0>(p, grid, st) : layout == 1 ? launch_b3_one<1>(p, grid, st) : launch_b3_one<2>(p, grid, st));

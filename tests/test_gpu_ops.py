@@ -26,6 +26,9 @@ GEMM_SHAPES = [(512, 501, 167), (512, 167, 167), (512, 2048, 167), (512, 167, 20
                # 128 x 128 tiles on the bf16 pipe with split operands: full tiles, ragged M / N, K not a multiple of the 32-deep stage,
                # split-K over a deep K; (516, 1028, 514): K % 4 != 0 keeps the f32 kernel for the k-contiguous layouts
                (512, 2048, 2048), (500, 2044, 516), (260, 6144, 2048), (2048, 2048, 512), (516, 1028, 514),
+               # 64 x 64 tiles over the whole K (gemm_b3s_kernel: fewer than 256 tiles of 128 x 128 but >= 2.5 tiles of 64 x 64 per CU, K >= 512):
+               # the F = 2048 encoder's in_proj at B = 512, ragged M / N with a 6-element K tail, and one that stays on the 128-tile plan
+               (512, 6144, 2048), (200, 10240, 1030), (512, 2048, 6144),
                # a K that ends in a partial 32-deep stage on the bf16 pipe (B3Loader::load_tail): linear1 / Q K^T of a 4096-row screening
                # batch at the MACCS width (K = 167 = 5 stages + 7), and a tail of exactly one element
                (4096, 2048, 167), (4096, 4096, 167), (1024, 2048, 161),
