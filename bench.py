@@ -21,6 +21,8 @@ os.exec*).  With WORLD_SIZE set (the driver's torch.distributed.run form) the pr
   5  screening: eval-mode forward of (3) at B = 4096 + the shipped linear meta-learner over [nn, rf, xgb] columns
 --scaling weak (default) keeps the per-GPU batch fixed; strong shards the configuration's global batch over the ranks.
 --host-fed feeds every step's batch from pinned host memory through the double-buffered loader (preprocess.HostFedBatches).
+--exact-batch runs configs 3 / 4 in exact-global-batch mode on the fused engine (the configuration's GLOBAL batch sharded over the ranks, K|V
+  all-gather + dK|dV reduce-scatter per encoder layer, BatchNorm on global statistics): an N-rank step equals the single-GPU step.
 
 Prints ONE JSON line on rank 0 (contract in the build prompt) with two extra objects:
   roofline     -- the configuration's dominant kernel, timed with HIP events on its own stream inside the timed region;
