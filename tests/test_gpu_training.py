@@ -206,7 +206,9 @@ def test_out_of_fold_driver_and_stack_against_oracle_folds(dev):
                                    g[f"fold{k}/param_checksum"], rtol=1e-9)
     rng = np.random.default_rng(3)
     orders = [[rng.permutation(len(tr)) for _ in range(EPOCHS)] for tr, _ in folds]
-    rfp = dict(n_estimators=12, max_depth=6, random_state=42)
+    # max_features: scikit-learn's default for a regressor scans all 49 319 columns at every node -- 170 s of CPU for the twenty small fits
+    # of this test; the driver under test passes rf_params through, so a column subsample exercises the same code
+    rfp = dict(n_estimators=12, max_depth=6, random_state=42, max_features=0.02)
     xgb = y.numpy() + 0.3 * rng.normal(size=N)                        # stands in for the absent booster's out-of-fold column
     got = training.cross_validate_oof(fp, img, y, model_factory=lambda: small_model_noseed(F), n_splits=10, epochs=EPOCHS, batch_size=BS,
                                       rf_params=rfp, extra_columns={"xgb": xgb}, init_seed=SEED, device=dev, folds=folds,
