@@ -405,6 +405,17 @@ int head_parts(int nhead, int B) {
     return parts < 1 ? 1 : (parts > 16 ? 16 : parts);
 }
 
+// forward only (the single-sweep backward wants a whole head per work-group): BBBP_ATTN_FWD_WGS = target number of work-groups.  Default 512:
+// at F = 2048 (256 heads) a head's query blocks are split over two groups, and two groups per CU cover each other's exp / Philox / LDS
+// latencies: 135 -> 124 us per layer at B = 512 (256: one group per head, 1024: 138 us)
+int fwd_parts(int nhead, int B) {
+    static const int target = [] { const char* e = getenv("BBBP_ATTN_FWD_WGS"); return e ? atoi(e) : 512; }();
+    int parts = (target > 0 ? target : 512) / (nhead > 0 ? nhead : 1);
+    const int blocks = (B + 15) / 16;
+    if (parts > (blocks + NW - 1) / NW) parts = (blocks + NW - 1) / NW;
+    return parts < 1 ? 1 : (parts > 16 ? 16 : parts);
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------
 // ONE (or a few) WIDE heads: the MACCS width F = 167 is prime, the reference's head rule gives nhead = 1, head_dim = 167 (R:71-73).
 // As separate launches the attention of a layer was QK^T -> softmax(+dropout) -> PV forward and (dV | dPd) -> softmax backward ->
@@ -735,8 +746,8 @@ int bbbp_attn_small_fwd(hipStream_t st, const float* qkv, float* ctx, float* lse
         return BBBP_OK;
     }
     const size_t lds = fwd_lds(B, D);
-    if (D == 8) { int rc = set_dyn_lds(attn_small_fwd_kernel<2>, lds); if (rc) return rc; hipLaunchKernelGGL(attn_small_fwd_kernel<2>, dim3(nhead, head_parts(nhead, B)), dim3(NTH), lds, st, P); }
-    else { int rc = set_dyn_lds(attn_small_fwd_kernel<4>, lds); if (rc) return rc; hipLaunchKernelGGL(attn_small_fwd_kernel<4>, dim3(nhead, head_parts(nhead, B)), dim3(NTH), lds, st, P); }
+    if (D == 8) { int rc = set_dyn_lds(attn_small_fwd_kernel<2>, lds); if (rc) return rc; hipLaunchKernelGGL(attn_small_fwd_kernel<2>, dim3(nhead, fwd_parts(nhead, B)), dim3(NTH), lds, st, P); }
+    else { int rc = set_dyn_lds(attn_small_fwd_kernel<4>, lds); if (rc) return rc; hipLaunchKernelGGL(attn_small_fwd_kernel<4>, dim3(nhead, fwd_parts(nhead, B)), dim3(NTH), lds, st, P); }
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }
