@@ -63,6 +63,7 @@ _SIGNATURES = {
     "bbbp_gemm_f32_grouped": (c_int, [c_void_p, POINTER(GemmDesc), c_int, c_void_p, c_size_t]),
     "bbbp_mixed_backward_wait_bucket": (c_int, [c_void_p, c_int]),
     "bbbp_mixed_backward_wait_released": (c_int, [c_void_p, c_int]),
+    "bbbp_set_release_events": (c_int, [c_int]),
     "bbbp_mixed_bucket_param": (c_int, [POINTER(MixedDesc), c_int]),
     "bbbp_mixed_bucket_range": (c_int, [POINTER(MixedDesc), c_int, POINTER(c_int), POINTER(c_int)]),
     "bbbp_mixed_debug_ffn_gate": (c_int, [c_void_p, POINTER(MixedDesc), c_void_p, c_int, c_void_p]),

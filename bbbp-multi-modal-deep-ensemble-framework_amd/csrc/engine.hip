@@ -229,7 +229,9 @@ SideStream g_side[64];
 // final, i.e. after the first GEMM of the image branch's backward: a data-parallel caller can start reducing that bucket
 // while the remaining ~2 ms of the backward pass run (bbbp_mixed_backward_wait_bucket)
 hipEvent_t g_bucket_event[64];
-hipEvent_t g_bucket0_released[64];      // recorded after the last READ of the image-FC weight in a backward pass
+hipEvent_t g_bucket0_released[64];      // recorded after the last READ of the image-FC weight in a backward pass ...
+bool g_release_events = false;          // ... only on request (bbbp_set_release_events): one more record on the image branch's stream
+bool g_bucket0_released_recorded[64];
 bool g_bucket_recorded[64];
 // bucket 1: everything except the image-FC weight and the four conv tensors -- final when the fingerprint branch's chain
 // and all weight-gradient leaves are done (~0.25 ms before the image branch's last kernel); recorded on the leaf stream
@@ -980,9 +982,12 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         // ... and from here on the image-FC weight itself is no longer read by this pass (bbbp_mixed_backward_wait_released, bucket 0)
         int dev = 0;
         BBBP_CHECK_HIP(hipGetDevice(&dev));
-        if (dev >= 0 && dev < 64 && g_bucket_recorded[dev]) {
+        if (g_release_events && dev >= 0 && dev < 64 && g_bucket_recorded[dev]) {
             if (!g_bucket0_released[dev]) BBBP_CHECK_HIP(hipEventCreateWithFlags(&g_bucket0_released[dev], hipEventDisableTiming));
             BBBP_CHECK_HIP(hipEventRecord(g_bucket0_released[dev], c.st));
+            g_bucket0_released_recorded[dev] = true;
+        } else if (dev >= 0 && dev < 64) {
+            g_bucket0_released_recorded[dev] = false;
         }
     }
     next_section(SEC_CONV2_WGRAD);
@@ -1271,12 +1276,19 @@ extern "C" int bbbp_mixed_backward_wait_bucket(void* stream, int bucket) {
 // GEMM.  Layer l >= 1 (bucket 2 + l): when layer l - 1's bucket is final -- its leaves read what layer l's last kernel (the in_proj
 // input gradient, the last reader of layer l's weights) wrote, and the leaf stream is in order, so layer l's own leaves are done too.
 // Layer 0 and bucket 1 (everything but the conv tensors): the end of the fingerprint branch and its leaves (bucket 1's event).
+extern "C" int bbbp_set_release_events(int on) {
+    const int prev = g_release_events ? 1 : 0;
+    g_release_events = on != 0;
+    return prev;
+}
+
 extern "C" int bbbp_mixed_backward_wait_released(void* stream, int bucket) {
     BBBP_CHECK_ARG(bucket >= 0 && bucket < 2 + 32, "wait_released: unknown bucket %d", bucket);
     if (bucket == 0) {
         int dev = 0;
         BBBP_CHECK_HIP(hipGetDevice(&dev));
-        BBBP_CHECK_ARG(dev >= 0 && dev < 64 && g_bucket_recorded[dev] && g_bucket0_released[dev], "wait_released: no event for bucket 0 on device %d", dev);
+        BBBP_CHECK_ARG(dev >= 0 && dev < 64 && g_bucket_recorded[dev] && g_bucket0_released[dev] && g_bucket0_released_recorded[dev],
+                       "wait_released: no event for bucket 0 on device %d (bbbp_set_release_events(1) before the backward pass)", dev);
         BBBP_CHECK_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), g_bucket0_released[dev], 0));
         return BBBP_OK;
     }

@@ -112,13 +112,17 @@ class OverlappedGradAllReduce:
     missing event or an unexpected gradient layout raises.  HIP-graph replay of the engine calls is switched off while a reducer
     exists (a replayed backward records no bucket events, and ranks could capture on different steps)."""
 
-    def __init__(self, model, group=None, min_world: int = 2):
+    def __init__(self, model, group=None, min_world: int = 2, pipelined_step: bool = False):
+        """``pipelined_step``: also allow ``step(optimizer, params)`` (the optimizer pipelined into the pass): the engine then records
+        one more event per backward pass (the release point of the image-FC weight)."""
         import ctypes
         from . import _lib
         self.model, self.group, self.min_world = model, group, int(min_world)
         self.comm = None
         L = _lib.lib()
         self._graphs_before = L.bbbp_set_graphs(0)        # restored by close(): graph replay is off only while a reducer exists
+        self.pipelined_step = bool(pipelined_step)
+        self._release_before = L.bbbp_set_release_events(1) if self.pipelined_step else None
         self._closed = False
         params = list(model.parameters())
         offs, o = [], 0
@@ -159,6 +163,8 @@ class OverlappedGradAllReduce:
             try:
                 from . import _lib
                 _lib.lib().bbbp_set_graphs(self._graphs_before)
+                if self._release_before is not None:
+                    _lib.lib().bbbp_set_release_events(self._release_before)
             except Exception:      # noqa: BLE001  (interpreter shutdown)
                 pass
 
@@ -226,6 +232,8 @@ def _pipelined_step(self, optimizer, params, grad_scale: float = 1.0) -> int:
     from . import _lib, ops
     if self._closed:
         raise RuntimeError("OverlappedGradAllReduce: used after close()")
+    if not self.pipelined_step:
+        raise RuntimeError("OverlappedGradAllReduce.step needs OverlappedGradAllReduce(model, pipelined_step=True)")
     params = list(params)
     if any(p.grad is None for p in params):
         raise RuntimeError("OverlappedGradAllReduce.step: every parameter must have a gradient (call it right after backward())")

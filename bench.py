@@ -304,7 +304,7 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
     reducer = None
     pipelined = train and os.environ.get("BBBP_BENCH_PIPELINED_STEP", "0") == "1" and hasattr(model, "_descriptor")
     if train and (world > 1 or pipelined) and os.environ.get("BBBP_BENCH_PLAIN_ALLREDUCE", "0") != "1":
-        reducer = D.OverlappedGradAllReduce(model)
+        reducer = D.OverlappedGradAllReduce(model, pipelined_step=pipelined)
     pipelined = pipelined and reducer is not None
 
     opt_events = []                       # (start, end) around the optimizer step, only while `time_opt` is set (untimed pass)

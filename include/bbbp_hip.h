@@ -359,6 +359,9 @@ int bbbp_mixed_backward_wait_bucket(void* stream, int bucket);
  * encoder layer l >= 1: when layer l - 1's bucket is final; layer 0 and bucket 1: the end of the fingerprint branch).  The four conv
  * tensors have no bucket: conv2's weight is read by conv2's data gradient, update them after the pass. */
 int bbbp_mixed_backward_wait_released(void* stream, int bucket);
+/* Bucket 0's release point needs one more event on the image branch's stream: recorded only while this is on (default off).  Returns the
+ * previous setting. */
+int bbbp_set_release_events(int on);
 /* Test hook: the ReLU decisions of encoder layer `layer`'s linear1 (R:75-78; nn.TransformerEncoderLayer.linear1 + ReLU) as
  * the forward pass that filled `workspace` took them -- gate[b * dim_feedforward + j] = 1 where the (post-dropout) hidden
  * activation is > 0.  Parity tests at B = 512 hand these to the float64 oracle: a pre-activation within float32 rounding of

@@ -74,7 +74,7 @@ def _train(dev, pipelined, world_reduce, steps=4, F=167, B=24, rank=0):
     m = bbbp_amd.MixedInputModel(F, 128).to(dev).train()
     params = list(m.parameters())
     opt = AdamW(params, lr=1e-3, weight_decay=1e-5)
-    reducer = D.OverlappedGradAllReduce(m) if (pipelined or world_reduce) else None
+    reducer = D.OverlappedGradAllReduce(m, pipelined_step=pipelined) if (pipelined or world_reduce) else None
     world = D.world_size()
     torch.manual_seed(11)
     for i in range(steps):
