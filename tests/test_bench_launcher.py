@@ -43,3 +43,5 @@ def test_launcher_command_is_the_contract_form():
     cmd = bench.launcher_command(4, ["--gpus", "4", "--steps", "5"], port=29511)
     assert cmd[1:9] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1", "--master-port", "29511"]
     assert cmd[9].endswith("bench.py") and cmd[10:] == ["--gpus", "4", "--steps", "5"]
+    # every other option reaches the ranks untouched (the exact-global-batch mode shards the global batch over them)
+    assert bench.launcher_command(2, ["--gpus", "2", "--exact-batch", "--config", "4"], port=1)[10:] == ["--gpus", "2", "--exact-batch", "--config", "4"]
