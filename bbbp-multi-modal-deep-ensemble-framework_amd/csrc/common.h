@@ -53,6 +53,10 @@ extern thread_local size_t g_bbbp_small_lds_pad;
 // at B = 512) but holds 2 x 248 registers per lane slot on every SIMD, and the forward pass of that step is bound by the encoder's
 // latency chain, which then finds no wave slots (measured: conv1 0.31 -> 0.20 ms in-step, encoder forward 1.21 -> 1.33, step 2.61 -> 2.70)
 extern thread_local int g_bbbp_conv1_fwd_f32;
+// conv2's weight gradient on the structured-sparse MFMA (conv_b3.hip: conv_b3_wgrad_sp_kernel) has an 8-wave form (fastest alone: two waves
+// of 256 registers per SIMD) and a 4-wave form that leaves ~200 registers per lane slot to the fingerprint branch's kernels; the engine
+// asks for the latter while an encoder chain runs beside the image branch (0 = no preference: 8 waves)
+extern thread_local int g_bbbp_conv_wgrad_beside_encoder;
 extern thread_local int g_bbbp_wino_side_cus;      // CUs the Winograd conv grids leave free while the engine overlaps its branches
 // head.hip: fused fusion-block + regression-head forward (two launches); `partial`: ceil(B/16) * 2 * 256 floats
 int bbbp_head_forward_fused(hipStream_t st, const float* comb, const float* const* fw1, const float* const* fb1,
@@ -107,7 +111,8 @@ int bbbp_wino_last_clock(unsigned long long* shader_cycles, unsigned long long* 
 size_t bbbp_b3_workspace_bytes();
 int bbbp_b3_conv2_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* y, uint8_t* mask, int B, void* workspace);
 int bbbp_b3_conv2_dgrad(hipStream_t st, const float* gy, const uint8_t* gmask, const float* w, float* dx, int B, void* workspace);
-int bbbp_b3_conv2_wgrad(hipStream_t st, const float* x, const float* gy, const uint8_t* mask, float* slab, float* bslab, int B, int grid);
+// form: 0 dense split-bf16, 1 structured-sparse MFMA (8 waves, or 4 beside an encoder chain), 2 structured-sparse, 4 waves
+int bbbp_b3_conv2_wgrad(hipStream_t st, const float* x, const float* gy, const uint8_t* mask, float* slab, float* bslab, int B, int grid, int form);
 int bbbp_b3_last_clock(unsigned long long* shader_cycles, unsigned long long* ticks_100mhz);
 // conv_b3c1.hip: forward of the first stage (3 -> 32 @ 128x128) in the same arithmetic, channel-innermost LDS strip, no operand assembly
 size_t bbbp_b3_conv1_fwd_workspace_bytes();

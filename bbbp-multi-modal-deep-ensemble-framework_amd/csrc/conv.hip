@@ -801,14 +801,16 @@ inline int winograd_mask() {
     // the training step 0.47 / 0.42 vs 0.57 / 0.61 ms: 66 KB of LDS and 160 registers per wave leave room for the other branch's
     // kernels on every CU (the Winograd work-groups take whole CUs and give 64 of them up), and a bf16 MFMA holds the vector issue
     // for 8 of its 32 cycles where the f32 MFMA blocks it for all 64
-    if (g_winograd < 0) { const char* e = getenv("BBBP_CONV_WINOGRAD"); g_winograd = e ? atoi(e) & 127 : 124; }
+    // round 3: + bit 7, conv2's weight gradient on the 2:4 structured-sparse MFMA (conv_b3.hip: conv_b3_wgrad_sp_kernel; 0.54 -> 0.33 ms in
+    // the step); bit 8 (test hook) forces its 4-wave form
+    if (g_winograd < 0) { const char* e = getenv("BBBP_CONV_WINOGRAD"); g_winograd = e ? atoi(e) & 511 : 252; }
     return g_winograd;
 }
 
 }  // namespace
 
 extern "C" int bbbp_set_conv_winograd(int mask) {
-    BBBP_CHECK_ARG(mask >= 0 && mask <= 127, "set_conv_winograd: mask %d (bits 0/1 Winograd forward / data gradient, bits 2/3/4 split-bf16 forward / data gradient / weight gradient of conv2, bits 5/6 split-bf16 weight gradient / forward of conv1)", mask);
+    BBBP_CHECK_ARG(mask >= 0 && mask <= 511, "set_conv_winograd: mask %d (bits 0/1 Winograd forward / data gradient, bits 2/3/4 split-bf16 forward / data gradient / weight gradient of conv2, bits 5/6 split-bf16 weight gradient / forward of conv1, bit 7 conv2's split-bf16 weight gradient on the structured-sparse MFMA, bit 8 its 4-wave form)", mask);
     g_winograd = mask;
     return BBBP_OK;
 }
@@ -970,7 +972,8 @@ extern "C" int bbbp_conv3x3_relu_pool_bwd_weight(void* stream, const float* x, c
         p.groups = groups;
         p.bslab = slab + (size_t)grid * 64 * 288;
         int rc;
-        if (cin == 32 && cout == 64 && (winograd_mask() & 16)) rc = bbbp_b3_conv2_wgrad(st, x, gy, mask, slab, p.bslab, B, grid);
+        if (cin == 32 && cout == 64 && (winograd_mask() & 16))
+            rc = bbbp_b3_conv2_wgrad(st, x, gy, mask, slab, p.bslab, B, grid, (winograd_mask() & 128) ? ((winograd_mask() & 256) ? 2 : 1) : 0);
         else rc = cin == 32 ? launch_wgrad32<64, 32, 64>(p, grid, st)
                : cin == 64 ? launch_wgrad32<64, 64, 128>(p, grid, st) : launch_wgrad32<32, 128, 256>(p, grid, st);
         if (rc) return rc;

@@ -482,6 +482,217 @@ __global__ __launch_bounds__(256) void conv_b3_wgrad_kernel(B3WgradParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// The same weight gradient on the 2:4 STRUCTURED-SPARSE matrix instruction (round 3; conv-form bit 7, part of the default mask 252; without
+// it the dense kernel above runs).  The A operand -- the pooled gradient expanded through the arg-max mask -- is sparse by construction: a 2 x 2 pooling window
+// passes its gradient to ONE of its four pixels, so along a full-resolution row every pair of adjacent pixels holds at most one nonzero,
+// i.e. at most two in any aligned group of four: exactly the pattern v_smfmac_f32_32x32x32_bf16 wants.  Its compressed A operand (the
+// two kept values of every group + a 2-bit position each) IS the pooled gradient: value = g[pooled px] if the window's maximum sits in
+// this row, else 0; position = (pooled px & 1) * 2 + (mask & 1).  Nothing is expanded: the operand is a quarter of the dense one in LDS
+// and in LDS reads, and one instruction contracts 32 pixels for the cost of 16 -- half the matrix-pipe time for the same products (the
+// six split-bf16 piece products per float32 product are kept: float32 accuracy, exact zeros skipped).
+// Operand layout of the instruction, measured (tools/micro/smfmac_probe.hip; profiles/r03_smfmac_probe.txt): lane (row i = l & 31,
+// kb = l >> 5) of A holds 8 compressed elements; elements (0,1) and (2,3) pair with B rows (pixels) 8 kb + 0..3 and 8 kb + 4..7 as held by
+// the B lanes of wave half 0, elements (4,5) / (6,7) with the same positions of wave half 1; a B lane (column j, half h) holds 16
+// consecutive k; the 2-bit positions sit at bits [2 e + 1 : 2 e] of the index register's low half (ABID = 0).  With B half h holding
+// pixels x0 + 16 h .. + 15, A lane (co, kb) therefore holds pooled pixels P0 + 4 kb .. + 3 and P0 + 8 + 4 kb .. + 3 (P0 = x0 / 2): two
+// quads of four, stored adjacent in LDS (one ds_read_b128 per plane).
+// Work-group: NW waves = (m-tile 2) x (k-group NW / 2); a stage (one pooled row, as before) is four k-blocks of 32 pixels (upper / lower
+// row x left / right half).  NW = 8: one k-block per wave, two waves per SIMD -- fastest alone (0.236 ms at B = 512 against 0.405 dense), but
+// its 2 x 256 registers per SIMD lane leave nothing for the fingerprint branch's kernels beside it (whole step 2.59 -> 2.67 ms).  NW = 4
+// (what the engine asks for while an encoder chain runs beside the image branch, common.h: g_bbbp_conv_wgrad_beside_encoder;
+// BBBP_C2_WGRAD_SPARSE_WAVES overrides): two k-blocks per wave, one wave of 297 registers per SIMD: 0.26 ms alone, 0.33 in the step
+// (dense: 0.39 / 0.54), whole step 2.59 -> 2.52 ms; the two-branch model without an encoder takes the 8-wave form (1.126 -> 1.046 ms).
+constexpr int ASP_CO = 32 + 8;                  // pooled pixels of one output channel and row (+ 16 B: bank spread), quads in slot order
+constexpr int ASP_PLANE = 64 * ASP_CO;
+constexpr int ASP_RR = 3 * ASP_PLANE;
+constexpr size_t WGS_LDS_BYTES = (size_t)(3 * WXPLANE + 2 * ASP_RR) * 2 + 64 * 8;
+typedef __bf16 bf16x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void conv_b3_wgrad_sp_kernel(B3WgradParams p) {
+    constexpr int NTH = 64 * NW, NA = 512 / NTH, NX = 1024 / NTH, NKB = 8 / NW;          // items per thread, k-blocks per wave
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    uint16_t* XsW = smem;                        // [plane][ci][row 4][XROW]
+    uint16_t* Asp = smem + 3 * WXPLANE;          // [row of the window 2][plane][co][slot 8][4 pooled px]
+    uint8_t* Aidx = reinterpret_cast<uint8_t*>(smem + 3 * WXPLANE + 2 * ASP_RR);      // [co][slot 8]: four 2-bit positions per quad
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    const int mt = wave & 1, kq = wave >> 1;                 // k-group: NW = 8: one k-block (row kq >> 1, half kq & 1); NW = 4: row kq, both halves
+    const int rr = NW == 8 ? kq >> 1 : kq;
+    const int nstrips = p.B * (IMG / 2);
+    for (int i = t * 8; i < 3 * WXPLANE + 2 * ASP_RR + 64 * 4; i += NTH * 8) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0, 0, 0, 0};
+
+    // ---- loader: NA dY items (co, quad of 4 pooled px) and NX X items (ci, row, 8 px) per thread ----
+    f32x4 gq[NA]; uint32_t mq[NA]; f32x4 xq[NX][2];
+    float bsum[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) bsum[i] = 0.f;
+    uint32_t okx = 0;
+    auto load_stage = [&](int strip) __attribute__((always_inline)) {
+        const int b = strip / (IMG / 2), ph = strip % (IMG / 2);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = t + i * NTH, a_q = idx & 7, a_co = idx >> 3;
+            const long off = (((long)b * 64 + a_co) * (IMG / 2) + ph) * (IMG / 2) + a_q * 4;
+            gq[i] = *reinterpret_cast<const f32x4*>(p.gy + off);
+            mq[i] = *reinterpret_cast<const uint32_t*>(p.mask + off);
+        }
+        okx = 0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = t + i * NTH, q = idx & 7, row = (idx >> 3) & 3, ci = idx >> 5;
+            const int yr = 2 * ph - 1 + row;
+            okx |= (yr >= 0 && yr < IMG ? 1u : 0u) << i;
+            const float* src = p.x + (((long)b * 32 + ci) * IMG + min(max(yr, 0), IMG - 1)) * IMG + q * 8;
+            xq[i][0] = *reinterpret_cast<const f32x4*>(src);
+            xq[i][1] = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+    };
+    auto store_stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = t + i * NTH, a_q = idx & 7, a_co = idx >> 3;
+            const int a_slot = (a_q >> 2) * 4 + (a_q & 1) * 2 + ((a_q >> 1) & 1);       // quads q and q + 2 of a 16-pixel half end up adjacent
+            uint32_t pc[2][3];
+            split2(gq[i][0], gq[i][1], pc[0][0], pc[0][1], pc[0][2]);
+            split2(gq[i][2], gq[i][3], pc[1][0], pc[1][1], pc[1][2]);
+            uint32_t m[4], pos = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                m[e] = (mq[i] >> (8 * e)) & 0xffu;
+                bsum[i] += m[e] < 4u ? gq[i][e] : 0.f;
+                pos |= (((uint32_t)(e & 1) << 1) | (m[e] & 1u)) << (2 * e);        // even element: 0 / 1, odd element: 2 / 3 of its group of four
+            }
+            Aidx[a_co * 8 + a_slot] = (uint8_t)pos;
+#pragma unroll
+            for (int row = 0; row < 2; ++row) {
+                // keep a pooled pixel's pieces only in the row its maximum came from (mask 4 = ReLU inactive: in neither)
+                const uint32_t k01 = ((m[0] >> 1) == (uint32_t)row ? 0xffffu : 0u) | ((m[1] >> 1) == (uint32_t)row ? 0xffff0000u : 0u);
+                const uint32_t k23 = ((m[2] >> 1) == (uint32_t)row ? 0xffffu : 0u) | ((m[3] >> 1) == (uint32_t)row ? 0xffff0000u : 0u);
+                uint16_t* d = Asp + row * ASP_RR + a_co * ASP_CO + a_slot * 4;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x2*>(d + pl * ASP_PLANE) = u32x2{pc[0][pl] & k01, pc[1][pl] & k23};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = t + i * NTH, q = idx & 7, row = (idx >> 3) & 3, ci = idx >> 5;
+            const bool ok = (okx >> i) & 1u;
+            uint32_t hi[4], mid[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = j < 2 ? xq[i][0][2 * j] : xq[i][1][2 * j - 4], c = j < 2 ? xq[i][0][2 * j + 1] : xq[i][1][2 * j - 3];
+                split2(ok ? a : 0.f, ok ? c : 0.f, hi[j], mid[j], lo[j]);
+            }
+            uint16_t* d = XsW + ci * XCI + row * XROW + 8 + q * 8;
+            *reinterpret_cast<u32x4*>(d) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<u32x4*>(d + WXPLANE) = u32x4{mid[0], mid[1], mid[2], mid[3]};
+            *reinterpret_cast<u32x4*>(d + 2 * WXPLANE) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+
+    int strip = xcd_adjacent(blockIdx.x, gridDim.x);
+    __syncthreads();
+    if (strip < nstrips) { load_stage(strip); store_stage(); }
+    const int co = mt * 32 + r;
+    for (; strip < nstrips; strip += gridDim.x) {
+        const int nstrip = strip + gridDim.x;
+        __syncthreads();                                     // this stage's LDS image is complete
+        if (nstrip < nstrips) load_stage(nstrip);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+        const int xb = NW == 8 ? (kq & 1) : kb;
+        const uint16_t* abase = Asp + rr * ASP_RR + co * ASP_CO + (4 * xb + 2 * h) * 4;
+        const uint16_t* bbase = XsW + r * XCI + 8 + 32 * xb + 16 * h;
+        bf16x8 a[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(abase + pl * ASP_PLANE);
+        const int idx = *reinterpret_cast<const uint16_t*>(Aidx + co * 8 + 4 * xb + 2 * h);
+#pragma unroll
+        for (int dyi = 0; dyi < 3; ++dyi) {
+            // 16 pixels of input channel r in row rr + dyi, three bf16 planes: words w[0..7] + the two neighbouring words
+            u32x8 w[3]; uint32_t wm[3], wp[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const uint16_t* src = bbase + pl * WXPLANE + (rr + dyi) * XROW;
+                const u32x4 w0 = *reinterpret_cast<const u32x4*>(src), w1 = *reinterpret_cast<const u32x4*>(src + 8);
+                w[pl] = u32x8{w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+                wm[pl] = *reinterpret_cast<const uint32_t*>(src - 2);
+                wp[pl] = *reinterpret_cast<const uint32_t*>(src + 16);
+            }
+#pragma unroll
+            for (int dxi = 0; dxi < 3; ++dxi) {
+                bf16x16 bf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    u32x8 f;
+                    if (dxi == 1) f = w[pl];
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            // dx = -1: pixels x - 1 ..: (previous word's high half, this word's low half); dx = +1: (this high, next low)
+                            const uint32_t lo_w = dxi == 0 ? (j == 0 ? wm[pl] : w[pl][j - 1]) : w[pl][j];
+                            const uint32_t hi_w = dxi == 0 ? w[pl][j] : (j == 7 ? wp[pl] : w[pl][j + 1]);
+                            f[j] = __builtin_amdgcn_alignbit(hi_w, lo_w, 16);
+                        }
+                    }
+                    bf[pl] = __builtin_bit_cast(bf16x16, f);
+                }
+                const int tap = dyi * 3 + dxi;
+                acc[tap] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(a[1], bf[1], acc[tap], idx, 0, 0);
+                acc[tap] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(a[2], bf[0], acc[tap], idx, 0, 0);
+                acc[tap] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(a[0], bf[2], acc[tap], idx, 0, 0);
+                acc[tap] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(a[1], bf[0], acc[tap], idx, 0, 0);
+                acc[tap] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(a[0], bf[1], acc[tap], idx, 0, 0);
+                acc[tap] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(a[0], bf[0], acc[tap], idx, 0, 0);
+            }
+        }
+        }
+        __syncthreads();                                     // every wave is done reading this stage
+        if (nstrip < nstrips) store_stage();
+    }
+    __syncthreads();
+    // ---- the k-groups through LDS (the staging buffers are free now), tap by tap, in k-group order; k-group 0 adds and keeps ----
+    float* red = reinterpret_cast<float*>(smem);             // [mt 2][16][64] floats per pass
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        for (int g = 1; g < NW / 2; ++g) {
+            if (kq == g) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) red[(mt * 16 + q) * 64 + lane] = acc[tap][q];
+            }
+            __syncthreads();
+            if (kq == 0) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[tap][q] += red[(mt * 16 + q) * 64 + lane];
+            }
+            __syncthreads();
+        }
+    }
+    if (kq == 0) {
+        float* sdst = p.slab + (long)blockIdx.x * 64 * 288;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sdst[(mt * 32 + mfma_row(q, lane)) * 288 + tap * 32 + r] = acc[tap][q];
+    }
+    // bias-gradient partials: the 8 threads of one channel (consecutive lanes) reduce by shuffles
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        float v = bsum[i];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+        const int idx = t + i * NTH;
+        if ((idx & 7) == 0) p.bslab[(long)blockIdx.x * 64 + (idx >> 3)] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // Weight gradient of the FIRST conv stage (3 -> 32 channels on 128x128 images, R:85-87): M = co (32), N = (ci, kh, kw) = 27 of 32
 // columns, K = pixels.  435 MB of compulsory traffic against 14.5 GFLOP: the kernel is HBM-bound (~0.09 ms), what the split-bf16 form
 // buys here is not matrix rate but (i) a bf16 MFMA stream that leaves the vector ALU to the loader and to the other branch's kernels
@@ -702,9 +913,24 @@ extern "C" int bbbp_conv_b3_phases(unsigned long long* phases4) {
 }
 
 // grid work-groups, each writes slab[g][64][288] and bslab[g][64] (conv.hip: conv_wgrad32_reduce_kernel finishes)
-int bbbp_b3_conv2_wgrad(hipStream_t st, const float* x, const float* gy, const uint8_t* mask, float* slab, float* bslab, int B, int grid) {
-    { int rc_ = bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(conv_b3_wgrad_kernel), (size_t)WG_LDS_BYTES); if (rc_) return rc_; }
+int bbbp_b3_conv2_wgrad(hipStream_t st, const float* x, const float* gy, const uint8_t* mask, float* slab, float* bslab, int B, int grid, int form) {
     B3WgradParams p{x, gy, mask, slab, bslab, B};
+    const bool sparse = form != 0;
+    static const int waves_env = [] { const char* e = getenv("BBBP_C2_WGRAD_SPARSE_WAVES"); return e ? atoi(e) : 0; }();
+    const int waves = waves_env ? waves_env : ((form == 2 || g_bbbp_conv_wgrad_beside_encoder) ? 4 : 8);
+    if (sparse && waves == 8) {
+        { int rc_ = bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(conv_b3_wgrad_sp_kernel<8>), WGS_LDS_BYTES); if (rc_) return rc_; }
+        hipLaunchKernelGGL(conv_b3_wgrad_sp_kernel<8>, dim3(grid), dim3(512), WGS_LDS_BYTES, st, p);
+        BBBP_CHECK_LAUNCH();
+        return BBBP_OK;
+    }
+    if (sparse) {
+        { int rc_ = bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(conv_b3_wgrad_sp_kernel<4>), WGS_LDS_BYTES); if (rc_) return rc_; }
+        hipLaunchKernelGGL(conv_b3_wgrad_sp_kernel<4>, dim3(grid), dim3(256), WGS_LDS_BYTES, st, p);
+        BBBP_CHECK_LAUNCH();
+        return BBBP_OK;
+    }
+    { int rc_ = bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(conv_b3_wgrad_kernel), (size_t)WG_LDS_BYTES); if (rc_) return rc_; }
     hipLaunchKernelGGL(conv_b3_wgrad_kernel, dim3(grid), dim3(256), WG_LDS_BYTES, st, p);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;

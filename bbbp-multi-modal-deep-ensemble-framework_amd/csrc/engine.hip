@@ -991,8 +991,15 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         }
     }
     next_section(SEC_CONV2_WGRAD);
-    TRY(bbbp_conv3x3_relu_pool_bwd_weight(c.st, pool1, dpool2, c.u8(plan.mask2), G[ix.c2_w()], G[ix.c2_b()], B, C1, C2, IMG / 2,
-                                          IMG / 2, c.scratch(), c.scratch_bytes()));
+    {
+        // beside the encoder's backward chain the sparse weight-gradient kernel runs one wave per SIMD (common.h); the rule looks at the
+        // plan only, not at the stream mode: one stream or three give bit-identical steps
+        g_bbbp_conv_wgrad_beside_encoder = plan.L > 0 ? 1 : 0;
+        const int rcw = bbbp_conv3x3_relu_pool_bwd_weight(c.st, pool1, dpool2, c.u8(plan.mask2), G[ix.c2_w()], G[ix.c2_b()], B, C1, C2, IMG / 2,
+                                                          IMG / 2, c.scratch(), c.scratch_bytes());
+        g_bbbp_conv_wgrad_beside_encoder = 0;
+        TRY(rcw);
+    }
     next_section(SEC_CONV2_DGRAD);
     TRY(bbbp_conv3x3_relu_pool_bwd_data(c.st, dpool2, c.u8(plan.mask2), P[ix.c2_w()], dpool1, B, C1, C2, IMG / 2, IMG / 2,
                                         c.scratch(), c.scratch_bytes()));

@@ -14,6 +14,7 @@ thread_local int g_bbbp_reserved_cus = 0;
 thread_local size_t g_bbbp_small_lds_pad = 0;
 thread_local int g_bbbp_wino_side_cus = 0;
 thread_local int g_bbbp_conv1_fwd_f32 = 0;
+thread_local int g_bbbp_conv_wgrad_beside_encoder = 0;
 thread_local const unsigned long long* g_bbbp_seed_base = nullptr;
 
 // More than 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize per (kernel, DEVICE): code objects are loaded

@@ -98,7 +98,10 @@ int bbbp_conv_last_clock(unsigned long long* shader_cycles, unsigned long long* 
  * in-lane pooling windows).  Inside bbbp_mixed_forward the engine keeps the first stage's forward on the f32 kernel while a training
  * step's encoder chain runs beside it (the split-bf16 kernel leaves that chain no wave slots: measured slower for the step), so bit 6
  * acts on forward-only (inference-plan) passes -- eval loops, screening --, the encoder-less two-branch model and the op-level entry point.
- * 0 = direct implicit GEMM on the f32 MFMA everywhere.  Initial value: environment BBBP_CONV_WINOGRAD, else 124. */
+ * 0 = direct implicit GEMM on the f32 MFMA everywhere.  Initial value: environment BBBP_CONV_WINOGRAD, else 252.
+ * bit 7 (128, round 3): conv2's split-bf16 weight gradient on the 2:4 structured-sparse MFMA (v_smfmac_f32_32x32x32_bf16): the pooled
+ * gradient expanded through the arg-max mask has at most one nonzero per pixel pair, so its compressed form is the pooled tensor itself
+ * -- half the matrix-pipe time, same six piece products, same float32 accuracy; bit 8 (256): its 4-wave form wherever it runs (tests). */
 int bbbp_set_conv_winograd(int mask);
 int bbbp_get_conv_winograd(void);
 /* Measurement aid: with BBBP_WINO_PROBE=1 in the environment the Winograd kernels stamp the shader clock at phase boundaries;

@@ -327,8 +327,8 @@ def test_fused_head_backward_matches_the_launch_per_op_chain(dev, B, training):
         assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), float(b.abs().max()))
 
 
-@pytest.mark.parametrize("conv2_form,overlap", [(0, 1), (3, 1), (124, 1), (124, 0)],
-                         ids=["direct", "winograd", "split-bf16-default", "split-bf16-default-one-stream"])
+@pytest.mark.parametrize("conv2_form,overlap", [(0, 1), (3, 1), (252, 1), (252, 0), (124, 1)],
+                         ids=["direct", "winograd", "split-bf16-default", "split-bf16-default-one-stream", "split-bf16-dense-wgrad"])
 def test_real_molecule_images_against_oracle(dev, conv2_form, overlap):
     """The eight depictions shipped with the reference (tests/golden/img, white background: large flat regions, i.e. exact
     ties inside pooling windows in BOTH conv stages) through the full model: output, loss and every gradient element against

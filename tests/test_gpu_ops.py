@@ -259,11 +259,12 @@ def test_conv1_split_bf16_forward_keeps_ties_and_matches_f32(dev):
     assert float((m1 != m0).float().mean()) < 1e-4           # near-ties on the random part only
 
 
-@pytest.fixture(params=[0, 3, 28], ids=["direct", "winograd", "split-bf16"])
+@pytest.fixture(params=[0, 3, 28, 28 | 128, 28 | 128 | 256], ids=["direct", "winograd", "split-bf16", "split-bf16-sparse-wgrad-8w", "split-bf16-sparse-wgrad-4w"])
 def conv2_algo(request):
     """The forms of the 32 -> 64 @ 64x64 stage (bbbp_set_conv_winograd): direct implicit GEMM on the f32 MFMA, Winograd F(2x2,3x3),
-    and the direct form on the bf16 matrix pipe with every float32 operand split into three bf16 pieces (conv_b3.hip: forward, data
-    gradient and weight gradient)."""
+    the direct form on the bf16 matrix pipe with every float32 operand split into three bf16 pieces (conv_b3.hip: forward, data
+    gradient and weight gradient), and that form with the weight gradient on the 2:4 structured-sparse MFMA (the pooled gradient is the
+    compressed operand; 8-wave and 4-wave work-groups)."""
     L = _lib.lib()
     old = L.bbbp_get_conv_winograd()
     _lib.check(L.bbbp_set_conv_winograd(request.param), "bbbp_set_conv_winograd")

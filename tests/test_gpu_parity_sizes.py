@@ -101,14 +101,14 @@ def check_b512_step_against_float64(dev, F, seed, conv_mask, max_flips=8):
     return checked
 
 
-@pytest.mark.parametrize("conv_mask", [124, 3, 0], ids=["split-bf16-default", "winograd", "direct"])
+@pytest.mark.parametrize("conv_mask", [252, 124, 3, 0], ids=["split-bf16-sparse-default", "split-bf16-dense-wgrad", "winograd", "direct"])
 def test_headline_batch_fwd_bwd_against_oracle(dev, conv_mask):
-    """BASELINE config 3 exactly as bench.py runs it: B = 512, F = 167, the library's DEFAULT conv mask 124 (conv2 forward / data
+    """BASELINE config 3 exactly as bench.py runs it: B = 512, F = 167, the library's DEFAULT conv mask 252 (conv2 forward / data
     gradient / weight gradient AND conv1's weight gradient in the split-bf16 form -- conv_b3_wgrad3_kernel at its B = 512 slab
     count; bit 6, conv1's split-bf16 forward, is held back by the engine beside a training step's encoder chain and runs in the
     B = 4096 screening test below and in test_gpu_config2.py), and the two all-float32 alternatives (Winograd on the 192-CU
     partition, direct)."""
-    assert _lib.lib().bbbp_get_conv_winograd() == 124, "the library default changed: run the B = 512 step under the new default too"
+    assert _lib.lib().bbbp_get_conv_winograd() == 252, "the library default changed: run the B = 512 step under the new default too"
     assert check_b512_step_against_float64(dev, 167, 20250113, conv_mask) == 90
 
 
@@ -116,7 +116,7 @@ def test_morgan_2048_batch_512_every_gradient_against_oracle(dev):
     """BASELINE config 4 at its benchmarked shape: F = 2048 (nhead 256, head_dim 8: fused small-head attention; 160 M parameters;
     every encoder GEMM on the 128 x 128 split-bf16 plan, wide-row LayerNorm), B = 512, default conv forms -- every non-degenerate
     gradient tensor, element for element, at the tolerances of the F = 167 step."""
-    assert check_b512_step_against_float64(dev, 2048, 7, 124) == 90
+    assert check_b512_step_against_float64(dev, 2048, 7, 252) == 90
 
 
 def test_screening_batch_4096_eval_and_screen(dev):

@@ -13,10 +13,10 @@ from helpers import golden, oracle_train, synth_inputs
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[0, 3, 124], ids=["direct", "winograd", "split-bf16-default"])
+@pytest.fixture(params=[0, 3, 252], ids=["direct", "winograd", "split-bf16-default"])
 def conv2_form(request):
     """The forms of the conv stages (include/bbbp_hip.h: bbbp_set_conv_winograd): all-f32 direct, conv2 forward / data gradient as
-    Winograd, and 124 = the library default that bench.py times (conv2's three kernels and conv1's weight gradient split-bf16; conv1's
+    Winograd, and 252 = the library default that bench.py times (conv2's three kernels and conv1's weight gradient split-bf16; conv1's
     split-bf16 forward in eval-mode passes)."""
     L = _lib.lib()
     old = L.bbbp_get_conv_winograd()
