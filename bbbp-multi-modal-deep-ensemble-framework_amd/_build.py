@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbbbp_hip.so")
-SOURCES = ["util.hip", "gemm.hip", "conv.hip", "conv_wino.hip", "conv_b3.hip", "conv_b3c1.hip", "rowops.hip", "engine.hip", "encoder.hip", "attention.hip", "attention_b3.hip", "preprocess.hip", "mlp.hip", "head.hip", "forest.hip"]
+SOURCES = ["util.hip", "gemm.hip", "conv.hip", "conv_wino.hip", "conv_b3.hip", "conv_b3c1.hip", "rowops.hip", "engine.hip", "encoder.hip", "fold.hip", "attention.hip", "attention_b3.hip", "preprocess.hip", "mlp.hip", "head.hip", "forest.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "bbbp_set_graphs": (c_int, [c_int]),
     "bbbp_set_fused_head_bwd": (c_int, [c_int]),
     "bbbp_set_fused_encoder": (c_int, [c_int]),
+    "bbbp_set_fold_outproj": (c_int, [c_int]),
     "bbbp_set_flash_attention": (c_int, [c_int]),
     "bbbp_set_gemm_split_bf16": (c_int, [c_int]),
     "bbbp_set_gemm_fold_reduce": (c_int, [c_int]),

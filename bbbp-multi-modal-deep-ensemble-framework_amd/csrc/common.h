@@ -119,6 +119,13 @@ size_t bbbp_b3_conv1_fwd_workspace_bytes();
 int bbbp_b3_conv1_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* y, uint8_t* mask, int B, void* workspace);
 int bbbp_b3_conv1_wgrad(hipStream_t st, const float* x, const float* gy, const uint8_t* mask, float* slab, float* bslab, int B, int grid);
 int bbbp_wino_last_phases(unsigned long long* phases4);     // BBBP_WINO_PROBE=1 builds of the kernel only
+// fold.hip: out_proj folded into the value projection of a one-head encoder layer (W' = Wo Wv, b' = Wo bv) and the gradients unfolded
+bool bbbp_outproj_fold_supported(int F, int nhead, int layers);
+size_t bbbp_outproj_fold_floats(int F, int which);          // 0 wf [3F][F], 1 bf [3F], 2 wvt [F + 1][F], 3 tdw [F][F], 4 tdb [F]
+int bbbp_outproj_fold(hipStream_t st, int layers, int F, const float* const* win, const float* const* bin, const float* const* wo,
+                      const float* const* bo, float* const* wf, float* const* bf, float* const* wvt);
+int bbbp_outproj_unfold(hipStream_t st, int F, int B, const float* tdw, const float* tdb, const float* wo, const float* wvt, const float* dz,
+                        int lddz, float* g_outw, float* g_outb, float* g_inw_v, float* g_inb_v);
 
 // Work-groups are dealt to the 8 XCDs round-robin by id and every XCD has its own L2.  Persistent kernels whose consecutive
 // work items share input rows (conv strips and their halos) map group w of n to logical index (w % 8) * (n / 8) + w / 8: the

@@ -72,6 +72,9 @@ struct Plan {
     bool exact; int world, rank; size_t Bg;
     size_t dkvg, dkvl;         // this rank's queries' share of dK | dV for all Bg keys; the reduce-scattered rows of this rank
     bool attn_b3;          // forward-only plan, wide head, >= 1024 rows: split-bf16 attention (attention_b3.hip)
+    // one-head layers on the launch-per-op schedule: out_proj folded into the value projection (fold.hip); per layer the folded in_proj
+    // weight / bias, [Wv | bv]^T, and (training plans) the folded gradient dW' | db'
+    bool fold; size_t fwf[32], fbf[32], fwvt[32], ftdw[32], ftdb[32];
     size_t attn_part, attn_part_bytes;
     LayerOff layer[32];
     LayerGrad lgrad[32];
@@ -87,6 +90,22 @@ struct Plan {
 
 // Fused attention for many small heads (attention.hip); 0 selects the GEMM + softmax schedule with materialised probabilities.
 int g_flash_attention = -1;
+
+// out_proj folded into the value projection for one-head layers (fold.hip): two launches fewer per layer on the encoder's forward and
+// backward chains.  A bit mask: bit 0 (default) the launch-per-op schedule with materialised probabilities; bit 1 (opt-in) also the
+// forward-only split-bf16 attention kernel of 2048+ row plans -- there the encoder alone gets faster (1.88 -> 1.76 ms at B = 4096) but the
+// whole step, whose branches only time-share the matrix pipe, measured slower (7.54 -> 7.79 ms; profiles/r03_fold_outproj.txt).
+// BBBP_FOLD_OUTPROJ=0 / bbbp_set_fold_outproj(0) keep the reference's operation order.
+int g_fold_outproj = -1;
+int g_fused_encoder = -1;              // bit 0: row-fused kernels (opt-in); bits 1 / 2: sliced persistent forward / backward for small batches
+int fold_outproj_on() {
+    if (g_fold_outproj < 0) { const char* e = getenv("BBBP_FOLD_OUTPROJ"); g_fold_outproj = e ? (atoi(e) & 3) : 1; }
+    return g_fold_outproj;
+}
+int fused_encoder_mode() {
+    if (g_fused_encoder < 0) { const char* e = getenv("BBBP_FUSED_ENCODER"); g_fused_encoder = e ? atoi(e) & 7 : 0; }
+    return g_fused_encoder;
+}
 
 int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     BBBP_CHECK_ARG(d, "null desc");
@@ -117,6 +136,10 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
     const bool wide = (g_flash_attention & 2) || ((g_flash_attention & 4) && p->inference && p->B >= 2048);
     p->flash = p->L > 0 && !p->exact && (p->attn_b3 || ((g_flash_attention & 1) && bbbp_attn_small_supported(p->B, p->NH, p->D)) ||
                             (wide && bbbp_attn_wide_supported(p->B, p->NH, p->D)));
+    // the fused / sliced encoder schedules (opt-in) and the fused attention kernels keep the reference's operation order
+    // (the forward-only split-bf16 attention kernel reads VW where it read V: its rows of P sum to one, so bo rides in b')
+    p->fold = ((fold_outproj_on() & 1) && !p->flash || (fold_outproj_on() & 2) && p->attn_b3) && p->L > 0 && !p->exact && fused_encoder_mode() == 0 &&
+              bbbp_outproj_fold_supported(p->F, p->NH, p->L);
     const size_t B = p->B, F = p->F, NH = p->NH, DFF = p->DFF, Bg = p->Bg;
     Bump b;
     p->seed_slot = b.take(256);
@@ -148,6 +171,12 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
         p->sl_kvpart = p->inference ? 0 : b.take(bbbp_enc_sliced_kvpart_bytes(p->B, p->F));
     } else {
         p->sl_sync = p->sl_part = p->sl_kvpart = 0;
+    }
+    for (int l = 0; l < p->L; ++l) {
+        p->fwf[l] = p->fold ? b.f(bbbp_outproj_fold_floats(p->F, 0)) : 0; p->fbf[l] = p->fold ? b.f(bbbp_outproj_fold_floats(p->F, 1)) : 0;
+        p->fwvt[l] = p->fold ? b.f(bbbp_outproj_fold_floats(p->F, 2)) : 0;
+        p->ftdw[l] = (p->fold && !p->inference) ? b.f(bbbp_outproj_fold_floats(p->F, 3)) : 0;
+        p->ftdb[l] = (p->fold && !p->inference) ? b.f(bbbp_outproj_fold_floats(p->F, 4)) : 0;
     }
     p->attn_part_bytes = p->attn_b3 ? bbbp_attn_b3_workspace_bytes(p->B, p->NH, p->D) : 0;
     p->attn_part = p->attn_part_bytes ? b.take(p->attn_part_bytes) : 0;
@@ -258,11 +287,6 @@ int g_fused_head_bwd = -1;
 // bbbp_set_fused_encoder(1).  Correct (tests compare the two schedules) but OFF by default: a 16-row work-group streams a whole
 // layer's weights by itself (3.2 MB forward) through ONE wave per SIMD, which is bound by load latency -- 176 / 289 us per
 // forward / backward launch against ~50 us for the launch-per-op chain whose GEMMs spread over all CUs.
-int g_fused_encoder = -1;              // bit 0: row-fused kernels (opt-in); bits 1 / 2: sliced persistent forward / backward for small batches
-int fused_encoder_mode() {
-    if (g_fused_encoder < 0) { const char* e = getenv("BBBP_FUSED_ENCODER"); g_fused_encoder = e ? atoi(e) & 7 : 0; }
-    return g_fused_encoder;
-}
 bool fused_encoder(const Plan& p) {
     return (fused_encoder_mode() & 1) && p.L > 0 && !p.flash && !p.exact && bbbp_enc_rows_supported(p.F, p.NH, p.DFF);
 }
@@ -510,6 +534,12 @@ extern "C" int bbbp_set_fused_encoder(int mode) {
     return prev;
 }
 
+extern "C" int bbbp_set_fold_outproj(int on) {
+    const int prev = fold_outproj_on();
+    g_fold_outproj = on & 3;
+    return prev;
+}
+
 extern "C" int bbbp_set_flash_attention(int on) {
     if (g_flash_attention < 0) { const char* e = getenv("BBBP_FLASH_ATTENTION"); g_flash_attention = e ? atoi(e) & 31 : 13; }
     const int prev = g_flash_attention;
@@ -640,6 +670,17 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         }
         TRY(bbbp_enc_sliced_fwd(ce.st, &a));
     }
+    if (plan.fold) {
+        // W' = Wo Wv, b' = Wo bv of every layer in one launch at the head of the chain (the parameters change every step)
+        const float* win[32]; const float* bin[32]; const float* wo[32]; const float* bo[32]; float* wf[32]; float* bf[32]; float* wvt[32];
+        for (int l = 0; l < plan.L; ++l) {
+            win[l] = P[ix.layer(l, L_INW)]; bin[l] = P[ix.layer(l, L_INB)]; wo[l] = P[ix.layer(l, L_OUTW)];
+            // fused attention (forward-only, no dropout): softmax rows sum to one, so out_proj's bias is carried by b' = Wo bv + bo
+            bo[l] = plan.attn_b3 ? P[ix.layer(l, L_OUTB)] : nullptr;
+            wf[l] = c.f(plan.fwf[l]); bf[l] = c.f(plan.fbf[l]); wvt[l] = c.f(plan.fwvt[l]);
+        }
+        TRY(bbbp_outproj_fold(ce.st, plan.L, F, win, bin, wo, bo, wf, bf, wvt));
+    }
     const bool fused_rows = !sliced && fused_encoder(plan);
     if (fused_rows) {
         // in_proj of layer 0; every later in_proj (and fingerprint_fc) is the tail of the previous layer's row kernel
@@ -673,12 +714,14 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         float* qkv = c.f(o.qkv); float* prob = c.f(o.prob); float* ctx = c.f(o.ctx);
         {
             Section sq(ce.st, SEC_QKV_FWD);
-            TRY(linear_fwd(ce, x, F, P[ix.layer(l, L_INW)], P[ix.layer(l, L_INB)], qkv, 3 * F, B, 3 * F, F, 0));
+            // folded plan: [Q | K | VW] = x [Wq; Wk; Wo Wv]^T + [bq; bk; Wo bv]
+            TRY(linear_fwd(ce, x, F, plan.fold ? c.f(plan.fwf[l]) : P[ix.layer(l, L_INW)], plan.fold ? c.f(plan.fbf[l]) : P[ix.layer(l, L_INB)], qkv,
+                           3 * F, B, 3 * F, F, 0));
         }
         std::optional<Section> sec_attn;
         sec_attn.emplace(ce.st, SEC_ATTN_FWD);
         if (plan.attn_b3) {
-            TRY(bbbp_attn_b3_fwd(ce.st, qkv, ctx, B, F, NH, scale, plan.attn_part_bytes ? c.f(plan.attn_part) : nullptr, plan.attn_part_bytes));
+            TRY(bbbp_attn_b3_fwd(ce.st, qkv, plan.fold ? c.f(o.z1) : ctx, B, F, NH, scale, plan.attn_part_bytes ? c.f(plan.attn_part) : nullptr, plan.attn_part_bytes));
         } else if (plan.flash) {
             TRY(bbbp_attn_small_fwd(ce.st, qkv, ctx, c.f(o.lse), B, F, NH, scale, p_drop, site_seed(d->seed, l, 0), o.keep ? c.u8(o.keep) : nullptr));
         } else {
@@ -698,9 +741,9 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
                           (long)B * Bk, 0, ce.scratch(), ce.scratch_bytes()));
         float* pd = c.f(o.pd);
         TRY(bbbp_softmax_fwd(ce.st, prob, pd, (long)NH * B, Bk, p_drop, site_seed(d->seed, l, 0)));
-        // ctx_h = Pd_h V_h
-        TRY(bbbp_gemm_f32(ce.st, 0, 0, B, D, Bk, 1.f, pd, Bk, vmat, ldkv, ctx, F, nullptr, nullptr, 0, 0, NH, (long)B * Bk,
-                          D, D, 0, ce.scratch(), ce.scratch_bytes()));
+        // ctx_h = Pd_h V_h; folded plan (one head): z1 = Pd VW + bo, the out_proj output itself
+        TRY(bbbp_gemm_f32(ce.st, 0, 0, B, D, Bk, 1.f, pd, Bk, vmat, ldkv, plan.fold ? c.f(o.z1) : ctx, F, plan.fold ? P[ix.layer(l, L_OUTB)] : nullptr,
+                          nullptr, 0, 0, NH, (long)B * Bk, D, D, 0, ce.scratch(), ce.scratch_bytes()));
         }
         sec_attn.reset();
         float* z1 = c.f(o.z1); float* y1 = c.f(o.y1);
@@ -709,12 +752,12 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         // beside the resident conv work-groups (encoder forward 0.98 -> 1.15 ms in the step, 0.58 -> 0.60 alone); linear2 -> norm2 is never
         // fused (one wave per tile walking K = 2048 alone: 90 us against 22 + 4)
         static const bool ln_opt_in = [] { const char* e = getenv("BBBP_FUSED_LINEAR_LN"); return e && atoi(e) != 0; }();
-        const bool ln_fused = ln_opt_in && bbbp_linear_layernorm_supported(B, F, F) && F <= 512;
+        const bool ln_fused = !plan.fold && ln_opt_in && bbbp_linear_layernorm_supported(B, F, F) && F <= 512;
         if (ln_fused) {
             TRY(bbbp_linear_layernorm_fwd(ce.st, ctx, F, P[ix.layer(l, L_OUTW)], P[ix.layer(l, L_OUTB)], x, F, z1, F, y1, F, P[ix.layer(l, L_N1W)],
                                           P[ix.layer(l, L_N1B)], c.f(o.mean1), c.f(o.rstd1), B, F, F, 1e-5f, p_drop, site_seed(d->seed, l, 1)));
         } else {
-        {
+        if (!plan.fold) {
             Section so(ce.st, SEC_OUTPROJ_FWD);
             TRY(linear_fwd(ce, ctx, F, P[ix.layer(l, L_OUTW)], P[ix.layer(l, L_OUTB)], z1, F, B, F, F, 0));
         }
@@ -1136,11 +1179,12 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
             TRY(bbbp_layernorm_bwd(ce.st, dy1, z1, P[ix.layer(l, L_N1W)], c.f(o.mean1), c.f(o.rstd1), dz1, plan.drop ? dsa : nullptr,
                                    nullptr, nullptr, B, F, p_drop, site_seed(d->seed, l, 1)));
         }
-        // out_proj input gradient
-        {
+        // out_proj input gradient (folded plan: dVW = Pd^T dsa and dPd = dsa VW^T take the out_proj output's gradient itself)
+        if (!plan.fold) {
             Section sg(ce.st, SEC_OUTPROJ_DGRAD);
             TRY(linear_bwd_input(ce, dsa, F, P[ix.layer(l, L_OUTW)], dctx, F, B, F, F));
         }
+        const float* dattn = plan.fold ? dsa : dctx;
         // attention backward.  Products that become ready together share a launch (bbbp_gemm_f32_grouped):
         //   dV_h = Pd_h^T dctx_h -> dqkv[:, 2F + hD]   |   dPd_h = dctx_h V_h^T
         const float* pdp = c.f(o.pd);
@@ -1157,8 +1201,8 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         float* dkmat = plan.exact ? c.f(plan.dkvg) : dqkv + F; float* dvmat = plan.exact ? c.f(plan.dkvg) + F : dqkv + 2 * F;
         {
             bbbp_gemm_desc g[2] = {
-                gemm_desc(1, 0, Bk, D, B, 1.f, pdp, Bk, dctx, F, dvmat, ldkv, NH, (long)B * Bk, D, D),
-                gemm_desc(0, 1, B, Bk, D, 1.f, dctx, F, vmat, ldkv, dprob, Bk, NH, D, D, (long)B * Bk)};
+                gemm_desc(1, 0, Bk, D, B, 1.f, pdp, Bk, dattn, F, dvmat, ldkv, NH, (long)B * Bk, D, D),
+                gemm_desc(0, 1, B, Bk, D, 1.f, dattn, F, vmat, ldkv, dprob, Bk, NH, D, D, (long)B * Bk)};
             TRY(bbbp_gemm_f32_grouped(ce.st, g, 2, ce.scratch(), ce.scratch_bytes()));
         }
         TRY(bbbp_softmax_bwd(ce.st, dprob, prob, (long)NH * B, Bk, p_drop, site_seed(d->seed, l, 0)));
@@ -1178,18 +1222,34 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
         }
         sec_attn.reset();
         TRY(leaf_after(ce));
-        {
+        if (!plan.fold) {
             Section sw(cl.st, SEC_OUTPROJ_WGRAD);
             TRY(linear_bwd_weight_bias(cl, dsa, F, ctx, F, G[ix.layer(l, L_OUTW)], G[ix.layer(l, L_OUTB)], B, F, F));
         }
-        {
+        if (plan.fold) {
+            // [dWq; dWk | dbq; dbk] straight into the gradient, the folded block dW' | db' = dVW^T [x | 1] into its scratch (one launch), then
+            // dWo = dW' Wv^T + db' bv^T, d[Wv | bv] = Wo^T [dW' | db'] and dbo = column sums of dsa in one more (fold.hip)
+            Section sw(cl.st, SEC_QKV_WGRAD);
+            float* tdw = c.f(plan.ftdw[l]); float* tdb = c.f(plan.ftdb[l]);
+            if (bbbp_gemm_folds_asum(2 * F, F, B, 1) && bbbp_gemm_folds_asum(F, F, B, 1)) {
+                bbbp_gemm_desc gg[2] = {gemm_desc(1, 0, 2 * F, F, B, 1.f, dqkv, 3 * F, xin, F, G[ix.layer(l, L_INW)], F, 1, 0, 0, 0),
+                                        gemm_desc(1, 0, F, F, B, 1.f, dqkv + 2 * F, 3 * F, xin, F, tdw, F, 1, 0, 0, 0)};
+                gg[0].asum = G[ix.layer(l, L_INB)]; gg[1].asum = tdb;
+                TRY(bbbp_gemm_f32_grouped(cl.st, gg, 2, cl.scratch(), cl.scratch_bytes()));
+            } else {
+                TRY(linear_bwd_weight_bias(cl, dqkv, 3 * F, xin, F, G[ix.layer(l, L_INW)], G[ix.layer(l, L_INB)], B, 2 * F, F));
+                TRY(linear_bwd_weight_bias(cl, dqkv + 2 * F, 3 * F, xin, F, tdw, tdb, B, F, F));
+            }
+            TRY(bbbp_outproj_unfold(cl.st, F, B, tdw, tdb, P[ix.layer(l, L_OUTW)], c.f(plan.fwvt[l]), dsa, F, G[ix.layer(l, L_OUTW)],
+                                    G[ix.layer(l, L_OUTB)], G[ix.layer(l, L_INW)] + (size_t)2 * F * F, G[ix.layer(l, L_INB)] + 2 * F));
+        } else {
             Section sw(cl.st, SEC_QKV_WGRAD);
             TRY(linear_bwd_weight_bias(cl, dqkv, 3 * F, xin, F, G[ix.layer(l, L_INW)], G[ix.layer(l, L_INB)], B, 3 * F, F));
         }
         TRY(layer_norm_leaves(l));
         if (l > 0 || d->need_input_grad) {
             Section sg(ce.st, SEC_QKV_DGRAD);
-            TRY(linear_bwd_input(ce, dqkv, 3 * F, P[ix.layer(l, L_INW)], l > 0 ? c.f(plan.lgrad[l - 1].dyout) : c.f(plan.dA), F, B, 3 * F, F, dz1, F));
+            TRY(linear_bwd_input(ce, dqkv, 3 * F, plan.fold ? c.f(plan.fwf[l]) : P[ix.layer(l, L_INW)], l > 0 ? c.f(plan.lgrad[l - 1].dyout) : c.f(plan.dA), F, B, 3 * F, F, dz1, F));
         }
     }
     {

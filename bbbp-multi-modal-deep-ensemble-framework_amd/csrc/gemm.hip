@@ -1214,6 +1214,7 @@ bool launch_pair(const DirectParams& a, int la, int ta, const DirectParams& b, i
     if (ta == 1 && tb == 1) {
         if (la == 2 && lb == 0) { launch_pair_one<2, 1, 0, 1>(a, b, st); return true; }      // dV = Pd^T dO | dPd = dO V^T
         if (la == 1 && lb == 2) { launch_pair_one<1, 1, 2, 1>(a, b, st); return true; }      // dQ = dS K   | dK = dS^T Q
+        if (la == 2 && lb == 2) { launch_pair_one<2, 1, 2, 1>(a, b, st); return true; }      // [dWq; dWk] = dQK^T x | dW' = dVW^T x (fold.hip)
     }
     return false;
 }

@@ -325,6 +325,18 @@ int bbbp_set_fused_head_bwd(int on);
  * bit 2: the same for the BACKWARD input-gradient chain (enc_sliced_bwd_kernel); the weight gradients stay leaf launches.
  * Returns the previous mask. */
 int bbbp_set_fused_encoder(int mode);
+/* One-head encoder layers (nhead 1: a prime fingerprint width such as 167) on the launch-per-op schedule: out_proj folded into the value
+ * projection (csrc/fold.hip).  out_proj(Pd V) = Pd (x (Wo Wv)^T + 1 (Wo bv)^T) + bo, so in_proj produces [Q | K | VW] with the folded
+ * weight block W' = Wo Wv (one launch per step for all layers), the out_proj GEMM leaves the forward chain, its input-gradient GEMM leaves
+ * the backward chain, and its weight gradient is unfolded from the in_proj weight gradient's V block (dWo = dW' Wv^T + db' bv^T,
+ * d[Wv | bv] = Wo^T [dW' | db'], dbo = column sums).  The same function as nn.TransformerEncoderLayer (...20250113.py:75-78) up to
+ * float32 rounding of the reassociated products.  A bit mask, default 1 (initial value BBBP_FOLD_OUTPROJ): bit 0 the launch-per-op
+ * schedule with materialised probabilities (training steps, eval batches below 2048 rows); bit 1 also the forward-only split-bf16
+ * attention kernel of 2048+ row plans (no dropout there: bo rides in b'; opt-in, measured slower inside the overlapped step); 0 keeps
+ * the reference's operation order.  Never applied with the small-head fused attention, the exact-global-batch mode or
+ * bbbp_set_fused_encoder != 0.  Changes the workspace layout: set it before bbbp_mixed_workspace_bytes / the forward call of a step.
+ * Returns the previous mask. */
+int bbbp_set_fold_outproj(int mask);
 /* Fused flash-style self-attention (csrc/attention.hip, csrc/attention_b3.hip), a bit mask (default 13, initial value BBBP_FLASH_ATTENTION):
  * bit 0: many heads of head_dim 8 / 16 (F = 2048: 256 x 8), one work-group per head, scores in registers, no [nhead, B, B] tensors;
  * bit 1: one wide head of 161 .. 176 columns (F = 167, nhead = 1), operands straight from global memory, everywhere -- correct but
