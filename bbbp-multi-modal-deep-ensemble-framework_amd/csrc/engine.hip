@@ -330,6 +330,8 @@ int get_side(SideStream** out) {
     BBBP_CHECK_ARG(dev >= 0 && dev < 64, "device index %d", dev);
     SideStream& ss = g_side[dev];
     if (!ss.s) {
+        // (queue priorities -- hipStreamCreateWithPriority, chain stream highest / leaf stream lowest -- were measured on the headline step:
+        // 2.497 ms default, 2.501 / 2.508 with them, profiles/r03_rebalance.txt; the wave priority set inside the kernels is what matters)
         BBBP_CHECK_HIP(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
         BBBP_CHECK_HIP(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
         BBBP_CHECK_HIP(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));

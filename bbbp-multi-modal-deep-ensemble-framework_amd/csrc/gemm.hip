@@ -385,6 +385,8 @@ __device__ __forceinline__ void gemm_b3_body(const GemmParams& p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int batch = blockIdx.z / p.splits, split = blockIdx.z % p.splits;
+    // (an XCD-aware order of the row tiles of one column block -- id % 8 = XCD, row tile the slot's fastest digit -- was measured on the
+    // image FC's input gradient, 4 x 512 tiles, K = 128: 103.6 vs 103.2 us, the re-read column blocks come from the Infinity Cache anyway)
     const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
     const int kbeg = split * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
