@@ -503,6 +503,8 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
             roofline["dvfs_note"] = ("bf16 MFMA loops on random data hold ~1.9 GHz, not 2.4 (MI355X_MICROARCH.md 'DVFS give-back'); the guide's "
                                      "best bf16 loops reach 1250-1480 TFLOP/s executed")
         roofline["algorithm"] = ("winograd F(2x2,3x3) f32" if wino.get(dom) else
+                                 "direct implicit GEMM, f32 operands split into 3 bf16 pieces, pooled gradient as the 2:4-compressed operand of v_smfmac (products with the max-pool's zeros skipped; dense flop count)"
+                                 if (b3.get(dom) and dom == "conv2_wgrad" and (wmask & 128)) else
                                  "direct implicit GEMM, f32 operands split into 3 bf16 pieces (6 bf16 MFMAs per f32 product, f32 accumulate)" if b3.get(dom)
                                  else "direct implicit GEMM f32") if dom.startswith("conv2") \
             else ("fused small-head attention (one work-group per head, v_mfma_f32_16x16x4_f32; bound by its exp / Philox / LDS work)"
@@ -521,6 +523,14 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
                         executed_bf16_tflops=round(6 * conv2 / (sections[k] * 1e-3) / 1e12, 1),
                         executed_frac_of_bf16_peak=round(6 * conv2 / (sections[k] * 1e-3) / 1e12 / 2500.0, 4))
                 for k in b3 if b3[k] and k in sections}
+            if (wmask & 128) and "conv2_wgrad" in roofline["split_bf16"]:
+                # conv-form bit 7: the weight gradient on v_smfmac_f32_32x32x32_bf16 -- the pooled gradient is the 2:4-compressed operand, so
+                # the products with the zeros the max-pool created are never issued; the figures above count the DENSE form's products
+                roofline["split_bf16"]["conv2_wgrad"].update(
+                    structured_sparse_mfma=True,
+                    issued_bf16_tflops=round(3 * conv2 / (sections["conv2_wgrad"] * 1e-3) / 1e12, 1),
+                    note="2:4 structured-sparse MFMA: half the dense form's matrix-pipe time; executed_* are dense-equivalent, issued_* what the pipe ran; "
+                         "priced against the DENSE ceiling (skipped zeros are algorithm, not hardware peak)")
         if any(wino.get(k) and k in sections for k in wino):
             roofline["winograd"] = {
                 k: dict(ms_per_launch=round(sections[k], 4), ms_per_launch_isolated=round(isolated.get(k, 0.0), 4),

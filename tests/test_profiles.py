@@ -74,7 +74,7 @@ def test_rocprof_kernel_table_agrees_with_the_bench_line(config):
     launch in the table is an in-step one), and the PMC traffic quoted in the line is the committed pass of that configuration."""
     d = bench(config)
     r = d["roofline"]
-    pattern = {"conv2_wgrad": "conv_b3_wgrad_kernel", "conv2_fwd": "conv_b3_kernel<0>", "conv2_dgrad": "conv_b3_kernel<1>"}[r["kernel"]]
+    pattern = {"conv2_wgrad": "conv_b3_wgrad_", "conv2_fwd": "conv_b3_kernel<0>", "conv2_dgrad": "conv_b3_kernel<1>"}[r["kernel"]]
     rows = [x for x in csv.DictReader(open(os.path.join(PROF, f"{ROUND}_kernel_stats_config{config}.csv"))) if pattern in x["Name"]]
     assert len(rows) == 1
     avg_ms = float(rows[0]["AverageNs"]) * 1e-6

@@ -13,7 +13,7 @@ import sys
 KERNELS = {"conv2_fwd (winograd)": "wino_conv_kernel<0>", "conv2_dgrad (winograd)": "wino_conv_kernel<1>", "conv2_wgrad (f32)": "conv_wgrad32_kernel",
            "conv1_fwd": "conv3x3_kernel<3, 32", "conv1_wgrad (f32)": "conv_wgrad3_kernel", "conv2_fwd (direct f32)": "conv3x3_kernel<32, 64",
            "conv2_dgrad (direct f32)": "conv3x3_kernel<64, 32", "conv2_fwd (split-bf16)": "conv_b3_kernel<0>", "conv2_dgrad (split-bf16)": "conv_b3_kernel<1>",
-           "conv2_wgrad (split-bf16)": "conv_b3_wgrad_kernel", "conv1_wgrad (split-bf16)": "conv_b3_wgrad3_kernel", "imgfc / large GEMM NT (split-bf16)": "gemm_b3_kernel<0>",
+           "conv2_wgrad (split-bf16)": "conv_b3_wgrad_kernel", "conv2_wgrad (split-bf16, 2:4 structured-sparse MFMA)": "conv_b3_wgrad_sp_kernel", "conv1_wgrad (split-bf16)": "conv_b3_wgrad3_kernel", "imgfc / large GEMM NT (split-bf16)": "gemm_b3_kernel<0>",
            "large GEMM NN (split-bf16)": "gemm_b3_kernel<1>", "large GEMM TN (split-bf16)": "gemm_b3_kernel<2>"}
 CUS, XCDS = 256, 8
 
