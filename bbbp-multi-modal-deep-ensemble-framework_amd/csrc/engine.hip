@@ -92,14 +92,14 @@ struct Plan {
 int g_flash_attention = -1;
 
 // out_proj folded into the value projection for one-head layers (fold.hip): two launches fewer per layer on the encoder's forward and
-// backward chains.  A bit mask: bit 0 (default) the launch-per-op schedule with materialised probabilities; bit 1 (opt-in) also the
-// forward-only split-bf16 attention kernel of 2048+ row plans -- there the encoder alone gets faster (1.88 -> 1.76 ms at B = 4096) but the
-// whole step, whose branches only time-share the matrix pipe, measured slower (7.54 -> 7.79 ms; profiles/r03_fold_outproj.txt).
-// BBBP_FOLD_OUTPROJ=0 / bbbp_set_fold_outproj(0) keep the reference's operation order.
+// backward chains.  A bit mask (default 3): bit 0 the launch-per-op schedule with materialised probabilities; bit 1 also the
+// forward-only split-bf16 attention kernel of 2048+ row plans -- there the encoder alone gets faster (1.88 -> 1.76 ms at B = 4096); beside the
+// conv kernels on a second stream the step measured slower with it (7.54 -> 7.79 ms; profiles/r03_fold_outproj.txt), which is one of the
+// reasons those plans run on one stream (forward_enqueue).  BBBP_FOLD_OUTPROJ=0 / bbbp_set_fold_outproj(0) keep the reference's operation order.
 int g_fold_outproj = -1;
 int g_fused_encoder = -1;              // bit 0: row-fused kernels (opt-in); bits 1 / 2: sliced persistent forward / backward for small batches
 int fold_outproj_on() {
-    if (g_fold_outproj < 0) { const char* e = getenv("BBBP_FOLD_OUTPROJ"); g_fold_outproj = e ? (atoi(e) & 3) : 1; }
+    if (g_fold_outproj < 0) { const char* e = getenv("BBBP_FOLD_OUTPROJ"); g_fold_outproj = e ? (atoi(e) & 3) : 3; }
     return g_fold_outproj;
 }
 int fused_encoder_mode() {
@@ -614,7 +614,12 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
     // ---- fingerprint branch: encoder (R:75-78, 110-111), on the side stream -------------------
     Ctx ce = c;
     SideStream* ss = nullptr;
-    if (overlap_enabled()) {
+    // Screening plans (forward-only, 2048+ rows on the bf16 attention kernel) run on ONE stream: there both branches are bound by the matrix
+    // pipe, so the second stream only time-shares it -- measured equal on one box (6.66 / 6.83 ms overlapped, 6.59 / 6.85 one stream) and
+    // WORSE than the sum of the branches on others (7.6 ms against 5.29 + 1.85 + 0.06; profiles/r03_config5_streams.txt); alone, the
+    // encoder also takes the out_proj fold's gain (fold mask bit 1).  BBBP_SCREEN_OVERLAP=1 restores the two-stream schedule.
+    static const bool screen_overlap = [] { const char* e = getenv("BBBP_SCREEN_OVERLAP"); return e && atoi(e) != 0; }();
+    if (overlap_enabled() && (screen_overlap || !plan.attn_b3)) {
         TRY(get_side(&ss));
         TRY(fork_side(c.st, ss));
         ce.st = ss->s;

@@ -330,9 +330,9 @@ int bbbp_set_fused_encoder(int mode);
  * weight block W' = Wo Wv (one launch per step for all layers), the out_proj GEMM leaves the forward chain, its input-gradient GEMM leaves
  * the backward chain, and its weight gradient is unfolded from the in_proj weight gradient's V block (dWo = dW' Wv^T + db' bv^T,
  * d[Wv | bv] = Wo^T [dW' | db'], dbo = column sums).  The same function as nn.TransformerEncoderLayer (...20250113.py:75-78) up to
- * float32 rounding of the reassociated products.  A bit mask, default 1 (initial value BBBP_FOLD_OUTPROJ): bit 0 the launch-per-op
+ * float32 rounding of the reassociated products.  A bit mask, default 3 (initial value BBBP_FOLD_OUTPROJ): bit 0 the launch-per-op
  * schedule with materialised probabilities (training steps, eval batches below 2048 rows); bit 1 also the forward-only split-bf16
- * attention kernel of 2048+ row plans (no dropout there: bo rides in b'; opt-in, measured slower inside the overlapped step); 0 keeps
+ * attention kernel of 2048+ row plans (no dropout there: bo rides in b'; those plans run on one stream); 0 keeps
  * the reference's operation order.  Never applied with the small-head fused attention, the exact-global-batch mode or
  * bbbp_set_fused_encoder != 0.  Changes the workspace layout: set it before bbbp_mixed_workspace_bytes / the forward call of a step.
  * Returns the previous mask. */
