@@ -797,6 +797,49 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
 }
 
 
+// the same sums, four consecutive columns per lane (N, every leading dimension and every base a multiple of 4 floats: the F = 2048
+// encoder's 42 reduce launches per step; 16 K waves of one element each become 4 K waves of one 16-byte access per slab).  Element by
+// element the slabs are added in the same order as above: bit-identical.
+__global__ __launch_bounds__(256) void gemm_splitk_reduce4_kernel(GemmParams p) {
+    BBBP_HIGH_PRIO();
+    const long mn = (long)p.M * p.N, mn4 = mn >> 2;
+    const int batch = blockIdx.y;
+    const float* S = p.slab + (long)batch * p.splits * mn;
+    float* C = p.C + (long)batch * p.sC;
+    const float* R = p.R ? p.R + (long)batch * p.sR : nullptr;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < mn4; q += (long)gridDim.x * 256) {
+        const long idx = q << 2;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 8 <= p.splits; k += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(S + (long)(k + u) * mn + idx);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < p.splits; ++k) s += *reinterpret_cast<const f32x4*>(S + (long)k * mn + idx);
+        const int m = (int)(idx / p.N), n = (int)(idx - (long)m * p.N);
+        const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 gt = {1.f, 1.f, 1.f, 1.f};
+        if (p.gate) gt = *reinterpret_cast<const f32x4*>(p.gate + (long)batch * p.sG + (long)m * p.ldg + n);
+        f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+        if (R) rv = *reinterpret_cast<const f32x4*>(R + (long)m * p.ldr + n);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = apply_act(p.alpha * s[e] + bv[e], p.act);
+            const float gsel = p.gate ? (gt[e] > 0.f ? p.gate_scale : 0.f) : 1.f;
+            if (!p.gate_after) v *= gsel;
+            if (R) v += rv[e];
+            if (p.gate_after) v *= gsel;
+            o[e] = v;
+        }
+        *reinterpret_cast<f32x4*>(C + (long)m * p.ldc + n) = o;
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Latency path for the SMALL GEMMs (the F = 167 encoder: M = 512, N, K in {167, 501, 512, 2048}).
 // Those launches are not bound by MFMA issue or HBM but by the serial chain inside one work-group of the tiled
@@ -1480,6 +1523,15 @@ int gemm_run(hipStream_t st, const bbbp_gemm_desc& g, void* workspace, size_t wo
         long mn = (long)M * N;
         int gx = (int)((mn + 255) / 256);
         if (gx > 4096) gx = 4096;
+        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        static const int vec4_on = [] { const char* e = getenv("BBBP_GEMM_REDUCE_VEC4"); return e ? atoi(e) : 1; }();
+        const bool vec4 = vec4_on && N % 4 == 0 && p.ldc % 4 == 0 && p.sC % 4 == 0 && al16(p.C) && al16(p.slab) && (!p.bias || al16(p.bias)) &&
+                          (!p.R || (p.ldr % 4 == 0 && p.sR % 4 == 0 && al16(p.R))) && (!p.gate || (p.ldg % 4 == 0 && p.sG % 4 == 0 && al16(p.gate)));
+        if (vec4) {
+            int g4 = (int)((mn / 4 + 255) / 256);
+            if (g4 > 4096) g4 = 4096;
+            hipLaunchKernelGGL(gemm_splitk_reduce4_kernel, dim3(g4, batch), dim3(256), g_bbbp_small_lds_pad, st, p);
+        } else
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(gx, batch), dim3(256), g_bbbp_small_lds_pad, st, p);
         BBBP_CHECK_LAUNCH();
     }
