@@ -880,13 +880,16 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
     auto leaf_after = [&](const Ctx& producer) -> int { return ss ? after(ss, producer.st, cl.st) : BBBP_OK; };
     // both LayerNorms' weight / bias gradients of layer l in ONE leaf launch (dgamma = sum_rows dy * xhat, dbeta = sum_rows dy),
     // the last leaf of the layer: its gradient bucket (all twelve tensors, one contiguous slice) is final after it
-    auto layer_norm_leaves = [&](int l) -> int {
+    auto layer_norm_grads = [&](int l) -> int {
         const LayerOff& o = plan.layer[l]; const LayerGrad& g = plan.lgrad[l];
         const PIdx ixl(d);
         const float* dy[2] = {c.f(g.dyout), c.f(g.dy1)}; const float* zz[2] = {c.f(o.z2), c.f(o.z1)};
         const float* mm[2] = {c.f(o.mean2), c.f(o.mean1)}; const float* rr[2] = {c.f(o.rstd2), c.f(o.rstd1)};
         float* dg[2] = {G[ixl.layer(l, L_N2W)], G[ixl.layer(l, L_N1W)]}; float* db[2] = {G[ixl.layer(l, L_N2B)], G[ixl.layer(l, L_N1B)]};
-        TRY(bbbp_ln_param_grad_multi(cl.st, 2, dy, zz, mm, rr, dg, db, plan.B, plan.F));
+        return bbbp_ln_param_grad_multi(cl.st, 2, dy, zz, mm, rr, dg, db, plan.B, plan.F);
+    };
+    auto layer_norm_leaves = [&](int l) -> int {
+        TRY(layer_norm_grads(l));
         return record_layer_bucket(cl.st, l);
     };
     const PIdx ix(d);
@@ -1180,6 +1183,10 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
             Section sg(ce.st, SEC_FFN1_DGRAD);
             TRY(linear_bwd_input(ce, dhff, DFF, P[ix.layer(l, L_W1)], dy1, F, B, DFF, F, dz2, F));
         }
+        // Layer 0 is the end of the pass: whatever its leaves still hold after the chain's last kernel is the step's tail.  Its LayerNorm
+        // parameter gradients only need dyout and dy1, so they start here (one more event) instead of after the attention block.
+        const bool ln_grads_early = l == 0 && ss != nullptr;
+        if (ln_grads_early) { TRY(leaf_after(ce)); TRY(layer_norm_grads(l)); }
         // norm1
         {
             Section sl(ce.st, SEC_LN_BWD);
@@ -1253,7 +1260,8 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
             Section sw(cl.st, SEC_QKV_WGRAD);
             TRY(linear_bwd_weight_bias(cl, dqkv, 3 * F, xin, F, G[ix.layer(l, L_INW)], G[ix.layer(l, L_INB)], B, 3 * F, F));
         }
-        TRY(layer_norm_leaves(l));
+        if (ln_grads_early) TRY(record_layer_bucket(cl.st, l));
+        else TRY(layer_norm_leaves(l));
         if (l > 0 || d->need_input_grad) {
             Section sg(ce.st, SEC_QKV_DGRAD);
             TRY(linear_bwd_input(ce, dqkv, 3 * F, plan.fold ? c.f(plan.fwf[l]) : P[ix.layer(l, L_INW)], l > 0 ? c.f(plan.lgrad[l - 1].dyout) : c.f(plan.dA), F, B, 3 * F, F, dz1, F));

@@ -26,12 +26,13 @@ struct FoldLds {
 // C[r0 + rr][c] = sum_k U[r0 + rr][k] V[k][c] for UR rows and the 64 columns c = c0 + lane: the rows of U sit in LDS (every lane reads the
 // same word: a broadcast), V is read coalesced, K is split over the four waves (each issues its loads KB at a time: the loop is bound by
 // load latency, not by bytes or FMAs) and the partial sums are added in wave order -- bit-reproducible.
-template <class LoadU, class LoadV, class Store>
+// ROW_FAST: consecutive lanes of the LDS fill take consecutive ROWS of U (for a U stored k-major, i.e. read as U^T)
+template <bool ROW_FAST = false, class LoadU, class LoadV, class Store>
 __device__ __forceinline__ void small_product(FoldLds& L, int K, int rows, int cols, int r0, int c0, LoadU lu, LoadV lv, Store st) {
     const int t = threadIdx.x, w = t >> 6, lane = t & 63, c = c0 + lane;
     const int Kp = K + KB;                  // the KB words past K are read (times a zero operand) by the last round: they must be finite
     for (int idx = t; idx < UR * Kp; idx += 256) {
-        const int rr = idx / Kp, k = idx - rr * Kp;
+        const int rr = ROW_FAST ? idx % UR : idx / Kp, k = ROW_FAST ? idx / UR : idx - rr * Kp;
         L.u[rr][k] = (r0 + rr < rows && k < K) ? lu(r0 + rr, k) : 0.f;
     }
     __syncthreads();
@@ -123,6 +124,7 @@ struct UnfoldArgs {
 // work-groups: nrt x ceil(F / 64) tiles of dWo = [dW' | db'] [Wv | bv]^T; nrt x ceil((F + 1) / 64) tiles of d[Wv | bv] = Wo^T [dW' | db'];
 // then 32 columns of dbo = column sums of dz each
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void outproj_unfold_kernel(UnfoldArgs a) {
+    BBBP_HIGH_PRIO();
     __shared__ FoldLds L;
     const int F = a.F, t = threadIdx.x;
     const float* __restrict__ tdw = a.tdw;
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const float* __restrict__ wo = a.wo;
         float* __restrict__ gw = a.g_inw_v;
         float* __restrict__ gb = a.g_inb_v;
-        small_product(L, F, F, F + 1, (b / ncb) * UR, (b % ncb) * 64,
+        small_product<true>(L, F, F, F + 1, (b / ncb) * UR, (b % ncb) * 64,
                       [&](int r, int k) { return wo[(long)k * F + r]; },
                       [&](int k, int c) { return c < F ? tdw[(long)k * F + c] : tdb[k]; },
                       [&](int r, int c, float v) { if (c < F) gw[(long)r * F + c] = v; else gb[r] = v; });
