@@ -15,28 +15,40 @@
 namespace {
 
 constexpr int FOLD_MAX_F = 256;          // a reduction or a row of columns covers at most F + 1 <= 256 elements
-constexpr int UR = 8;                    // output rows per work-group
-constexpr int KB = 10;                   // loads in flight per lane and round (42 k per wave at F = 167); 62 VGPRs, no scratch (14: spills at the 64-VGPR cap)
+constexpr int NW = 8, NT = 64 * NW;      // waves / threads of a work-group: K is split eight ways
+constexpr int UR = 4;                    // output rows per work-group
+constexpr int KB = 7;                    // loads in flight per lane and round (21 k per wave at F = 167: three rounds); 64 VGPRs, no scratch (8+: spills at the cap)
+constexpr int FILL_IT = (UR * (FOLD_MAX_F + KB) + NT - 1) / NT;      // LDS-fill loads per thread, all issued before the first wait
 
 struct FoldLds {
-    float u[UR][FOLD_MAX_F + KB];        // the work-group's UR rows of the row operand, all k
-    float red[4][UR][64];                // the four waves' partial sums
+    float u[8][FOLD_MAX_F + KB];         // rows 0 .. UR-1: the work-group's rows of the row operand, all k (8 rows: the transposing copy)
+    float red[NW][UR][64];               // the waves' partial sums
 };
 
 // C[r0 + rr][c] = sum_k U[r0 + rr][k] V[k][c] for UR rows and the 64 columns c = c0 + lane: the rows of U sit in LDS (every lane reads the
-// same word: a broadcast), V is read coalesced, K is split over the four waves (each issues its loads KB at a time: the loop is bound by
-// load latency, not by bytes or FMAs) and the partial sums are added in wave order -- bit-reproducible.
+// same word: a broadcast), V is read coalesced, K is split over the eight waves and the partial sums are added in wave order --
+// bit-reproducible.  The kernels are bound by load LATENCY (167^3 products, everything L2-resident), so every phase issues all of its
+// loads before it waits: the LDS fill (the first version waited per element: 6 round trips), then KB operand loads per round.
 // ROW_FAST: consecutive lanes of the LDS fill take consecutive ROWS of U (for a U stored k-major, i.e. read as U^T)
 template <bool ROW_FAST = false, class LoadU, class LoadV, class Store>
 __device__ __forceinline__ void small_product(FoldLds& L, int K, int rows, int cols, int r0, int c0, LoadU lu, LoadV lv, Store st) {
     const int t = threadIdx.x, w = t >> 6, lane = t & 63, c = c0 + lane;
     const int Kp = K + KB;                  // the KB words past K are read (times a zero operand) by the last round: they must be finite
-    for (int idx = t; idx < UR * Kp; idx += 256) {
+    float fill[FILL_IT];
+#pragma unroll
+    for (int i = 0; i < FILL_IT; ++i) {
+        const int idx = t + i * NT;
         const int rr = ROW_FAST ? idx % UR : idx / Kp, k = ROW_FAST ? idx / UR : idx - rr * Kp;
-        L.u[rr][k] = (r0 + rr < rows && k < K) ? lu(r0 + rr, k) : 0.f;
+        fill[i] = (idx < UR * Kp && r0 + rr < rows && k < K) ? lu(r0 + rr, k) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < FILL_IT; ++i) {
+        const int idx = t + i * NT;
+        const int rr = ROW_FAST ? idx % UR : idx / Kp, k = ROW_FAST ? idx / UR : idx - rr * Kp;
+        if (idx < UR * Kp) L.u[rr][k] = fill[i];
     }
     __syncthreads();
-    const int kq = (K + 3) / 4, k0 = w * kq, k1 = min(K, k0 + kq);
+    const int kq = (K + NW - 1) / NW, k0 = w * kq, k1 = min(K, k0 + kq);
     const bool c_ok = c < cols;
     float acc[UR];
 #pragma unroll
@@ -56,7 +68,12 @@ __device__ __forceinline__ void small_product(FoldLds& L, int K, int rows, int c
     if (w == 0 && c_ok) {
 #pragma unroll
         for (int rr = 0; rr < UR; ++rr)
-            if (r0 + rr < rows) st(r0 + rr, c, ((L.red[0][rr][lane] + L.red[1][rr][lane]) + L.red[2][rr][lane]) + L.red[3][rr][lane]);
+            if (r0 + rr < rows) {
+                float sum = L.red[0][rr][lane];
+#pragma unroll
+                for (int g = 1; g < NW; ++g) sum += L.red[g][rr][lane];
+                st(r0 + rr, c, sum);
+            }
     }
 }
 
@@ -68,7 +85,7 @@ struct FoldArgs {
 
 // grid (nrt * nct + copy blocks, L), nrt = ceil(F / UR) row tiles, nct = ceil((F + 1) / 64) column tiles of W' | b' = Wo [Wv | bv];
 // the copy blocks write [Wq; Wk | bq; bk] (rows 0 .. 2F-1 of wf | bf) and [Wv | bv]^T (F + 1 rows of F), 8 rows each
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void outproj_fold_kernel(FoldArgs a) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void outproj_fold_kernel(FoldArgs a) {
     BBBP_HIGH_PRIO();
     __shared__ FoldLds L;
     const int l = blockIdx.y, F = a.F, t = threadIdx.x;
@@ -93,7 +110,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     b -= nrt * nct;
     const int ncopy = (2 * F + 7) / 8;
     if (b < ncopy) {
-        for (int idx = t; idx < 8 * (F + 1); idx += 256) {
+        for (int idx = t; idx < 8 * (F + 1); idx += NT) {
             const int r = b * 8 + idx / (F + 1), c = idx % (F + 1);
             if (r < 2 * F) { if (c < F) wf[(long)r * F + c] = win[(long)r * F + c]; else bf[r] = bin[r]; }
         }
@@ -101,12 +118,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     b -= ncopy;
     // [Wv | bv]^T: rows c = 8 b .. + 7 of F columns k; read through LDS so that both sides are coalesced
-    for (int idx = t; idx < 8 * F; idx += 256) {
+    for (int idx = t; idx < 8 * F; idx += NT) {
         const int k = idx / 8, cc = idx % 8, c = b * 8 + cc;
         L.u[cc][k] = c < F ? wv[(long)k * F + c] : (c == F ? bv[k] : 0.f);
     }
     __syncthreads();
-    for (int idx = t; idx < 8 * F; idx += 256) {
+    for (int idx = t; idx < 8 * F; idx += NT) {
         const int cc = idx / F, k = idx % F, c = b * 8 + cc;
         if (c <= F) a.wvt[l][(long)c * F + k] = L.u[cc][k];
     }
@@ -123,7 +140,7 @@ struct UnfoldArgs {
 
 // work-groups: nrt x ceil(F / 64) tiles of dWo = [dW' | db'] [Wv | bv]^T; nrt x ceil((F + 1) / 64) tiles of d[Wv | bv] = Wo^T [dW' | db'];
 // then 32 columns of dbo = column sums of dz each
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void outproj_unfold_kernel(UnfoldArgs a) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void outproj_unfold_kernel(UnfoldArgs a) {
     BBBP_HIGH_PRIO();
     __shared__ FoldLds L;
     const int F = a.F, t = threadIdx.x;
@@ -152,16 +169,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         return;
     }
     b -= nrt * ncb;
+    // column sums of dz: 32 columns per work-group, 16 row groups, added in group order
+    float* part = &L.red[0][0][0];               // [16][32]
     const int cc = t & 31, rg = t >> 5, c = b * 32 + cc;
     float s = 0.f;
     if (c < F)
-        for (int m = rg; m < a.B; m += 8) s += a.dz[(long)m * a.lddz + c];
-    L.red[0][rg][cc] = s;
+        for (int m = rg; m < a.B; m += NT / 32) s += a.dz[(long)m * a.lddz + c];
+    part[rg * 32 + cc] = s;
     __syncthreads();
     if (rg == 0 && c < F) {
         float tot = 0.f;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) tot += L.red[0][g][cc];
+        for (int g = 0; g < NT / 32; ++g) tot += part[g * 32 + cc];
         a.g_outb[c] = tot;
     }
 }
@@ -187,7 +206,7 @@ int bbbp_outproj_fold(hipStream_t st, int layers, int F, const float* const* win
     for (int l = layers; l < 32; ++l) { a.win[l] = a.bin[l] = a.wo[l] = a.bo[l] = nullptr; a.wf[l] = a.bf[l] = a.wvt[l] = nullptr; }
     a.F = F;
     const int nrt = (F + UR - 1) / UR, nct = (F + 1 + 63) / 64;
-    hipLaunchKernelGGL(outproj_fold_kernel, dim3(nrt * nct + (2 * F + 7) / 8 + (F + 1 + 7) / 8, layers), dim3(256), g_bbbp_small_lds_pad, st, a);
+    hipLaunchKernelGGL(outproj_fold_kernel, dim3(nrt * nct + (2 * F + 7) / 8 + (F + 1 + 7) / 8, layers), dim3(NT), g_bbbp_small_lds_pad, st, a);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }
@@ -198,7 +217,7 @@ int bbbp_outproj_unfold(hipStream_t st, int F, int B, const float* tdw, const fl
     BBBP_CHECK_ARG(tdw && tdb && wo && wvt && dz && g_outw && g_outb && g_inw_v && g_inb_v, "outproj_unfold: null pointer");
     UnfoldArgs a{tdw, tdb, wo, wvt, dz, lddz, B, g_outw, g_outb, g_inw_v, g_inb_v, F};
     const int nrt = (F + UR - 1) / UR;
-    hipLaunchKernelGGL(outproj_unfold_kernel, dim3(nrt * ((F + 63) / 64) + nrt * ((F + 1 + 63) / 64) + (F + 31) / 32), dim3(256), g_bbbp_small_lds_pad, st, a);
+    hipLaunchKernelGGL(outproj_unfold_kernel, dim3(nrt * ((F + 63) / 64) + nrt * ((F + 1 + 63) / 64) + (F + 31) / 32), dim3(NT), g_bbbp_small_lds_pad, st, a);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }
