@@ -138,7 +138,7 @@ int make_plan(const bbbp_mixed_desc* d, Plan* p) {
                             (wide && bbbp_attn_wide_supported(p->B, p->NH, p->D)));
     // the fused / sliced encoder schedules (opt-in) and the fused attention kernels keep the reference's operation order
     // (the forward-only split-bf16 attention kernel reads VW where it read V: its rows of P sum to one, so bo rides in b')
-    p->fold = ((fold_outproj_on() & 1) && !p->flash || (fold_outproj_on() & 2) && p->attn_b3) && p->L > 0 && !p->exact && fused_encoder_mode() == 0 &&
+    p->fold = (((fold_outproj_on() & 1) && !p->flash) || ((fold_outproj_on() & 2) && p->attn_b3)) && p->L > 0 && !p->exact && fused_encoder_mode() == 0 &&
               bbbp_outproj_fold_supported(p->F, p->NH, p->L);
     const size_t B = p->B, F = p->F, NH = p->NH, DFF = p->DFF, Bg = p->Bg;
     Bump b;
