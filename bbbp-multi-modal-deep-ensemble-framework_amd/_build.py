@@ -16,6 +16,10 @@ LIB = os.path.join(HERE, "libbbbp_hip.so")
 SOURCES = ["util.hip", "gemm.hip", "conv.hip", "conv_wino.hip", "conv_b3.hip", "conv_b3c1.hip", "rowops.hip", "engine.hip", "encoder.hip", "fold.hip", "attention.hip", "attention_b3.hip", "preprocess.hip", "mlp.hip", "head.hip", "forest.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# per-source flags.  conv_b3c1.hip: the pooling epilogue takes maxima of accumulator registers; in IEEE mode every such operand first gets a
+# quieting `v_max_f32 x, x, x` (two extra vector instructions per maximum in a kernel whose vector issue slots are the budget).  Without the
+# IEEE bit and with finite-math NaN rules the maxima are single instructions; NaN inputs are outside this path's contract.
+EXTRA_FLAGS = {"conv_b3c1.hip": ["-mno-amdgpu-ieee", "-fno-honor-nans"]}
 
 
 def _stale(target: str, deps) -> bool:
@@ -38,8 +42,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src] + hdrs):
-            jobs.append([HIPCC, *FLAGS, "-I", os.path.join(os.path.dirname(HERE), "include"), "-c", src, "-o", obj])
+        if force or _stale(obj, [src, os.path.abspath(__file__)] + hdrs):
+            jobs.append([HIPCC, *FLAGS, *EXTRA_FLAGS.get(s, []), "-I", os.path.join(os.path.dirname(HERE), "include"), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

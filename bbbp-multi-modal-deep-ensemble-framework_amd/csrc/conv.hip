@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
                     int co = cb * COUT + mt * 32 + mfma_row(r + (odd ? 1 : 0), lane);
                     long o = (((long)b * CO_T + co) * Hp + ph) * Wp + ((c0 + j) >> 1);
                     p.y[o] = m > 0.f ? m : 0.f;
-                    p.ymask[o] = m > 0.f ? (uint8_t)am : (uint8_t)4;
+                    if (p.ymask) p.ymask[o] = m > 0.f ? (uint8_t)am : (uint8_t)4;       // null: a forward-only plan keeps no decisions
                 }
             }
         } else {
@@ -846,7 +846,7 @@ extern "C" int bbbp_conv3x3_relu_pool_fwd(void* stream, const float* x, const fl
                                           float* y, uint8_t* mask, int B, int cin, int cout, int H, int W,
                                           void* workspace, size_t workspace_bytes) {
     BBBP_CHECK_ARG(supported(cin, cout, H, W), "conv fwd: unsupported shape cin=%d cout=%d H=%d W=%d", cin, cout, H, W);
-    BBBP_CHECK_ARG(x && w && bias && y && mask && workspace, "conv fwd: null pointer");
+    BBBP_CHECK_ARG(x && w && bias && y && workspace, "conv fwd: null pointer");      // mask may be null: forward-only call, no decisions kept
     if (B == 0) return BBBP_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int cinp = cin < 8 ? 4 : cin;

@@ -268,7 +268,7 @@ __device__ __forceinline__ void conv_b3_body(const B3Params& p) {
                 const int co = mb * 32 + mfma_row(mine, lane);
                 const long o = (((long)b * 64 + co) * (IMG / 2) + ph2) * (IMG / 2) + pw;
                 p.y[o] = act ? best : 0.f;
-                p.ymask[o] = act ? (uint8_t)arg : (uint8_t)4;
+                if (p.ymask) p.ymask[o] = act ? (uint8_t)arg : (uint8_t)4;        // null: a forward-only plan keeps no decisions
             }
         } else {
 #pragma unroll

@@ -25,6 +25,7 @@
 #include "common.h"
 #include "bbbp_hip.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -48,7 +49,9 @@ struct C1Params {
 };
 
 // filters W[co 32][ci 3][tap 9] -> A fragments: k = 16 s + 8 h + e  <->  tap = k / 4, channel = k % 4 (taps >= 9 / channel 3: zero)
-__global__ void c1_prep_kernel(const float* __restrict__ w, uint32_t* __restrict__ wf) {
+// `bias` (pipelined kernel only): rides as one more row of the GEMM -- k = 4 * 4 + 3, the padding channel of the CENTRE tap, whose B
+// operand that kernel keeps at 1.0 for every pixel inside the image -- so the accumulators leave the MFMAs with the bias added.
+__global__ void c1_prep_kernel(const float* __restrict__ w, uint32_t* __restrict__ wf, const float* __restrict__ bias) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;           // (s, lane, pair j)
     if (idx >= 3 * 64 * 4) return;
     const int j = idx & 3, lane = (idx >> 2) & 63, s = idx >> 8;
@@ -57,7 +60,7 @@ __global__ void c1_prep_kernel(const float* __restrict__ w, uint32_t* __restrict
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int k = 16 * s + 8 * h + 2 * j + e, tap = k >> 2, ci = k & 3;
-        v[e] = (tap < 9 && ci < 3) ? w[(m * 3 + ci) * 9 + tap] : 0.f;
+        v[e] = (tap < 9 && ci < 3) ? w[(m * 3 + ci) * 9 + tap] : (bias && tap == 4 && ci == 3) ? bias[m] : 0.f;
     }
     uint32_t hi, mid, lo;
     split2(v[0], v[1], hi, mid, lo);
@@ -66,6 +69,7 @@ __global__ void c1_prep_kernel(const float* __restrict__ w, uint32_t* __restrict
     wf[((s * 3 + 2) * 64 + lane) * 4 + j] = lo;
 }
 
+template <bool MASK>      // MASK = false: a forward-only plan, no pooling decisions are kept (p.ymask is null)
 __global__ __launch_bounds__(256, 2) void conv1_b3_fwd_kernel(C1Params p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
@@ -197,13 +201,12 @@ __global__ __launch_bounds__(256, 2) void conv1_b3_fwd_kernel(C1Params p) {
                 const int co = (q & 3) + 8 * (q >> 2) + 4 * h;
                 const float v0 = acc[0][q], v1 = acc[1][q], v2 = acc[2][q], v3 = acc[3][q];
                 const float m = __builtin_fmaxf(__builtin_fmaxf(v0, v1), __builtin_fmaxf(v2, v3));
-                const int arg = v0 == m ? 0 : v1 == m ? 1 : v2 == m ? 2 : 3;
                 // uniform addresses: the two candidates sit in scalar registers, the lane's half picks one
                 const float bias0 = p.bias[(q & 3) + 8 * (q >> 2)], bias1 = p.bias[(q & 3) + 8 * (q >> 2) + 4];
                 const float best = m + (h ? bias1 : bias0);
                 const bool act = best > 0.f;
                 of[co * 32 + r] = act ? best : 0.f;
-                om[co * 32 + r] = act ? (uint8_t)arg : (uint8_t)4;
+                if (MASK) { const int arg = v0 == m ? 0 : v1 == m ? 1 : v2 == m ? 2 : 3; om[co * 32 + r] = act ? (uint8_t)arg : (uint8_t)4; }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -216,8 +219,10 @@ __global__ __launch_bounds__(256, 2) void conv1_b3_fwd_kernel(C1Params p) {
                     const int i = lane + 64 * j, co = i >> 3, quad = i & 7;
                     *reinterpret_cast<f32x4*>(yb + (long)co * (W1 / 2) * (W1 / 2) + 4 * quad) = *reinterpret_cast<const f32x4*>(of + i * 4);
                 }
-                uint8_t* mbp = p.ymask + ((long)b * 32 * (W1 / 2) + ph2) * (W1 / 2) + 32 * ch;
-                *reinterpret_cast<u32x4*>(mbp + (long)(lane >> 1) * (W1 / 2) * (W1 / 2) + 16 * (lane & 1)) = *reinterpret_cast<const u32x4*>(om + lane * 16);
+                if (MASK) {
+                    uint8_t* mbp = p.ymask + ((long)b * 32 * (W1 / 2) + ph2) * (W1 / 2) + 32 * ch;
+                    *reinterpret_cast<u32x4*>(mbp + (long)(lane >> 1) * (W1 / 2) * (W1 / 2) + 16 * (lane & 1)) = *reinterpret_cast<const u32x4*>(om + lane * 16);
+                }
             }
             __builtin_amdgcn_wave_barrier();     // the staging area is rewritten by the next strip
         }
@@ -227,6 +232,216 @@ __global__ __launch_bounds__(256, 2) void conv1_b3_fwd_kernel(C1Params p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same stage, SOFTWARE-PIPELINED inside every wave (round 4).  In the kernel above a wave runs its phases one after the other
+// (issue the next stage's loads, 72 MFMAs, ~300 vector instructions of pooling epilogue, the split of the next stage, a barrier), and
+// the ablation of round 4 (profiles/r04_c1_ablate.txt, B = 4096: 1.47 ms; without stores 1.19, without MFMAs 0.89, without stage loads
+// 1.04, without all three 0.43) shows the phases ADD: the second work-group of a CU runs in lockstep with the first and hides
+// nothing.  A bf16 MFMA holds its SIMD's vector issue for only 8 of its 32 cycles, so one wave can carry ~5 vector instructions in
+// every MFMA gap for free.  Here ONE instruction stream interleaves, at a skew of half a strip:
+//   first half of strip i  -- the 36 MFMAs of its row-0 tiles (even / odd pixels)  ||  the second half of strip i - 1's pooling epilogue
+//                             (row 1 against the kept row-0 maxima, ReLU, decision byte, staging, 16-byte stores);
+//   second half of strip i -- the 36 MFMAs of its row-1 tiles  ||  the first half of its own epilogue (row-0 maxima of the tiles just
+//                             finished: 16 + 16 kept registers) and the split + LDS writes of strip i + 1's input stage.
+// A tile's accumulators are consumed in the half after they are produced and rewritten in the half after that, so ONE set of 64 accumulator
+// registers serves (a full-strip skew needs two sets and spilled: 320 live registers).  One wave per SIMD keeps the matrix pipe busy by
+// itself, so ONE 4-wave work-group per CU is enough -- which leaves half of every SIMD's register file and 100 KB of LDS to the encoder
+// chain's kernels on the other stream: the form a training step can run beside its chain.
+// The bias rides as one more row of the GEMM (c1_prep_kernel: k = 19, the padding channel of the centre tap, whose B operand this kernel
+// keeps at 1.0 for pixels inside the image): no bias registers, no add.  Same LDS image, filter fragments, tie rule as above.
+// ------------------------------------------------------------------------------------------------------------------------------
+#define C1P_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+// max(a, b) as ONE instruction: fmaxf quiets signalling NaNs first (a v_max_f32 x, x, x per operand that is not known canonical -- every
+// accumulator register), v_med3_f32 with +inf does not.  For a NaN operand it returns the other one or +inf instead of fmaxf's "the
+// non-NaN operand": inputs with NaNs are outside this path's contract either way (PyTorch would propagate the NaN).
+__device__ __forceinline__ float fmax_raw(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_huge_valf()); }
+
+template <bool MASK>
+__global__ __launch_bounds__(256, 2) void conv1_b3p_fwd_kernel(C1Params p) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    const int nstrips = p.B * (W1 / R1);
+    const int stride = gridDim.x;
+    const int first = xcd_adjacent(blockIdx.x, gridDim.x);
+    if (first >= nstrips) return;                                    // uniform: the whole work-group leaves
+    const int n = (nstrips - first + stride - 1) / stride;           // strips of this work-group
+    const int last_strip = first + (n - 1) * stride;
+
+    bf16x8 a[3][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            a[s][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p.wfrag + ((s * 3 + pl) * 64 + lane) * 4));
+
+    for (int i = t * 8; i < 2 * XBUF1; i += 256 * 8) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0, 0, 0, 0};
+
+    // ---- stage loader: item i of thread t = pixel (row t / 128 + 2 i, x = t % 128) ----
+    constexpr int NIT = ROWS1 * W1 / 256;                            // 3
+    const int px = t & (W1 - 1), row0 = t >> 7, par = px & 1;
+    const int loff0 = (row0 * PXW1 + par * 65 + (px >> 1) + par) * 4;
+    float xr[NIT][3];
+    uint32_t okbits = 0;
+    auto load_stage = [&](int strip) __attribute__((always_inline)) {
+        const int b = strip / (W1 / R1), h0 = (strip % (W1 / R1)) * R1;
+        // uniform 64-bit bases (one per channel plane) + ONE 32-bit per-lane byte offset per item: no 64-bit vector address arithmetic
+        const char* xb = reinterpret_cast<const char*>(p.x + (long)b * 3 * W1 * W1);
+        okbits = 0;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int yr = h0 - 1 + row0 + 2 * i;
+            const int yy = min(max(yr, 0), W1 - 1);
+            okbits |= (yr >= 0 && yr < W1 ? 1u : 0u) << i;
+            const unsigned o = 4u * (unsigned)(yy * W1 + px);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) xr[i][c] = *reinterpret_cast<const float*>(xb + (size_t)c * (W1 * W1 * 4) + (size_t)o);
+        }
+    };
+    auto store_item = [&](uint16_t* Xs, int i) __attribute__((always_inline)) {
+        const bool ok = (okbits >> i) & 1u;
+        uint32_t h01, m01, l01, h2, m2, l2;
+        split2(ok ? xr[i][0] : 0.f, ok ? xr[i][1] : 0.f, h01, m01, l01);
+        split2(ok ? xr[i][2] : 0.f, ok ? 1.f : 0.f, h2, m2, l2);     // the padding channel carries 1.0: the bias row of the filters
+        uint16_t* d = Xs + loff0 + i * (2 * PXW1 * 4);
+        *reinterpret_cast<u32x2*>(d) = u32x2{h01, h2};
+        *reinterpret_cast<u32x2*>(d + XPL1) = u32x2{m01, m2};
+        *reinterpret_cast<u32x2*>(d + 2 * XPL1) = u32x2{l01, l2};
+    };
+
+    const int rp = wave >> 1, ch = wave & 1;
+    int toff[2][3][2];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int tap = min(4 * s + 2 * h + j, 8), dy1 = tap / 3, dx = tap % 3 - 1;
+            const int ev = dx == 0 ? 32 * ch + r : 65 + 32 * ch + r + (dx > 0 ? 1 : 0);
+            const int od = dx == 0 ? 65 + 32 * ch + r + 1 : 32 * ch + r + (dx > 0 ? 1 : 0);
+            toff[0][s][j] = (dy1 * PXW1 + ev) * 4;
+            toff[1][s][j] = (dy1 * PXW1 + od) * 4;
+        }
+    float* const of = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + (size_t)2 * XBUF1 * 2 + wave * OUT_WAVE_BYTES);
+    uint8_t* const om = reinterpret_cast<uint8_t*>(of + 32 * 32);
+
+    __syncthreads();                                                 // the zero fill
+    load_stage(first);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) store_item(smem, i);
+    __syncthreads();
+
+    f32x16 acc[4];                                                   // [row * 2 + pixel parity]
+    float m01[16];                                                   // max over row 0 of the window, per accumulator register
+    uint32_t a01[MASK ? 16 : 1];                                     // its position (0 / 1)
+
+    // One pipeline step.  MMA: the MFMAs of strip `strip` (LDS stage `cur`); EPI: the second epilogue half of the strip before it.
+    auto step = [&](auto MMAc, auto EPIc, int strip, int cur) __attribute__((always_inline)) {
+        constexpr bool MMA = decltype(MMAc)::value, EPI = decltype(EPIc)::value;
+        const int pstrip = MMA ? strip - stride : strip;             // the strip whose results leave in this step
+        const int pb = pstrip / (W1 / R1), ph0 = (pstrip % (W1 / R1)) * R1;
+        if (MMA) load_stage(min(strip + stride, last_strip));       // unconditional (clamped): a branch here would split the schedule
+        const uint16_t* Xs = smem + cur * XBUF1 + (2 * rp) * PXW1 * 4;
+        uint16_t* Xn = smem + (cur ^ 1) * XBUF1;
+        bf16x8 bq[2][3];
+        auto fetch = [&](int blk, int slot) __attribute__((always_inline)) {
+            const int nt = blk / 3, s = blk % 3;
+            const uint16_t* base = Xs + (nt >> 1) * PXW1 * 4;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(base + pl * XPL1 + toff[nt & 1][s][0]);
+                const u32x2 hi = *reinterpret_cast<const u32x2*>(base + pl * XPL1 + toff[nt & 1][s][1]);
+                bq[slot][pl] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+            }
+        };
+        // first epilogue half (row 0 of the window: tiles 0, 1), PyTorch scan order: the later pixel only if strictly larger
+        auto epi_a = [&](int q) __attribute__((always_inline)) {
+            const float v0 = acc[0][q], v1 = acc[1][q];
+            m01[q] = fmax_raw(v0, v1);
+            if (MASK) a01[q] = v1 > v0 ? 1u : 0u;
+        };
+        // second half (row 1: tiles 2, 3): the lower row only if strictly larger; ReLU; 4 = inactive
+        auto epi_b = [&](int q) __attribute__((always_inline)) {
+            const int co = (q & 3) + 8 * (q >> 2) + 4 * h;
+            const float v2 = acc[2][q], v3 = acc[3][q];
+            const float m23 = fmax_raw(v2, v3);
+            const float best = fmax_raw(m01[q], m23);                // bias included (filter row k = 19)
+            of[co * 32 + r] = fmax_raw(best, 0.f);
+            if (MASK) {
+                const uint32_t a23 = v3 > v2 ? 3u : 2u;
+                const uint32_t arg = m23 > m01[q] ? a23 : a01[q];
+                om[co * 32 + r] = best > 0.f ? (uint8_t)arg : (uint8_t)4;
+            }
+        };
+        auto epi_out = [&]() __attribute__((always_inline)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int ph2 = (ph0 >> 1) + rp;
+            float* yb = p.y + ((long)pb * 32 * (W1 / 2) + ph2) * (W1 / 2) + 32 * ch;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = lane + 64 * j, co = i >> 3, quad = i & 7;
+                *reinterpret_cast<f32x4*>(yb + (long)co * (W1 / 2) * (W1 / 2) + 4 * quad) = *reinterpret_cast<const f32x4*>(of + i * 4);
+            }
+            if (MASK) {
+                uint8_t* mbp = p.ymask + ((long)pb * 32 * (W1 / 2) + ph2) * (W1 / 2) + 32 * ch;
+                *reinterpret_cast<u32x4*>(mbp + (long)(lane >> 1) * (W1 / 2) * (W1 / 2) + 16 * (lane & 1)) = *reinterpret_cast<const u32x4*>(om + lane * 16);
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        constexpr int QB[6] = {0, 4, 7, 10, 13, 16};                  // epilogue B: registers [QB[blk], QB[blk + 1]) ride in block blk = 0..4
+        constexpr int QA[4] = {0, 6, 11, 16};                         // epilogue A: blocks 6..8
+        if (MMA) {
+            fetch(0, 0);
+#pragma unroll
+            for (int blk = 0; blk < 12; ++blk) {
+                const int sl = blk & 1, nt = blk / 3, s = blk % 3;
+                if (blk + 1 < 12) fetch(blk + 1, sl ^ 1);
+                f32x16 c0;
+                if (s == 0) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) c0[q] = 0.f;         // folds into the instruction's inline zero
+                } else c0 = acc[nt];
+                // small terms first, the leading product last
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], bq[sl][1], c0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][2], bq[sl][0], c0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], bq[sl][2], c0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], bq[sl][0], c0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], bq[sl][1], c0, 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], bq[sl][0], c0, 0, 0, 0);
+                if (EPI && blk < 5) {
+#pragma unroll
+                    for (int q = QB[blk]; q < QB[blk + 1]; ++q) epi_b(q);
+                }
+                if (EPI && blk == 5) epi_out();
+                if (blk >= 6 && blk < 9) {
+#pragma unroll
+                    for (int q = QA[blk - 6]; q < QA[blk - 5]; ++q) epi_a(q);
+                }
+                if (blk >= 9) store_item(Xn, blk - 9);
+                // issue order of the block: behind every MFMA up to two LDS accesses, six vector instructions and one global access
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    C1P_SGB(0x008, 1);
+                    C1P_SGB(0x080, 2);
+                    C1P_SGB(0x002, 6);
+                    C1P_SGB(0x010, 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);                   // nothing is hoisted across blocks (register pressure)
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS only: the epilogue's global stores stay in flight
+        } else if (EPI) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) epi_b(q);
+            epi_out();
+        }
+    };
+    using T = std::true_type; using Fa = std::false_type;
+    step(T{}, Fa{}, first, 0);
+    for (int i = 1; i < n; ++i) step(T{}, T{}, first + i * stride, i & 1);
+    step(Fa{}, T{}, last_strip, 0);
+}
+
 }  // namespace
 
 // workspace: WFRAG_WORDS uint32 of pre-split filter fragments (9 KB)
@@ -234,7 +449,8 @@ size_t bbbp_b3_conv1_fwd_workspace_bytes() { return (size_t)WFRAG_WORDS * sizeof
 
 int bbbp_b3_conv1_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* y, uint8_t* mask, int B, void* workspace) {
     uint32_t* wf = static_cast<uint32_t*>(workspace);
-    hipLaunchKernelGGL(c1_prep_kernel, dim3(3), dim3(256), 0, st, w, wf);
+    static const int pipe = [] { const char* e = getenv("BBBP_C1_PIPE"); return e ? atoi(e) : 0; }();     // round 4: 1 = the software-pipelined form (0: round 3's kernel)
+    hipLaunchKernelGGL(c1_prep_kernel, dim3(3), dim3(256), 0, st, w, wf, pipe ? bias : nullptr);
     BBBP_CHECK_LAUNCH();
     static const int exp_bits = [] { const char* e = getenv("BBBP_C1_EXP"); return e ? atoi(e) : 0; }();
     C1Params p{x, wf, bias, y, mask, B, exp_bits};
@@ -244,7 +460,11 @@ int bbbp_b3_conv1_fwd(hipStream_t st, const float* x, const float* w, const floa
     if (grid >= 8) grid -= grid % 8;
     if (grid > nstrips) grid = nstrips;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(conv1_b3_fwd_kernel, dim3(grid), dim3(256), LDS1_BYTES, st, p);
+    if (pipe) {
+        if (mask) hipLaunchKernelGGL(conv1_b3p_fwd_kernel<true>, dim3(grid), dim3(256), LDS1_BYTES, st, p);
+        else hipLaunchKernelGGL(conv1_b3p_fwd_kernel<false>, dim3(grid), dim3(256), LDS1_BYTES, st, p);
+    } else if (mask) hipLaunchKernelGGL(conv1_b3_fwd_kernel<true>, dim3(grid), dim3(256), LDS1_BYTES, st, p);
+    else hipLaunchKernelGGL(conv1_b3_fwd_kernel<false>, dim3(grid), dim3(256), LDS1_BYTES, st, p);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }

@@ -245,7 +245,7 @@ __device__ __forceinline__ void wino_conv_body(const WinoParams& p) {
                 if (v11 > m) { m = v11; am = 3; }
                 const long o = (((long)b * MOUT + co) * (IMG / 2) + (h0 >> 1) + wave) * (IMG / 2) + j;
                 p.y[o] = m > 0.f ? m : 0.f;
-                p.ymask[o] = m > 0.f ? (uint8_t)am : (uint8_t)4;
+                if (p.ymask) p.ymask[o] = m > 0.f ? (uint8_t)am : (uint8_t)4;
             } else {
                 float* o = p.y + (((long)b * MOUT + co) * IMG + h0 + 2 * wave) * IMG + 2 * j;
                 *reinterpret_cast<float2*>(o) = make_float2(v00, v01);

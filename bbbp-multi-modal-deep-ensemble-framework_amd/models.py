@@ -375,6 +375,11 @@ class MixedInputModel(nn.Module):
         world, rank = 0, 0
         if getattr(self, "exact_batch", False):
             _, world, rank = _exact_batch_group(self)
+            # the kernels index their Philox streams by LOCAL row; ranks that seed the host RNG alike (the usual same-init setup) would
+            # otherwise draw the SAME masks for local row i on every rank, which no single-GPU step at the global batch does: the rank
+            # is mixed into the call's seed
+            if seed and rank:
+                seed = (seed + rank * 0x9E3779B97F4A7C15) & (2 ** 62 - 1) or 1
         return _lib.MixedDesc(batch=batch, fingerprint_size=self.fingerprint_size, nhead=self.nhead, num_layers=layers,
                               dim_feedforward=dff, training=int(training), dropout_p=p, seed=seed, need_input_grad=0,
                               fusion=0 if self.FUSION == "attention" else 1, inference=int(inference and not training),

@@ -153,7 +153,9 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return gemm(x, weight, trans_b=True, bias=bias, act=act, residual=residual, out=out)
 
 
-def conv3x3_relu_pool_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+def conv3x3_relu_pool_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, keep_mask: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """``keep_mask=False``: a forward-only call -- no pooling decisions are written (the C entry takes a null mask) and None is returned
+    in their place."""
     _chk(x, "x"); _chk(w, "weight"); _chk(b, "bias")
     if not (x.is_contiguous() and w.is_contiguous() and b.is_contiguous()):
         raise RuntimeError("conv3x3_relu_pool: operands must be contiguous (NCHW)")
@@ -162,12 +164,12 @@ def conv3x3_relu_pool_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> 
     if tuple(w.shape) != (cout, cin, 3, 3):
         raise RuntimeError(f"conv3x3_relu_pool: weight shape {tuple(w.shape)} does not match input channels {cin}")
     y = torch.empty((B, cout, H // 2, W // 2), device=x.device, dtype=torch.float32)
-    mask = torch.empty((B, cout, H // 2, W // 2), device=x.device, dtype=torch.uint8)
+    mask = torch.empty((B, cout, H // 2, W // 2), device=x.device, dtype=torch.uint8) if keep_mask else None
     L = _lib.lib()
     wsb = L.bbbp_conv3x3_workspace_bytes(B, cin, cout, H, W)
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
     _lib.check(L.bbbp_conv3x3_relu_pool_fwd(_stream(), x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
-                                            mask.data_ptr(), B, cin, cout, H, W, ws.data_ptr(), wsb),
+                                            mask.data_ptr() if keep_mask else None, B, cin, cout, H, W, ws.data_ptr(), wsb),
                "bbbp_conv3x3_relu_pool_fwd")
     return y, mask
 

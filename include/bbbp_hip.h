@@ -83,7 +83,8 @@ int bbbp_gemm_f32_grouped(void* stream, const bbbp_gemm_desc* problems, int coun
 /* ---- Conv2d(k3,s1,p1) + ReLU + MaxPool2d(2,2), NCHW ------------------------------------------
  * forward: R:85-87 (3->32, 128x128) and R:88-90 (32->64, 64x64).  y is the pooled output,
  * mask[B][cout][H/2][W/2] (u8) records the arg-max of each 2x2 window (0..3, PyTorch first-max order)
- * or 4 where the ReLU is inactive; backward consumes it instead of the pre-pool activation.
+ * or 4 where the ReLU is inactive; backward consumes it instead of the pre-pool activation.  The forward's `mask` may be NULL
+ * (round 4): a forward-only call (eval loop R:195-203, screening) keeps no decisions -- the engine's inference plans pass NULL.
  * bwd_data / bwd_weight: autograd of the same statements under loss.backward() (R:190). */
 size_t bbbp_conv3x3_workspace_bytes(int B, int cin, int cout, int H, int W);
 /* Measurement aid (bench.py): shader-clock cycles and 100 MHz wall ticks that work-group 0 of the most recent

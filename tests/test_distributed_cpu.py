@@ -133,3 +133,38 @@ def test_shard_batch_edges():
     assert [shard_batch(10, r, 4) for r in range(4)] == [slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 10)]
     assert shard_batch(2, 3, 4) == slice(2, 2)
     assert shard_batch(512, 7, 8) == slice(448, 512)
+
+
+def _exact_seed_worker(rank, world, port):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bbbp_amd import distributed as D
+    from bbbp_amd.variants import ExactBatchMixedInputModel
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    D.init("gloo")
+    torch.manual_seed(20250113)                          # every rank seeds the host RNG alike, as bench.py and same-init setups do
+    model = ExactBatchMixedInputModel(64, 128).train()
+    seeds = [int(model._descriptor(8).seed) for _ in range(3)]
+    model.eval()
+    eval_seed = int(model._descriptor(8).seed)
+    dist.barrier()
+    dist.destroy_process_group()
+    return rank, seeds, eval_seed
+
+
+def test_exact_batch_ranks_draw_different_dropout_seeds_on_gloo_world2():
+    """in exact-global-batch mode every rank took its dropout seed from an identically seeded host RNG and the kernels
+    index their Philox streams by LOCAL row, so local row i drew the same masks on every rank.  The rank is now mixed into the call's
+    seed: same host stream on both ranks, different seeds in their descriptors; rank 0 keeps the host stream's value (the single-process
+    behaviour); eval-mode descriptors carry no seed."""
+    from helpers import run_ranks
+    res = sorted(run_ranks(_exact_seed_worker, 2, timeout=180))
+    (r0, s0, e0), (r1, s1, e1) = res
+    assert (r0, r1) == (0, 1) and e0 == 0 and e1 == 0
+    assert all(a != b for a, b in zip(s0, s1)) and len(set(s0 + s1)) == 6
+    torch.manual_seed(20250113)
+    from bbbp_amd.variants import ExactBatchMixedInputModel
+    ExactBatchMixedInputModel(64, 128)                   # consumes the same init stream
+    want = [int(torch.randint(0, 2 ** 62, (1,)).item()) for _ in range(3)]
+    assert s0 == want
+    assert s1 == [((w + 0x9E3779B97F4A7C15) & (2 ** 62 - 1)) or 1 for w in want]

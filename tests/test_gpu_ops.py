@@ -320,6 +320,23 @@ def test_conv_many_strips_persistent_loop(dev, conv2_algo):
     _conv_case(dev, 24, 3, 32, 128, seed=42)
 
 
+@pytest.mark.parametrize("form", [0, 3, 28, 64], ids=["f32", "winograd", "split-bf16", "split-bf16-conv1"])
+def test_conv_forward_without_mask_equals_forward_with_mask(dev, form):
+    """Forward-only plans (eval loop, screening) pass a NULL mask: the pooled activations are bit-identical to the training call's and
+    nothing is written where the decisions would go (every forward form: conv.hip, conv_wino.hip, conv_b3.hip, conv_b3c1.hip)."""
+    L = _lib.lib()
+    old = L.bbbp_get_conv_winograd()
+    try:
+        L.bbbp_set_conv_winograd(form)
+        for cin, cout, hw, B in ((3, 32, 128, 5), (32, 64, 64, 3)):
+            x, w, b = rnd(B, cin, hw, hw, seed=7).to(dev), rnd(cout, cin, 3, 3, seed=8, scale=0.2).to(dev), rnd(cout, seed=9, scale=0.1).to(dev)
+            y0, m0 = ops.conv3x3_relu_pool_fwd(x, w, b)
+            y1, m1 = ops.conv3x3_relu_pool_fwd(x, w, b, keep_mask=False)
+            assert m1 is None and m0 is not None and torch.equal(y0, y1)
+    finally:
+        L.bbbp_set_conv_winograd(old)
+
+
 def test_conv_rejects_unsupported(dev):
     with pytest.raises(RuntimeError):
         ops.conv3x3_relu_pool_fwd(torch.zeros(1, 5, 64, 64, device=dev), torch.zeros(8, 5, 3, 3, device=dev), torch.zeros(8, device=dev))

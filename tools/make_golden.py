@@ -283,6 +283,107 @@ def case_oof_f64():
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
 
 
+def b3db_inputs():
+    """The B3DB-scale acceptance set: every molecule of B3DB_regression.tsv that has a drawing under
+    Descriptors/img_output (1 058), in NO. order; image = the reference's own pipeline (convert('RGB') -> Resize((128,128)) -> ToTensor
+    -> flatten, ...fixed_1.py:56-71) kept as the resized uint8 bytes; label = the file's logBB; fingerprint = SYNTHETIC MACCS-shaped bits
+    (RDKit is absent): bit 0 always 0, bits 1..24 drawn with a probability that depends on the standardised label (so the encoder
+    branch has something to learn), the rest Bernoulli(0.25).  Returns (numbers [N], images_u8 [N,128,128,3], bits_u8 [N,167], logBB [N])."""
+    import csv
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from oracle import preprocess_cpu
+    rows = list(csv.DictReader(open(os.path.join(REF, "B3DB/B3DB/B3DB_regression.tsv"), encoding="utf-8"), delimiter="\t"))
+    nos, imgs, ys = [], [], []
+    for r in rows:
+        path = os.path.join(REF, "Descriptors/img_output", f"{int(r['NO.'])}.png")
+        if os.path.exists(path):
+            nos.append(int(r["NO."])); imgs.append(preprocess_cpu.resized_bytes(path)); ys.append(float(r["logBB"]))
+    nos = np.asarray(nos, dtype=np.int64); imgs = np.stack(imgs); ys = np.asarray(ys, dtype=np.float64)
+    rng = np.random.default_rng(167)
+    z = (ys - ys.mean()) / ys.std()
+    p = np.full((len(ys), 167), 0.25)
+    w = rng.choice([-1.2, 1.2], size=24)
+    p[:, 1:25] = 1.0 / (1.0 + np.exp(-(w[None, :] * z[:, None] - 1.1)))
+    bits = (rng.random((len(ys), 167)) < p).astype(np.uint8)
+    bits[:, 0] = 0
+    return nos, imgs, bits, ys
+
+
+def case_b3db_oof(epochs=10, batch_size=32, init_seed=4200):
+    """R^2 / MSE acceptance at B3DB scale (north_star: "R^2/MSE within +-0.002 of reference"): the published fold loop
+    (...20250113.py:146-241: KFold(10, shuffle, random_state=42), a fresh MixedInputModel + AdamW(1e-4, wd 1e-5) per fold, batch 32,
+    model.train() ONCE before the epoch loop and the per-epoch validation pass leaving it in eval() -- the faithful quirk) run with the
+    REFERENCE'S OWN CLASS and torch.optim.AdamW on the CPU, once in float32 (the reference's precision) and once in float64 (the
+    yardstick), 10 epochs, dropout zeroed (no cross-implementation parity for dropout masks), batch orders from default_rng(5).
+    Writes tests/golden/b3db_images_u8.npz (the resized bytes + labels + synthetic bits: DATA) and tests/golden/b3db_oof.npz
+    (per-fold held-out predictions and losses of both runs, R^2 / MSE)."""
+    from sklearn.model_selection import KFold
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from oracle import preprocess_cpu
+    ns = load_classes("Models/multi_input_data_regression_opt_transformer_cnn_20250113.py",
+                      {"MixedDataset", "MultiHeadAttentionFusion", "MixedInputModel"})
+    nos, imgs_u8, bits, ys = b3db_inputs()
+    N = len(ys)
+    np.savez_compressed(os.path.join(OUT, "b3db_images_u8.npz"), numbers=nos, images_u8=imgs_u8, bits_u8=bits, logBB=ys)
+    flat = (imgs_u8.transpose(0, 3, 1, 2).astype(np.float32) / np.float32(255.0)).reshape(N, -1)
+    fp_n, img_n = preprocess_cpu.standardize_features(bits, flat)            # ...fixed_1.py:86-101 (chunks of 100)
+    folds = list(KFold(10, shuffle=True, random_state=42).split(np.arange(N)))
+    rng = np.random.default_rng(5)
+    orders = [[rng.permutation(len(tr)) for _ in range(epochs)] for tr, _ in folds]
+    out = {"meta/N": np.array(N), "meta/F": np.array(167), "meta/batch_size": np.array(batch_size), "meta/epochs": np.array(epochs),
+           "meta/init_seed": np.array(init_seed), "meta/order_seed": np.array(5),
+           "inputs/checksum": np.array([float(fp_n.astype(np.float64).sum()), float(img_n.astype(np.float64).sum()), float(ys.sum())])}
+    crit = nn.MSELoss()
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        fp_t, img_t = torch.from_numpy(fp_n).to(dt), torch.from_numpy(img_n).to(dt)
+        y_t = torch.from_numpy(ys).to(torch.float32).to(dt)                   # MixedDataset casts labels to float32 (:44)
+        preds_all = np.zeros(N)
+        for k, (tr, te) in enumerate(folds):
+            torch.manual_seed(init_seed + k)
+            model = ns["MixedInputModel"](167, 128)
+            zero_dropout(model)
+            if tag == "f32":
+                sd = model.state_dict()
+                out[f"fold{k}/param_checksum"] = np.array([sum(float(v.double().sum()) for v in sd.values() if v.dtype.is_floating_point),
+                                                           sum(float(v.double().abs().sum()) for v in sd.values() if v.dtype.is_floating_point)])
+                out[f"fold{k}/test_idx"] = np.asarray(te, dtype=np.int64)
+            model = model.to(dt)
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5)
+            tr_t, te_t = torch.as_tensor(tr), torch.as_tensor(te)
+            losses, vals = [], []
+            model.train()
+            for ep in range(epochs):
+                tot, nb = 0.0, 0
+                for i in range(0, len(tr), batch_size):
+                    idx = tr_t[torch.as_tensor(orders[k][ep][i:i + batch_size])]
+                    opt.zero_grad()
+                    loss = crit(model(fp_t[idx], img_t[idx]).squeeze(), y_t[idx])
+                    loss.backward()
+                    opt.step()
+                    tot += loss.item(); nb += 1
+                model.eval()
+                with torch.no_grad():
+                    vl, vb = 0.0, 0
+                    for i in range(0, len(te), batch_size):
+                        idx = te_t[i:i + batch_size]
+                        vl += crit(model(fp_t[idx], img_t[idx]).squeeze(), y_t[idx]).item(); vb += 1
+                losses.append(tot / nb); vals.append(vl / vb)
+            with torch.no_grad():
+                pr = torch.cat([model(fp_t[te_t[i:i + batch_size]], img_t[te_t[i:i + batch_size]]).reshape(-1) for i in range(0, len(te), batch_size)])
+            preds_all[te] = pr.double().numpy()
+            out[f"fold{k}/train_loss_{tag}"] = np.asarray(losses); out[f"fold{k}/val_loss_{tag}"] = np.asarray(vals)
+            print(f"b3db_oof {tag} fold {k}: train {losses} val {vals}", flush=True)
+        out[f"nn_{tag}"] = preds_all
+        yt = y_t.double().numpy()
+        mse = float(((yt - preds_all) ** 2).mean()); r2 = 1.0 - float(((yt - preds_all) ** 2).sum()) / float(((yt - yt.mean()) ** 2).sum())
+        out[f"metrics_{tag}"] = np.array([r2, mse])
+        print(f"b3db_oof {tag}: R2 {r2:.6f} MSE {mse:.6f}", flush=True)
+        np.savez_compressed(os.path.join(OUT, "b3db_oof.npz"), **out)
+    print("wrote b3db_oof.npz")
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
@@ -333,6 +434,8 @@ def main():
         case_xgb_head()
     if not only or "oof_f64" in only:
         case_oof_f64()
+    if "b3db_oof" in only:                        # ~1 h of CPU: only on request
+        case_b3db_oof()
 
 
 if __name__ == "__main__":
