@@ -83,6 +83,9 @@ _SIGNATURES = {
     "bbbp_linear_layernorm_supported": (c_int, [c_int, c_int, c_int]),
     "bbbp_linear_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_uint64]),
+    "bbbp_layernorm_linear_supported": (c_int, [c_int, c_int, c_int]),
+    "bbbp_layernorm_linear_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
+                                  c_uint64, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int]),
     "bbbp_forest_groups": (c_int, [c_int]),
     "bbbp_forest_predict": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_void_p]),
@@ -122,6 +125,7 @@ _SIGNATURES = {
                                               c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
     "bbbp_standardize_chunk": (c_int, [c_void_p, c_void_p, _FP, _FP, _FP, c_void_p, c_void_p, c_int, c_int, c_int]),
     "bbbp_set_partition": (c_int, [c_int, c_size_t]),
+    "bbbp_set_comm_cus": (c_int, [c_int]),
     "bbbp_set_overlap": (c_int, [c_int]),
     "bbbp_profile_enable": (c_int, [c_int]),
     "bbbp_profile_select": (c_int, [ctypes.c_uint]),

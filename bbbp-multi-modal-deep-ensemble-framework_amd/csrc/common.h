@@ -53,6 +53,10 @@ extern thread_local size_t g_bbbp_small_lds_pad;
 // at B = 512) but holds 2 x 248 registers per lane slot on every SIMD, and the forward pass of that step is bound by the encoder's
 // latency chain, which then finds no wave slots (measured: conv1 0.31 -> 0.20 ms in-step, encoder forward 1.21 -> 1.33, step 2.61 -> 2.70)
 extern thread_local int g_bbbp_conv1_fwd_f32;
+// engine scope: work-groups per CU for the split-bf16 conv1 forward (0 = the kernel's own default).  The software-pipelined form keeps the
+// matrix pipe busy with ONE wave per SIMD, so beside an encoder chain the engine asks for one work-group per CU (half the register file and
+// 100 KB of LDS stay free for the chain's kernels)
+extern thread_local int g_bbbp_conv1_fwd_per_cu;
 // conv2's weight gradient on the structured-sparse MFMA (conv_b3.hip: conv_b3_wgrad_sp_kernel) has an 8-wave form (fastest alone: two waves
 // of 256 registers per SIMD) and a 4-wave form that leaves ~200 registers per lane slot to the fingerprint branch's kernels; the engine
 // asks for the latter while an encoder chain runs beside the image branch (0 = no preference: 8 waves)
@@ -119,6 +123,8 @@ size_t bbbp_b3_conv1_fwd_workspace_bytes();
 int bbbp_b3_conv1_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* y, uint8_t* mask, int B, void* workspace);
 int bbbp_b3_conv1_wgrad(hipStream_t st, const float* x, const float* gy, const uint8_t* mask, float* slab, float* bslab, int B, int grid);
 int bbbp_wino_last_phases(unsigned long long* phases4);     // BBBP_WINO_PROBE=1 builds of the kernel only
+// gemm.hip: LayerNorm absorbed by the consuming Linear (bbbp_layernorm_linear_fwd) -- is that the faster form for this product?
+bool bbbp_layernorm_linear_preferred(int M, int N, int K);
 // fold.hip: out_proj folded into the value projection of a one-head encoder layer (W' = Wo Wv, b' = Wo bv) and the gradients unfolded
 bool bbbp_outproj_fold_supported(int F, int nhead, int layers);
 size_t bbbp_outproj_fold_floats(int F, int which);          // 0 wf [3F][F], 1 bf [3F], 2 wvt [F + 1][F], 3 tdw [F][F], 4 tdb [F]

@@ -454,7 +454,8 @@ int bbbp_b3_conv1_fwd(hipStream_t st, const float* x, const float* w, const floa
     BBBP_CHECK_LAUNCH();
     static const int exp_bits = [] { const char* e = getenv("BBBP_C1_EXP"); return e ? atoi(e) : 0; }();
     C1Params p{x, wf, bias, y, mask, B, exp_bits};
-    static const int per_cu = [] { const char* e = getenv("BBBP_C1_PER_CU"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+    static const int per_cu_env = [] { const char* e = getenv("BBBP_C1_PER_CU"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+    const int per_cu = g_bbbp_conv1_fwd_per_cu > 0 ? g_bbbp_conv1_fwd_per_cu : per_cu_env;
     const int nstrips = B * (W1 / R1);
     int grid = bbbp_num_cus() * per_cu;
     if (grid >= 8) grid -= grid % 8;

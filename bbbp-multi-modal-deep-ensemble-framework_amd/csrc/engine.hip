@@ -637,10 +637,14 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         // beside a training step's encoder chain the f32 form stays (common.h: g_bbbp_conv1_fwd_f32); screening batches, eval loops and
         // the encoder-less two-branch model take the split-bf16 form when the conv mask selects it (bit 6, default)
         // (the rule looks at the plan only, not at the stream mode: one stream or three give bit-identical steps)
-        g_bbbp_conv1_fwd_f32 = (!plan.inference && plan.L > 0) ? 1 : 0;
+        // round 4: BBBP_C1_TRAIN=1 runs the software-pipelined split-bf16 kernel (conv_b3c1.hip) in training steps too, ONE work-group per CU
+        static const int c1_train = [] { const char* e = getenv("BBBP_C1_TRAIN"); return e ? atoi(e) : 0; }();
+        const bool beside_chain = !plan.inference && plan.L > 0;
+        g_bbbp_conv1_fwd_f32 = (beside_chain && !c1_train) ? 1 : 0;
+        g_bbbp_conv1_fwd_per_cu = (beside_chain && c1_train) ? (c1_train >= 2 ? 2 : 1) : 0;      // BBBP_C1_TRAIN=2: two work-groups per CU there too
         const int rc1 = bbbp_conv3x3_relu_pool_fwd(c.st, image, P[ix.c1_w()], P[ix.c1_b()], pool1, plan.inference ? nullptr : c.u8(plan.mask1), B, 3, C1, IMG, IMG,
                                                    c.scratch(), c.scratch_bytes());
-        g_bbbp_conv1_fwd_f32 = 0;
+        g_bbbp_conv1_fwd_f32 = 0; g_bbbp_conv1_fwd_per_cu = 0;
         TRY(rc1);
     }
     {
@@ -717,14 +721,34 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
             x = c.f(o.y2);
         }
     }
+    // LayerNorm absorbed by the Linear that consumes it (gemm.hip: gemm_direct_lna_kernel; BBBP_LN_ABSORB=0 keeps the stand-alone launches):
+    // norm1 -> linear1, norm2 -> the next in_proj / fingerprint_fc.  The dropout + residual that the LayerNorm launch applied to its input
+    // move into the epilogue of the GEMM that produces it (same Philox elements), so z1 / z2, y1 / y2 and the row statistics the backward
+    // pass reads are the same tensors as before.
+    struct { const float* z; const float* gamma; const float* beta; float* y; float* mean; float* rstd; } pend = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    static const int ln_absorb = [] { const char* e = getenv("BBBP_LN_ABSORB"); return e ? atoi(e) : 1; }();
+    const bool lna_ok = ln_absorb && !plan.exact && plan.L > 0 && bbbp_layernorm_linear_preferred(B, DFF, F) && bbbp_layernorm_linear_preferred(B, 3 * F, F) &&
+                        bbbp_layernorm_linear_preferred(B, FC, F) &&
+                        // training: the producers' dropout rides in the small-product GEMM's epilogue only
+                        (!plan.drop || (bbbp_gemm_folds_asum(B, F, DFF, 1) && bbbp_gemm_folds_asum(B, F, plan.fold ? Bk : F, 1)));
     for (int l = 0; l < ((fused_rows || sliced) ? 0 : plan.L); ++l) {
         const LayerOff& o = plan.layer[l];
         float* qkv = c.f(o.qkv); float* prob = c.f(o.prob); float* ctx = c.f(o.ctx);
+        const bool absorb1 = lna_ok && !(plan.attn_b3 && plan.fold);      // (that attention kernel writes z1 itself: no epilogue for the residual)
+        const bool absorb2 = lna_ok;
         {
             Section sq(ce.st, SEC_QKV_FWD);
             // folded plan: [Q | K | VW] = x [Wq; Wk; Wo Wv]^T + [bq; bk; Wo bv]
-            TRY(linear_fwd(ce, x, F, plan.fold ? c.f(plan.fwf[l]) : P[ix.layer(l, L_INW)], plan.fold ? c.f(plan.fbf[l]) : P[ix.layer(l, L_INB)], qkv,
-                           3 * F, B, 3 * F, F, 0));
+            const float* w_in = plan.fold ? c.f(plan.fwf[l]) : P[ix.layer(l, L_INW)];
+            const float* b_in = plan.fold ? c.f(plan.fbf[l]) : P[ix.layer(l, L_INB)];
+            if (pend.z) {
+                // the previous layer's norm2 is absorbed here: x = LayerNorm(z2) is written by the same launch (round 4)
+                TRY(bbbp_layernorm_linear_fwd(ce.st, pend.z, F, pend.gamma, pend.beta, 1e-5f, w_in, b_in, qkv, 3 * F, 0, 0.f, 0, pend.y, F, pend.mean,
+                                              pend.rstd, B, 3 * F, F));
+                pend.z = nullptr;
+            } else {
+                TRY(linear_fwd(ce, x, F, w_in, b_in, qkv, 3 * F, B, 3 * F, F, 0));
+            }
         }
         std::optional<Section> sec_attn;
         sec_attn.emplace(ce.st, SEC_ATTN_FWD);
@@ -750,8 +774,15 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         float* pd = c.f(o.pd);
         TRY(bbbp_softmax_fwd(ce.st, prob, pd, (long)NH * B, Bk, p_drop, site_seed(d->seed, l, 0)));
         // ctx_h = Pd_h V_h; folded plan (one head): z1 = Pd VW + bo, the out_proj output itself
+        if (plan.fold && absorb1) {
+            // ... and with norm1 absorbed by linear1, z1 = dropout(Pd VW + bo) + x: what bbbp_layernorm_fwd would have left in z1
+            bbbp_gemm_desc g = gemm_desc(0, 0, B, D, Bk, 1.f, pd, Bk, vmat, ldkv, c.f(o.z1), F, 1, 0, 0, 0);
+            g.bias = P[ix.layer(l, L_OUTB)]; g.residual = x; g.ldr = F; g.drop_p = p_drop; g.drop_seed = site_seed(d->seed, l, 1);
+            TRY(bbbp_gemm_f32_grouped(ce.st, &g, 1, ce.scratch(), ce.scratch_bytes()));
+        } else {
         TRY(bbbp_gemm_f32(ce.st, 0, 0, B, D, Bk, 1.f, pd, Bk, vmat, ldkv, plan.fold ? c.f(o.z1) : ctx, F, plan.fold ? P[ix.layer(l, L_OUTB)] : nullptr,
                           nullptr, 0, 0, NH, (long)B * Bk, D, D, 0, ce.scratch(), ce.scratch_bytes()));
+        }
         }
         sec_attn.reset();
         float* z1 = c.f(o.z1); float* y1 = c.f(o.y1);
@@ -767,18 +798,30 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         } else {
         if (!plan.fold) {
             Section so(ce.st, SEC_OUTPROJ_FWD);
-            TRY(linear_fwd(ce, ctx, F, P[ix.layer(l, L_OUTW)], P[ix.layer(l, L_OUTB)], z1, F, B, F, F, 0));
+            if (absorb1) {
+                bbbp_gemm_desc g = gemm_desc(0, 1, B, F, F, 1.f, ctx, F, P[ix.layer(l, L_OUTW)], F, z1, F, 1, 0, 0, 0);
+                g.bias = P[ix.layer(l, L_OUTB)]; g.residual = x; g.ldr = F; g.drop_p = p_drop; g.drop_seed = site_seed(d->seed, l, 1);
+                TRY(bbbp_gemm_f32_grouped(ce.st, &g, 1, ce.scratch(), ce.scratch_bytes()));
+            } else {
+                TRY(linear_fwd(ce, ctx, F, P[ix.layer(l, L_OUTW)], P[ix.layer(l, L_OUTB)], z1, F, B, F, F, 0));
+            }
         }
+        if (!absorb1) {
         Section sl(ce.st, SEC_LN_FWD);
         TRY(bbbp_layernorm_fwd(ce.st, z1, x, y1, P[ix.layer(l, L_N1W)], P[ix.layer(l, L_N1B)], c.f(o.mean1), c.f(o.rstd1), B, F,
                                1e-5f, p_drop, site_seed(d->seed, l, 1)));
+        }
         }
         float* hff = c.f(o.hff); float* z2 = c.f(o.z2); float* y2 = c.f(o.y2);
         // linear1 + ReLU (+ the FFN dropout in the same epilogue when the product takes the small-GEMM path: same Philox elements as bbbp_dropout)
         const bool drop_in_gemm = plan.drop && bbbp_gemm_folds_asum(B, DFF, F, 1);
         {
             Section sf(ce.st, SEC_FFN1_FWD);
-            if (drop_in_gemm) {
+            if (absorb1) {
+                // norm1 absorbed: hff = dropout(ReLU(LayerNorm(z1) W1^T + b1)); y1, mean1, rstd1 written by the same launch
+                TRY(bbbp_layernorm_linear_fwd(ce.st, z1, F, P[ix.layer(l, L_N1W)], P[ix.layer(l, L_N1B)], 1e-5f, P[ix.layer(l, L_W1)], P[ix.layer(l, L_B1)],
+                                              hff, DFF, BBBP_ACT_RELU, p_drop, site_seed(d->seed, l, 2), y1, F, c.f(o.mean1), c.f(o.rstd1), B, DFF, F));
+            } else if (drop_in_gemm) {
                 bbbp_gemm_desc g = gemm_desc(0, 1, B, DFF, F, 1.f, y1, F, P[ix.layer(l, L_W1)], F, hff, DFF, 1, 0, 0, 0);
                 g.bias = P[ix.layer(l, L_B1)]; g.act = BBBP_ACT_RELU; g.drop_p = p_drop; g.drop_seed = site_seed(d->seed, l, 2);
                 TRY(bbbp_gemm_f32_grouped(ce.st, &g, 1, ce.scratch(), ce.scratch_bytes()));
@@ -786,12 +829,20 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
                 TRY(linear_fwd(ce, y1, F, P[ix.layer(l, L_W1)], P[ix.layer(l, L_B1)], hff, DFF, B, DFF, F, BBBP_ACT_RELU));
             }
         }
-        if (plan.drop && !drop_in_gemm) TRY(bbbp_dropout(ce.st, hff, hff, (long)B * DFF, p_drop, site_seed(d->seed, l, 2)));
+        if (plan.drop && !drop_in_gemm && !absorb1) TRY(bbbp_dropout(ce.st, hff, hff, (long)B * DFF, p_drop, site_seed(d->seed, l, 2)));
         {
             Section sf(ce.st, SEC_FFN2_FWD);
-            TRY(linear_fwd(ce, hff, DFF, P[ix.layer(l, L_W2)], P[ix.layer(l, L_B2)], z2, F, B, F, DFF, 0));
+            if (absorb2) {
+                // norm2 is absorbed by the next in_proj (or fingerprint_fc): z2 = dropout(h W2^T + b2) + y1 here, normalised there
+                bbbp_gemm_desc g = gemm_desc(0, 1, B, F, DFF, 1.f, hff, DFF, P[ix.layer(l, L_W2)], DFF, z2, F, 1, 0, 0, 0);
+                g.bias = P[ix.layer(l, L_B2)]; g.residual = y1; g.ldr = F; g.drop_p = p_drop; g.drop_seed = site_seed(d->seed, l, 3);
+                TRY(bbbp_gemm_f32_grouped(ce.st, &g, 1, ce.scratch(), ce.scratch_bytes()));
+                pend.z = z2; pend.gamma = P[ix.layer(l, L_N2W)]; pend.beta = P[ix.layer(l, L_N2B)]; pend.y = y2; pend.mean = c.f(o.mean2); pend.rstd = c.f(o.rstd2);
+            } else {
+                TRY(linear_fwd(ce, hff, DFF, P[ix.layer(l, L_W2)], P[ix.layer(l, L_B2)], z2, F, B, F, DFF, 0));
+            }
         }
-        {
+        if (!absorb2) {
             Section sl(ce.st, SEC_LN_FWD);
             TRY(bbbp_layernorm_fwd(ce.st, z2, y1, y2, P[ix.layer(l, L_N2W)], P[ix.layer(l, L_N2B)], c.f(o.mean2), c.f(o.rstd2), B, F,
                                    1e-5f, p_drop, site_seed(d->seed, l, 3)));
@@ -799,7 +850,15 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         x = y2;
     }
     // fingerprint_fc (R:79-82, 112) -> combined[:, 0:128]
-    if (!fused_rows && !sliced) TRY(linear_fwd(ce, x, F, P[ix.fpfc_w()], P[ix.fpfc_b()], comb, COMB, B, FC, F, BBBP_ACT_RELU));
+    if (!fused_rows && !sliced) {
+        if (pend.z) {
+            TRY(bbbp_layernorm_linear_fwd(ce.st, pend.z, F, pend.gamma, pend.beta, 1e-5f, P[ix.fpfc_w()], P[ix.fpfc_b()], comb, COMB, BBBP_ACT_RELU, 0.f, 0,
+                                          pend.y, F, pend.mean, pend.rstd, B, FC, F));
+            pend.z = nullptr;
+        } else {
+            TRY(linear_fwd(ce, x, F, P[ix.fpfc_w()], P[ix.fpfc_b()], comb, COMB, B, FC, F, BBBP_ACT_RELU));
+        }
+    }
     sec_enc.reset();
 
     if (ss) TRY(join_side(c.st, ss));        // fusion needs both halves of `combined`

@@ -1170,6 +1170,129 @@ __global__ __launch_bounds__(1024, 2) void gemm_direct_ln_kernel(DirectParams p,
     }
 }
 
+// LayerNorm ABSORBED by the Linear that consumes it (round 4): out = act(LayerNorm(z) W^T + bias) and y = LayerNorm(z) (+ mean, rstd) in ONE
+// launch -- the encoder's norm1 -> linear1, norm2 -> the next layer's in_proj and the last norm2 -> fingerprint_fc (R:75-82): twelve
+// LayerNorm launches leave the encoder's forward chain, where every launch costs 8-15 us whatever its size.  Algebra, per output element:
+//     LayerNorm(z)_k = (z_k - mu) rstd gamma_k + beta_k
+//     out[m][n] = rstd_m ( sum_k (z[m][k] - x0_m) gamma_k W[n][k]  -  (mu_m - x0_m) c_n ) + d_n + bias_n,
+//     c_n = sum_k gamma_k W[n][k],   d_n = sum_k beta_k W[n][k],   x0_m = z[m][0] (a pivot: sums of z - x0 do not cancel like sums of z).
+// A wave of the small-product kernel walks ALL of K for its 16 rows and 16 columns (K <= 192: one K slice), so everything above is in its
+// own operand stream: the row sums (sum and sum of squares of z - x0: mean and variance), c_n and d_n from the weight rows it loads anyway,
+// gamma / beta from 1.5 KB of LDS; the MFMAs run on (z - x0) gamma, and the row statistics reach the accumulator layout through two
+// ds_bpermutes per accumulator register.  No prepared weights, no extra pass, no barrier in the K loop.
+// y, mean and rstd (the residual of the next block, linear1's weight gradient and the LayerNorm backward need them) are written by ONE
+// extra column of work-groups of the same launch that run the plain row kernel (rowops.hip: layernorm_fwd_kernel without dropout and
+// residual -- those moved into the epilogue of the GEMM that PRODUCES z): same statistics as the stand-alone launch, bit for bit.
+struct LnaParams {
+    const float* Z; int ldz;                 // [M][K] pre-norm rows
+    const float* gamma; const float* beta; float eps;
+    const float* W; int ldw; const float* bias;      // [N][K], [N]
+    float* C; int ldc;
+    int M, N, K, act;
+    float drop_p, drop_inv_keep; unsigned long long drop_seed; const unsigned long long* seed_base;
+    float* Y; int ldy; float* mean; float* rstd;
+    int gx;                                  // column blocks of the product; blockIdx.x == gx: the LayerNorm writers
+};
+constexpr int LNA_MAX_K = 192;
+
+__global__ __launch_bounds__(256) void gemm_direct_lna_kernel(LnaParams p) {
+    BBBP_HIGH_PRIO();
+    __shared__ __attribute__((aligned(16))) float gb[2][LNA_MAX_K];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int)blockIdx.x == p.gx) {
+        // ---- LayerNorm writers: 32 rows per work-group, one wave per row at a time, the row in registers (three elements per lane) ----
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i) {
+            const int row = blockIdx.y * 32 + wave * 8 + i;
+            if (row >= p.M) break;
+            const float* zr = p.Z + (long)row * p.ldz;
+            float v[3]; float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) { const int c = lane + 64 * e; v[e] = c < p.K ? zr[c] : 0.f; s += v[e]; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const float mean = s / p.K;
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) { const int c = lane + 64 * e; const float d = c < p.K ? v[e] - mean : 0.f; q += d * d; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+            const float rstd = rsqrtf(q / p.K + p.eps);
+            float* yr = p.Y + (long)row * p.ldy;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) { const int c = lane + 64 * e; if (c < p.K) yr[c] = (v[e] - mean) * rstd * p.gamma[c] + p.beta[c]; }
+            if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
+        }
+        return;
+    }
+    constexpr int D = 3;                                          // chunks in flight (4 spill at the 64-register cap that keeps 8 waves per SIMD)
+    const int q = lane & 15, kq = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    DirectOperand<1, false> opa, opb;
+    opa.init(p.Z, p.ldz, p.M, (blockIdx.y * 2 + wm) * 16, lane);
+    opb.init(p.W, p.ldw, p.N, (blockIdx.x * 2 + wn) * 16, lane);
+    const int nch = (p.K + 15) / 16, nfast = nch - 1;
+    // the first chunks and the row pivot are in flight before the LDS fill's barrier
+    float ra[D][4][1], rb[D][4][1];
+    if (nfast > 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) { const int c = min(d, nfast - 1); opa.fetch(c, ra[d]); opb.fetch(c, rb[d]); }
+    }
+    const float x0 = *(opa.ptr[0] - 4 * kq);
+    for (int i = threadIdx.x; i < LNA_MAX_K; i += 256) { gb[0][i] = i < p.K ? p.gamma[i] : 0.f; gb[1][i] = i < p.K ? p.beta[i] : 0.f; }
+    __syncthreads();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float s1 = 0.f, s2 = 0.f, cn = 0.f, dn = 0.f;
+    auto chunk = [&](const float (&a)[4][1], const float (&b)[4][1], int c, bool tail) __attribute__((always_inline)) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(&gb[0][16 * c + 4 * kq]);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(&gb[1][16 * c + 4 * kq]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float as = a[j][0] - x0;
+            if (tail) as = (16 * c + 4 * kq + j < p.K) ? as : 0.f;          // the zero-filled tail of K is not part of the row
+            s1 += as; s2 = fmaf(as, as, s2);
+            cn = fmaf(b[j][0], g[j], cn); dn = fmaf(b[j][0], bt[j], dn);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(as * g[j], b[j][0], acc, 0, 0, 0);
+        }
+    };
+    if (nfast > 0) {
+        for (int i0 = 0; i0 < nfast; i0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (i0 + d < nfast) chunk(ra[d], rb[d], i0 + d, false);
+                const int c = min(i0 + d + D, nfast - 1);
+                opa.fetch(c, ra[d]); opb.fetch(c, rb[d]);
+            }
+        }
+    }
+    {
+        float ta[4][1], tb[4][1];
+        opa.fetch_tail(nch - 1, p.K, ta); opb.fetch_tail(nch - 1, p.K, tb);
+        chunk(ta, tb, nch - 1, true);
+    }
+    // lanes (q, 0..3) hold the four K quarters of row q (A side) and of column q (B side)
+    s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+    cn += __shfl_xor(cn, 16); cn += __shfl_xor(cn, 32);
+    dn += __shfl_xor(dn, 16); dn += __shfl_xor(dn, 32);
+    const float mus = s1 / p.K;                                   // mean - pivot
+    const float rstd = rsqrtf(fmaxf(s2 / p.K - mus * mus, 0.f) + p.eps);
+    const int n = opb.index(0, q);
+    const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    const uint64_t seed = effective_seed(p.drop_seed, p.seed_base);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = opa.index(0, 4 * kq + r);
+        // accumulator register r of lane (q, kq) is row 4 kq + r, column q: that row's statistics sit in lane 4 kq + r
+        const float mu_r = __shfl(mus, 4 * kq + r), rs_r = __shfl(rstd, 4 * kq + r);
+        if (m < p.M && n < p.N) {
+            float v = apply_act(rs_r * (acc[r] - mu_r * cn) + dn + bv, p.act);
+            if (p.drop_p > 0.f) v *= dropout_scale(seed, (uint64_t)m * p.N + n, p.drop_p, p.drop_inv_keep);
+            p.C[(long)m * p.ldc + n] = v;
+        }
+    }
+}
+
 // Two independent products in one launch (dV | dP and dQ | dK of the attention backward, which become ready together):
 // the chain of small launches is bound by per-launch latency, not by work, so halving the launches halves the time.
 // blockIdx.z < p0.batch -> problem 0, else problem 1; work-groups outside a problem's own grid exit at once.
@@ -1618,6 +1741,38 @@ extern "C" int bbbp_linear_layernorm_fwd(void* stream, const float* x, int ldx, 
     d.drop_p = dropout_p; d.drop_inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f; d.drop_seed = seed; d.seed_base = g_bbbp_seed_base;
     LnFuse f{gamma, beta, y, ldy, mean, rstd, eps};
     hipLaunchKernelGGL(gemm_direct_ln_kernel, dim3(1, d.gy), dim3(64 * d.wsn), g_bbbp_small_lds_pad, static_cast<hipStream_t>(stream), d, f);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+// LayerNorm absorbed by the Linear that consumes it (gemm_direct_lna_kernel)
+extern "C" int bbbp_layernorm_linear_supported(int M, int N, int K) {
+    return (M >= 1 && N >= 1 && K >= 1 && K <= LNA_MAX_K && (M + 31) / 32 <= 65535 && (N + 31) / 32 < 65535) ? 1 : 0;
+}
+
+// engine: absorb the LayerNorm only where the plain product would run on the same 16 x 16 wave tiles anyway (larger outputs take 32 x 32
+// wave tiles or the split-bf16 kernels, which the absorbing kernel would be slower than)
+bool bbbp_layernorm_linear_preferred(int M, int N, int K) {
+    if (!bbbp_layernorm_linear_supported(M, N, K)) return false;
+    const DirectPlan dp = direct_plan(M, N, K, 1);
+    return dp.use && dp.t == 1 && dp.ks == 1;
+}
+
+extern "C" int bbbp_layernorm_linear_fwd(void* stream, const float* z, int ldz, const float* gamma, const float* beta, float eps,
+                                         const float* W, const float* bias, float* out, int ldo, int act, float dropout_p, uint64_t seed,
+                                         float* y, int ldy, float* mean, float* rstd, int M, int N, int K) {
+    BBBP_CHECK_ARG(bbbp_layernorm_linear_supported(M, N, K), "layernorm_linear: M=%d N=%d K=%d not supported (K <= %d)", M, N, K, LNA_MAX_K);
+    BBBP_CHECK_ARG(z && gamma && beta && W && out && y && mean && rstd, "layernorm_linear: null pointer");
+    BBBP_CHECK_ARG(ldz >= K && ldo >= N && ldy >= K, "layernorm_linear: leading dimension too small");
+    BBBP_CHECK_ARG(act >= 0 && act <= 2, "layernorm_linear: bad act %d", act);
+    BBBP_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "layernorm_linear: bad dropout %f", (double)dropout_p);
+    LnaParams p;
+    p.Z = z; p.ldz = ldz; p.gamma = gamma; p.beta = beta; p.eps = eps; p.W = W; p.ldw = K; p.bias = bias; p.C = out; p.ldc = ldo;
+    p.M = M; p.N = N; p.K = K; p.act = act;
+    p.drop_p = dropout_p; p.drop_inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f; p.drop_seed = seed; p.seed_base = g_bbbp_seed_base;
+    p.Y = y; p.ldy = ldy; p.mean = mean; p.rstd = rstd;
+    p.gx = cdiv(N, 32);
+    hipLaunchKernelGGL(gemm_direct_lna_kernel, dim3(p.gx + 1, cdiv(M, 32)), dim3(256), g_bbbp_small_lds_pad, static_cast<hipStream_t>(stream), p);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }

@@ -14,6 +14,7 @@ thread_local int g_bbbp_reserved_cus = 0;
 thread_local size_t g_bbbp_small_lds_pad = 0;
 thread_local int g_bbbp_wino_side_cus = 0;
 thread_local int g_bbbp_conv1_fwd_f32 = 0;
+thread_local int g_bbbp_conv1_fwd_per_cu = 0;
 thread_local int g_bbbp_conv_wgrad_beside_encoder = 0;
 thread_local const unsigned long long* g_bbbp_seed_base = nullptr;
 
@@ -48,21 +49,27 @@ void bbbp_set_error(const char* fmt, ...) {
 
 extern "C" const char* bbbp_last_error(void) { return g_err; }
 
+// CUs kept out of every persistent grid (they are all sized from bbbp_num_cus()): room for RCCL's ring kernels beside the conv work-groups
+// in a multi-GPU run.  Initial value BBBP_COMM_CUS (default 0); bench.py's N-rank diagnostic pass measures 0 against 8 and keeps the
+// faster one (bbbp_set_comm_cus).  Never measured on a multi-GPU node before that pass runs there.
+static int g_comm_cus = -1;
+static int comm_cus() {
+    if (g_comm_cus < 0) { const char* e = getenv("BBBP_COMM_CUS"); const int v = e ? atoi(e) : 0; g_comm_cus = v < 0 ? 0 : v; }
+    return g_comm_cus;
+}
+extern "C" int bbbp_set_comm_cus(int n) { const int prev = comm_cus(); g_comm_cus = n < 0 ? 0 : n; return prev; }
+
 int bbbp_num_cus() {
-    static int cached[64] = {0};                  // per device (benign race: every thread computes the same value)
-    // BBBP_COMM_CUS=n keeps n CUs out of every persistent grid (they are all sized from this count): room for RCCL's ring kernels
-    // beside the conv work-groups in a multi-GPU run.  Default 0; never measured on a multi-GPU node (none was available).
-    static const int comm_cus = [] { const char* e = getenv("BBBP_COMM_CUS"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : v; }();
+    static int cached[64] = {0};                  // per device: the hardware's count (benign race: every thread computes the same value)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
     if (cached[dev] == 0) {
         hipDeviceProp_t prop;
         int n = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
-        n = n > 0 ? n : 256;
-        if (comm_cus > 0 && n - comm_cus >= 64) n -= comm_cus;
-        cached[dev] = n;
+        cached[dev] = n > 0 ? n : 256;
     }
-    return cached[dev];
+    const int n = cached[dev], c = comm_cus();
+    return (c > 0 && n - c >= 64) ? n - c : n;
 }
 
 extern "C" int bbbp_abi_version(void) { return 1; }

@@ -241,6 +241,29 @@ def linear_layernorm_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[t
     return y, z, mean, rstd
 
 
+def layernorm_linear_fwd(z: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                         act: int = 0, eps: float = 1e-5, dropout_p: float = 0.0, seed: int = 0):
+    """out = dropout(act(LayerNorm(z) @ weight.T + bias)) with the LayerNorm absorbed by the product (ONE launch; K = z.shape[1] <= 192).
+    Returns (out [M, N], y = LayerNorm(z) [M, K], mean [M], rstd [M])."""
+    _chk(z, "z"); _chk(weight, "weight"); _chk(gamma, "gamma"); _chk(beta, "beta")
+    z = z.contiguous(); weight = weight.contiguous()
+    M, K = z.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K or gamma.numel() != K or beta.numel() != K:
+        raise RuntimeError("layernorm_linear_fwd: inner dimensions differ")
+    L = _lib.lib()
+    if not L.bbbp_layernorm_linear_supported(M, N, K):
+        raise RuntimeError(f"layernorm_linear_fwd: shape M={M} N={N} K={K} is not supported (K <= 192)")
+    out = torch.empty((M, N), device=z.device, dtype=torch.float32)
+    y = torch.empty_like(z)
+    mean = torch.empty(M, device=z.device, dtype=torch.float32)
+    rstd = torch.empty(M, device=z.device, dtype=torch.float32)
+    _lib.check(L.bbbp_layernorm_linear_fwd(_stream(), z.data_ptr(), K, gamma.data_ptr(), beta.data_ptr(), eps, weight.data_ptr(), _p(bias),
+                                           out.data_ptr(), N, act, dropout_p, seed, y.data_ptr(), K, mean.data_ptr(), rstd.data_ptr(), M, N, K),
+               "bbbp_layernorm_linear_fwd")
+    return out, y, mean, rstd
+
+
 def layernorm_bwd(dy, z, gamma, mean, rstd, dropout_p: float = 0.0, seed: int = 0):
     """Returns (dz, dx, dgamma, dbeta); dx is dz when dropout_p == 0."""
     rows, cols = z.shape

@@ -52,7 +52,7 @@ IMG_FLAT = 3 * 128 * 128
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense (MI355X_MICROARCH.md: Matrix cores)
 HBM_PEAK_GBS = 8000.0
-ROUND = "r03"
+ROUND = "r04"
 
 CONFIGS = {
     2: dict(F=167, batch=256, train=True, model="TwoBranchConcatModel", layers=0, fusion=False,
@@ -252,6 +252,50 @@ def comm_report(world, dev, dist, collectives_per_step):
                 collectives_per_step=collectives_per_step, launched_by=os.environ.get("BBBP_BENCH_LAUNCHED_BY", "torch.distributed.run"))
 
 
+def comm_diagnostics(dist, rank, world, fence, step_overlapped, step_no_collective, allreduce_only, set_comm_cus, grad_bytes,
+                     candidates=(0, 8), steps=5, warmup=2, reduce_device=None):
+    """The self-diagnosing part of an N-rank line: an UNTIMED pass every rank takes, before the timed region,
+    that prices the communication of one training step:
+      step_no_collective_ms   the step with its gradient collectives skipped (what the GPU needs by itself),
+      plain_allreduce_ms      ONE all-reduce of the whole flat gradient buffer, nothing beside it; algbw_GBps = bytes / time and
+                              busbw_GBps = algbw * 2 (N - 1) / N (ring traffic per link),
+      overlapped_ms[c]        the step with the overlapped bucket schedule while c CUs are kept out of every persistent grid
+                              (bbbp_set_comm_cus: room for the collective library's kernels beside the conv work-groups),
+      comm_cus_chosen         the candidate with the smallest overlapped step (rank 0 decides, broadcast; left set for the timed region),
+      exposed_ms              overlapped_ms[chosen] - step_no_collective_ms: the communication the backward pass does NOT hide.
+    Every time is the MAX over ranks of a (fence, `steps` calls, fence) host interval.  All callables take the step index."""
+    import torch as _torch
+
+    def timed(fn):
+        for i in range(warmup):
+            fn(i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(i)
+        fence()
+        t = _torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=_torch.float64, device=reduce_device or "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    out = {"step_no_collective_ms": round(timed(step_no_collective), 4), "plain_allreduce_ms": round(timed(allreduce_only), 4)}
+    per = {}
+    for c in candidates:
+        set_comm_cus(c)
+        per[c] = timed(step_overlapped)
+    pick = [min(per, key=per.get)]
+    dist.broadcast_object_list(pick, src=0)
+    chosen = int(pick[0])
+    set_comm_cus(chosen)
+    secs = out["plain_allreduce_ms"] * 1e-3
+    out.update(overlapped_ms={str(c): round(v, 4) for c, v in per.items()}, comm_cus_chosen=chosen,
+               exposed_ms=round(per[chosen] - out["step_no_collective_ms"], 4), bytes=int(grad_bytes),
+               algbw_GBps=round(grad_bytes / secs / 1e9, 2) if secs > 0 else None,
+               busbw_GBps=round(grad_bytes / secs / 1e9 * 2 * (world - 1) / world, 2) if secs > 0 else None,
+               steps_per_measurement=steps, note="untimed diagnostic pass before the timed region; MAX over ranks of host intervals between fences")
+    return out
+
+
 def bench_model(args, cfg_id, rank, world, dev, dist):
     import bbbp_amd
     from bbbp_amd import _lib
@@ -357,6 +401,20 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
     for i in range(args.warmup):
         step(i)
     L = _lib.lib()
+    comm_diag = None
+    if world > 1 and train and not args.exact_batch and not pipelined:
+        # what the collectives cost and how much of it the backward pass hides; also picks BBBP_COMM_CUS for the timed region
+        def allreduce_only(i):
+            if params[0].grad is None:             # dropped by zero_grad(set_to_none=True): one backward pass (inside the warm-up calls) brings the flat buffer back
+                b0 = batch_of(0)
+                crit(model(b0[0], b0[1]).squeeze(), b0[2]).backward()
+            D.allreduce_gradients(params, average=False)
+
+        comm_diag = comm_diagnostics(dist, rank, world, fence, lambda i: step(i), lambda i: step(i, collective=False),
+                                     allreduce_only, L.bbbp_set_comm_cus,
+                                     sum(q.numel() for q in params) * 4, reduce_device=dev,
+                                     candidates=tuple(int(v) for v in os.environ.get("BBBP_BENCH_COMM_CUS", "0,8").split(",")))
+        opt.zero_grad(set_to_none=True)
     nsec = L.bbbp_profile_num_sections()
     names = [L.bbbp_profile_section_name(i).decode() for i in range(nsec)]
     ms_sum = (ctypes.c_float * nsec)()
@@ -408,6 +466,7 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
     # outside the timed region: every section with the overlap on (where the step goes) ...
     # (rank 0 only -- except in exact-global-batch mode, where every step holds the engine's own collectives and all ranks must take it)
     all_ranks_step = bool(args.exact_batch) and world > 1
+    untimed_launches = {}                 # launches per step of every section, from the untimed all-sections pass
     if rank == 0 or all_ranks_step:
         L.bbbp_profile_enable(1)
         time_opt[0] = train
@@ -420,6 +479,8 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
         for i in range(nsec):
             if cnt[i] and names[i] not in sections:
                 sections[names[i]] = ms_sum[i] / cnt[i]
+            if cnt[i]:
+                untimed_launches[names[i]] = cnt[i] / 5.0
     # ... and the same kernels with the branch overlap off, i.e. each kernel alone on the GPU
     isolated, clock = {}, {}
     if (rank == 0 or all_ranks_step) and not args.no_isolated:
@@ -549,6 +610,33 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
             roofline["conv2_dgrad_isolated_clock"] = dict(
                 sustained_ghz=round(clock["ghz"], 3), kernel_cycles=clock["cycles"], mfma_pipe_busy=round(busy, 4),
                 note="shader clock (cycles / 100 MHz wall ticks of work-group 0) while the kernel runs alone; the peaks assume 2.4 GHz")
+    # The OTHER half of the critical path: the encoder chain's GEMM / attention launches, each far too small to be a
+    # "dominant kernel" yet together as long as the image branch.  Untimed all-sections pass (HIP events around every launch: ~6 us each,
+    # so the per-launch times are upper bounds); priced on the exact-f32 MFMA the small-product kernels issue to.
+    roofline_encoder = None
+    enc_names = [k for k in ("qkv_fwd", "attn_fwd", "outproj_fwd", "ffn1_fwd", "ffn2_fwd", "ffn2_dgrad", "ffn1_dgrad", "outproj_dgrad", "attn_bwd",
+                             "qkv_dgrad", "ffn2_wgrad", "ffn1_wgrad", "outproj_wgrad", "qkv_wgrad") if k in sections and k in untimed_launches]
+    if cfg["layers"] and enc_names and F <= 256:
+        per = {k: dict(ms_per_launch=round(sections[k], 4), launches_per_step=round(untimed_launches[k], 2),
+                       gflop_per_launch=round(kernel_flops[k] / 1e9, 3),
+                       tflops=round(kernel_flops[k] / (sections[k] * 1e-3) / 1e12, 2),
+                       ms_per_launch_isolated=round(isolated.get(k, 0.0), 4)) for k in enc_names}
+        tot_ms = sum(sections[k] * untimed_launches[k] for k in enc_names)
+        tot_fl = sum(kernel_flops[k] * untimed_launches[k] for k in enc_names)
+        ln_ms = sum(sections.get(k, 0.0) * untimed_launches.get(k, 0.0) for k in ("ln_fwd", "ln_bwd"))
+        roofline_encoder = dict(bound="mfma", kernel="gemm_direct_kernel / softmax (encoder chain, F=%d)" % F,
+                                achieved=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                                frac=round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                                gflop_per_step=round(tot_fl / 1e9, 2), kernel_ms_per_step=round(tot_ms, 4),
+                                launches_per_step=round(sum(untimed_launches[k] for k in enc_names), 1),
+                                layernorm_ms_per_step=round(ln_ms, 4),
+                                chain_ms={"encoder_fwd": round(sections.get("encoder_fwd", 0.0), 4), "encoder_bwd": round(sections.get("encoder_bwd", 0.0), 4),
+                                          "encoder_fwd_isolated": round(isolated.get("encoder_fwd", 0.0), 4),
+                                          "encoder_bwd_isolated": round(isolated.get("encoder_bwd", 0.0), 4)},
+                                sections=per,
+                                note="sum over the encoder's GEMM / attention sections of one step (untimed all-sections pass, ~6 us of event overhead per "
+                                     "launch included); these launches are bound by per-launch latency and by co-residency with the conv kernels, not by "
+                                     "the matrix pipe -- the fraction says how far")
     fwd_total = sum(fl.values())
     total_flops = (fwd_total * 3 - fl["conv1"]) if train else fwd_total          # bwd = 2 * fwd - conv1 dgrad
     result = {
@@ -563,7 +651,11 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
         "model_tflops_per_gpu": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
         "roofline": roofline,
     }
+    if roofline_encoder is not None:
+        result["roofline_encoder"] = roofline_encoder
     if comm is not None:
+        if comm_diag is not None:
+            comm["comm"] = comm_diag
         result["rccl"] = comm
         result["collectives_per_step"] = comm["collectives_per_step"]
     if train:

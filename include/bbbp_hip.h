@@ -134,6 +134,17 @@ int bbbp_linear_layernorm_supported(int M, int N, int K);
 int bbbp_linear_layernorm_fwd(void* stream, const float* x, int ldx, const float* W, const float* bias, const float* residual, int ldr,
                               float* z, int ldz, float* y, int ldy, const float* gamma, const float* beta, float* mean, float* rstd,
                               int M, int N, int K, float eps, float dropout_p, uint64_t seed);
+/* LayerNorm ABSORBED by the Linear that consumes it (round 4; the encoder's norm1 -> linear1, norm2 -> the next in_proj / fingerprint_fc,
+ * R:75-82): ONE launch computes out = dropout(act(LayerNorm(z) W^T + bias)) [M][N] and writes y = LayerNorm(z) [M][K], mean, rstd (what
+ * bbbp_layernorm_fwd writes for a z that already holds dropout(x) + residual -- the producing GEMM's epilogue does that now).  Per output
+ * element out = rstd_m (sum_k (z - x0_m) gamma_k W[n][k] - (mu_m - x0_m) c_n) + d_n + bias_n with c_n = sum_k gamma_k W[n][k],
+ * d_n = sum_k beta_k W[n][k], all taken from the product's own operand stream (csrc/gemm.hip: gemm_direct_lna_kernel); y / mean / rstd come
+ * from one extra column of work-groups of the same launch.  K <= 192 (bbbp_layernorm_linear_supported).  The dropout draws element
+ * m * N + n of `seed`, the stream bbbp_dropout draws for a contiguous [M][N] tensor. */
+int bbbp_layernorm_linear_supported(int M, int N, int K);
+int bbbp_layernorm_linear_fwd(void* stream, const float* z, int ldz, const float* gamma, const float* beta, float eps,
+                              const float* W, const float* bias, float* out, int ldo, int act, float dropout_p, uint64_t seed,
+                              float* y, int ldy, float* mean, float* rstd, int M, int N, int K);
 int bbbp_layernorm_bwd(void* stream, const float* dy, const float* z, const float* gamma, const float* mean,
                        const float* rstd, float* dz, float* dx, float* dgamma, float* dbeta, int rows, int cols,
                        float dropout_p, uint64_t seed);
@@ -313,6 +324,10 @@ int bbbp_oblivious_predict(void* stream, const float* X, long n, int n_features,
 /* ---- optional per-section timing (HIP events on the launch stream; used by bench.py's roofline leg) ----
  * enable(1), run steps, synchronise the stream, collect(ms_sum[n], count[n]) with n = num_sections(). */
 int bbbp_set_partition(int reserved_cus, size_t small_lds_pad);   /* CU partition knob, see csrc/common.h */
+/* CUs kept out of every persistent grid (conv / GEMM grids are sized from the CU count): room for the collective library's kernels
+ * beside the persistent work-groups in a multi-GPU run.  Initial value BBBP_COMM_CUS (default 0); ignored when fewer than 64 CUs would
+ * remain.  bench.py's N-rank diagnostic pass measures 0 against 8 and keeps the faster one.  Returns the previous value. */
+int bbbp_set_comm_cus(int n);
 /* The head / fusion-block input-gradient chain of bbbp_mixed_backward as two fused launches instead of ten (default on since
  * round 2: 3.32 -> 3.27 ms per step at B = 512).  Returns the previous setting.  Initial value: BBBP_FUSED_HEAD_BWD. */
 int bbbp_set_fused_head_bwd(int on);

@@ -168,3 +168,48 @@ def test_exact_batch_ranks_draw_different_dropout_seeds_on_gloo_world2():
     want = [int(torch.randint(0, 2 ** 62, (1,)).item()) for _ in range(3)]
     assert s0 == want
     assert s1 == [((w + 0x9E3779B97F4A7C15) & (2 ** 62 - 1)) or 1 for w in want]
+
+
+def _comm_diag_worker(rank, world, port):
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    state = {"cus": -1, "calls": []}
+    grads = torch.ones(1 << 16)
+
+    def set_cus(c):
+        state["calls"].append(c); state["cus"] = c
+        return 0
+
+    def no_coll(i):
+        time.sleep(0.004)
+
+    def overlapped(i):                                   # rank 1 is the slow one at 0 reserved CUs; both are faster with 8
+        time.sleep(0.004 + (0.030 if state["cus"] == 0 else 0.005) * (1 + rank))     # (no collective inside: gloo's jitter here is 10-30 ms)
+
+    out = bench.comm_diagnostics(dist, rank, world, dist.barrier, overlapped, no_coll, lambda i: dist.all_reduce(grads.clone()), set_cus,
+                                 grads.numel() * 4, candidates=(0, 8), steps=3, warmup=1)
+    dist.barrier()
+    dist.destroy_process_group()
+    return rank, out, state
+
+
+def test_bench_comm_diagnostics_fields_and_rank0_choice_on_gloo_world2():
+    """bench.py's N-rank diagnostic pass on the CPU with stand-in steps: every field of the `comm` object is
+    present, the times are the MAX over ranks (identical on both), the reserved-CU candidate with the smaller overlapped step is chosen
+    by rank 0 and left set on EVERY rank, exposed = overlapped[chosen] - step without collectives."""
+    from helpers import run_ranks
+    res = sorted(run_ranks(_comm_diag_worker, 2, timeout=180), key=lambda r: r[0])
+    (_, a, sa), (_, b, sb) = res
+    for k in ("exposed_ms", "step_no_collective_ms", "plain_allreduce_ms", "comm_cus_chosen", "bytes", "algbw_GBps", "busbw_GBps", "overlapped_ms"):
+        assert k in a and k in b, k
+    assert a == b                                        # MAX over ranks + rank 0's broadcast choice: the same object everywhere
+    assert a["comm_cus_chosen"] == 8 and sa["cus"] == 8 and sb["cus"] == 8 and sa["calls"] == [0, 8, 8]
+    assert a["bytes"] == 4 << 16 and a["algbw_GBps"] > 0 and abs(a["busbw_GBps"] - a["algbw_GBps"]) < 1e-2 + 0.01 * a["algbw_GBps"]   # 2 (N-1) / N = 1
+    assert a["overlapped_ms"]["0"] > a["overlapped_ms"]["8"] > a["step_no_collective_ms"] >= 3.9
+    assert abs(a["exposed_ms"] - (a["overlapped_ms"]["8"] - a["step_no_collective_ms"])) < 1e-3
+    assert 9.0 <= a["exposed_ms"] <= 20.0                # rank 1 sleeps 10 ms more than the collective-free step

@@ -178,6 +178,46 @@ def test_linear_layernorm_fused_matches_gemm_then_layernorm(dev, M, N, K, p):
         ops.linear_layernorm_fwd(torch.zeros(4, 8, device=dev), torch.zeros(300, 8, device=dev), None, None, torch.ones(300, device=dev), torch.zeros(300, device=dev))
 
 
+@pytest.mark.parametrize("M,N,K,act,p", [(512, 2048, 167, "relu", 0.1), (512, 501, 167, None, 0.0), (37, 128, 167, "relu", 0.0), (5, 33, 64, None, 0.0),
+                                         (100, 70, 176, "tanh", 0.25), (33, 17, 192, None, 0.0), (7, 16, 16, None, 0.0), (3, 5, 7, "relu", 0.0)])
+def test_layernorm_absorbed_by_the_consuming_linear(dev, M, N, K, act, p):
+    """bbbp_layernorm_linear_fwd (round 4): out = dropout(act(LayerNorm(z) W^T + b)) with the LayerNorm taken from the product's own operand
+    stream, and y / mean / rstd written by the same launch.  Against (i) the float64 composition, (ii) the two-launch schedule it
+    replaces -- bbbp_layernorm_fwd followed by the GEMM with the same dropout stream: y, mean, rstd and out to rounding, the same dropped
+    positions.  Rows with a LARGE common offset (mean >> spread: the pivot
+    keeps the row sums from cancelling) are part of the case."""
+    z = rnd(M, K, seed=41)
+    z[: max(1, M // 3)] += 30.0                                # mean / std ~ 30 (the stand-alone kernel's own (z - mean) loses ~2e-6 there)
+    z = z.to(dev)
+    gam, bet = (1 + 0.2 * rnd(K, seed=42)).to(dev), (0.3 * rnd(K, seed=43)).to(dev)
+    w, b = rnd(N, K, seed=44, scale=0.2).to(dev), rnd(N, seed=45).to(dev)
+    acts = {None: 0, "relu": 1, "tanh": 2}
+    out, y, mean, rstd = ops.layernorm_linear_fwd(z, gam, bet, w, b, act=acts[act], dropout_p=p, seed=777)
+    y0, _, m0, r0 = ops.layernorm_fwd(z.clone(), None, gam, bet)
+    # (the writer work-groups run the row kernel's arithmetic: equal to the last bits or so -- two translation units, two FMA contractions)
+    assert_close(mean.cpu().numpy(), m0.cpu().numpy(), rtol=1e-6, atol_frac=1e-7, what="mean")
+    assert_close(rstd.cpu().numpy(), r0.cpu().numpy(), rtol=2e-6, atol_frac=1e-7, what="rstd")
+    assert_close(y.cpu().numpy(), y0.cpu().numpy(), rtol=1e-5, atol_frac=2e-6, what="y")
+    if p > 0 and ops._lib.lib().bbbp_gemm_folds_asum(M, N, K, 1):
+        two = ops.gemm_grouped([dict(a=y0, b=w, trans_b=True, bias=b, act=act, dropout_p=p, dropout_seed=777)])[0]
+    else:
+        two = ops.gemm(y0, w, trans_b=True, bias=b, act=act)
+        if p > 0:
+            two = ops.dropout(two, p, 777)
+    assert torch.equal(out == 0, two == 0) or act == "relu" and float(((out == 0) != (two == 0)).float().mean()) < 1e-4   # ReLU near-zeros may differ
+    assert_close(out.cpu().numpy(), two.cpu().numpy(), rtol=2e-4, atol_frac=5e-5, what="out vs layernorm + gemm")
+    zz = z.double().cpu()
+    want_y = torch.nn.functional.layer_norm(zz, (K,), gam.double().cpu(), bet.double().cpu(), 1e-5)
+    lin = want_y @ w.double().cpu().t() + b.double().cpu()
+    lin = torch.relu(lin) if act == "relu" else torch.tanh(lin) if act == "tanh" else lin
+    keep = (two != 0).cpu() | (lin == 0) if p > 0 else torch.ones_like(lin, dtype=torch.bool)
+    scale = 1.0 / (1.0 - p) if p > 0 else 1.0
+    assert_close(torch.where(keep, out.cpu().double(), torch.zeros_like(lin)).numpy(), torch.where(keep, lin * scale, torch.zeros_like(lin)).numpy(),
+                 rtol=2e-4, atol_frac=2e-5, what="out vs float64")
+    with pytest.raises(RuntimeError):
+        ops.layernorm_linear_fwd(torch.zeros(4, 200, device=dev), torch.ones(200, device=dev), torch.zeros(200, device=dev), torch.zeros(8, 200, device=dev), None)
+
+
 def test_gemm_errors(dev):
     with pytest.raises(RuntimeError):
         ops.gemm(torch.zeros(4, 5), torch.zeros(5, 6))                    # CPU tensors: no fallback

@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""R^2 / MSE acceptance at B3DB scale (north_star: "R^2/MSE within +-0.002 of reference").
+
+The published fold loop (Models/multi_input_data_regression_opt_transformer_cnn_20250113.py:146-241: KFold(10, shuffle, 42), a fresh
+MixedInputModel + AdamW(1e-4, wd 1e-5) per fold, batch 32, train mode for epoch 1 only -- the faithful quirk) on the 1 058 B3DB molecules
+that have a drawing: real logBB labels, the reference's own depictions (kept as Pillow-resized bytes in tests/golden/b3db_images_u8.npz),
+synthetic MACCS-shaped bits (no RDKit), dropout off.  tests/golden/b3db_oof.npz holds the held-out predictions of the REFERENCE CLASS
+itself run on the CPU in float32 and in float64 (tools/make_golden.py b3db_oof).  This script trains the same folds on the GPU -- inputs
+through the HIP preprocessing (uint8 -> ToTensor -> per-chunk StandardScaler), `training.cross_validate_oof`, fused AdamW -- and prints
+
+    R^2 / MSE of: GPU (HIP path), CPU float32 (reference class), CPU float64 (reference class, the yardstick)
+
+and the pairwise prediction differences.  One gpurun call (~1 min of GPU); writes gpurun_out/r04_b3db_r2.txt.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bbbp_amd                                              # noqa: E402
+from bbbp_amd import preprocess, training                    # noqa: E402
+
+
+def metrics(y, p):
+    return training.r2_score(y, p), training.mean_squared_error(y, p)
+
+
+def main():
+    dev = torch.device("cuda")
+    d = np.load(os.path.join(ROOT, "tests", "golden", "b3db_images_u8.npz"))
+    g = np.load(os.path.join(ROOT, "tests", "golden", "b3db_oof.npz"))
+    imgs_u8, bits, ys = d["images_u8"], d["bits_u8"], d["logBB"]
+    N, EPOCHS, BS, SEED = int(g["meta/N"]), int(g["meta/epochs"]), int(g["meta/batch_size"]), int(g["meta/init_seed"])
+    assert N == len(ys)
+    # ToTensor (uint8 HWC -> float32 CHW / 255) and the per-chunk-of-100 StandardScaler, on the GPU (bit-identical to the CPU pipeline:
+    # tests/test_gpu_preprocess.py)
+    flat = (torch.from_numpy(imgs_u8).to(dev).permute(0, 3, 1, 2).contiguous().float() / 255.0).reshape(N, -1)
+    fp_n, img_n = preprocess.standardize_features(torch.from_numpy(bits).to(dev), flat)
+    chk = np.array([float(fp_n.double().sum()), float(img_n.double().sum()), float(ys.sum())])
+    print("input checksums (GPU pipeline vs the golden's CPU pipeline):", chk, g["inputs/checksum"])
+    # (sums of ~52 M standardised values that cancel to ~0: the CPU pipeline rounds float64 -> float32 at the end, the GPU kernel computes in
+    # float32 -- 1e-10 of the absolute sum is rounding)
+    assert np.allclose(chk, g["inputs/checksum"], rtol=1e-9, atol=1e-9 * float(img_n.double().abs().sum())), "the GPU preprocessing produced different inputs"
+    folds = training.kfold_indices(N, 10)
+    for k, (_, te) in enumerate(folds):
+        assert np.array_equal(te, g[f"fold{k}/test_idx"])
+    rng = np.random.default_rng(int(g["meta/order_seed"]))
+    orders = [[rng.permutation(len(tr)) for _ in range(EPOCHS)] for tr, _ in folds]
+
+    def factory():
+        m = bbbp_amd.MixedInputModel(167, 128)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+        return m
+
+    # the drop-in draws the reference class's initial weights under the same seed
+    for k in (0, 9):
+        torch.manual_seed(SEED + k)
+        sd = factory().state_dict()
+        got = [sum(float(v.double().sum()) for v in sd.values() if v.dtype.is_floating_point),
+               sum(float(v.double().abs().sum()) for v in sd.values() if v.dtype.is_floating_point)]
+        assert np.allclose(got, g[f"fold{k}/param_checksum"], rtol=1e-9), (k, got, g[f"fold{k}/param_checksum"])
+    t0 = time.perf_counter()
+    got = training.cross_validate_oof(fp_n.cpu(), img_n.cpu(), ys, model_factory=factory, n_splits=10, epochs=EPOCHS, batch_size=BS,
+                                      rf_params=False, init_seed=SEED, device=dev, folds=folds, batch_orders=orders)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    y32 = torch.from_numpy(ys).float().double().numpy()       # MixedDataset casts labels to float32
+    cols = {"GPU (HIP path, float32)": got["nn"], "CPU float32 (reference class)": g["nn_f32"], "CPU float64 (reference class)": g["nn_f64"]}
+    lines = [f"B3DB-scale acceptance: {N} molecules, 10 folds x {EPOCHS} epochs, batch {BS}, faithful loop, dropout off; GPU wall {wall:.1f} s "
+             f"({10 * EPOCHS * (N * 9 // 10) / wall:.0f} molecule-steps/s incl. validation passes)"]
+    res = {}
+    for name, p in cols.items():
+        res[name] = metrics(y32, p)
+        lines.append(f"  {name:34s} R^2 {res[name][0]:.6f}   MSE {res[name][1]:.6f}")
+    r64 = res["CPU float64 (reference class)"]
+    for name in ("GPU (HIP path, float32)", "CPU float32 (reference class)"):
+        lines.append(f"  {name:34s} vs float64: dR^2 {res[name][0] - r64[0]:+.6f}  dMSE {res[name][1] - r64[1]:+.6f}   "
+                     f"max |pred - f64| {np.max(np.abs(cols[name] - g['nn_f64'])):.4f}  rms {np.sqrt(np.mean((cols[name] - g['nn_f64']) ** 2)):.5f}")
+    lines.append(f"  GPU vs CPU float32: max |diff| {np.max(np.abs(got['nn'] - g['nn_f32'])):.4f}  rms {np.sqrt(np.mean((got['nn'] - g['nn_f32']) ** 2)):.5f}")
+    for k in range(10):
+        lines.append(f"  fold {k}: final train loss GPU {got['train_loss'][k][-1]:.5f}  f32 {g[f'fold{k}/train_loss_f32'][-1]:.5f}  f64 {g[f'fold{k}/train_loss_f64'][-1]:.5f};"
+                     f"  epoch-1 train loss GPU {got['train_loss'][k][0]:.6f}  f64 {g[f'fold{k}/train_loss_f64'][0]:.6f}")
+    dg, dc = abs(res["GPU (HIP path, float32)"][0] - r64[0]), abs(res["CPU float32 (reference class)"][0] - r64[0])
+    mg, mc = abs(res["GPU (HIP path, float32)"][1] - r64[1]), abs(res["CPU float32 (reference class)"][1] - r64[1])
+    verdict = ("GPU within +-0.002 of float64 in R^2 and MSE" if dg <= 0.002 and mg <= 0.002 else
+               f"GPU outside +-0.002 of float64 (dR^2 {dg:.4f}, dMSE {mg:.4f}); the reference's own float32 run deviates by dR^2 {dc:.4f}, dMSE {mc:.4f}: "
+               + ("GPU within 1x the CPU-float32 deviation" if dg <= max(dc, 0.002) and mg <= max(mc, 0.002) else "GPU deviates MORE than CPU float32"))
+    lines.append("  verdict: " + verdict)
+    out = "\n".join(lines)
+    print(out)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    open(os.path.join(ROOT, "gpurun_out", "r04_b3db_r2.txt"), "w").write(out + "\n")
+
+
+if __name__ == "__main__":
+    main()
