@@ -120,12 +120,16 @@ _SIGNATURES = {
     "bbbp_mse": (c_int, [c_void_p, _FP, _FP, _FP, _FP, c_int, c_float]),
     "bbbp_adamw_step": (c_int, [c_void_p, _FP, _FP, _FP, _FP, c_long, c_float, c_float, c_float, c_float, c_float, c_int,
                                 c_float]),
+    "bbbp_adamw_step_deferred": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_long, c_float, c_float, c_float, c_float, c_float, c_int, c_float]),
+    "bbbp_param_sync": (c_int, [c_void_p]),
+    "bbbp_param_stream": (c_void_p, []),
     "bbbp_scale": (c_int, [c_void_p, _FP, c_long, c_float]),
     "bbbp_resize_bilinear_totensor": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _FP, c_void_p, c_void_p, c_int, c_void_p,
                                               c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
     "bbbp_standardize_chunk": (c_int, [c_void_p, c_void_p, _FP, _FP, _FP, c_void_p, c_void_p, c_int, c_int, c_int]),
     "bbbp_set_partition": (c_int, [c_int, c_size_t]),
     "bbbp_set_comm_cus": (c_int, [c_int]),
+    "bbbp_set_ln_absorb": (c_int, [c_int]),
     "bbbp_set_overlap": (c_int, [c_int]),
     "bbbp_profile_enable": (c_int, [c_int]),
     "bbbp_profile_select": (c_int, [ctypes.c_uint]),

@@ -123,6 +123,10 @@ size_t bbbp_b3_conv1_fwd_workspace_bytes();
 int bbbp_b3_conv1_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* y, uint8_t* mask, int B, void* workspace);
 int bbbp_b3_conv1_wgrad(hipStream_t st, const float* x, const float* gy, const uint8_t* mask, float* slab, float* bslab, int B, int grid);
 int bbbp_wino_last_phases(unsigned long long* phases4);     // BBBP_WINO_PROBE=1 builds of the kernel only
+// rowops.hip: a slice of the optimizer step deferred to a side stream (bbbp_adamw_step_deferred).  Entry points that read parameters
+// order themselves behind it: bbbp_param_wait(stream, ptr) waits when ptr lies in the slice (null: unconditionally)
+int bbbp_param_wait(hipStream_t st, const void* ptr);
+bool bbbp_param_pending_elsewhere(const void* ptr);
 // gemm.hip: LayerNorm absorbed by the consuming Linear (bbbp_layernorm_linear_fwd) -- is that the faster form for this product?
 bool bbbp_layernorm_linear_preferred(int M, int N, int K);
 // fold.hip: out_proj folded into the value projection of a one-head encoder layer (W' = Wo Wv, b' = Wo bv) and the gradients unfolded

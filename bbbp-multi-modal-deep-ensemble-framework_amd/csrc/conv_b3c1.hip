@@ -449,7 +449,7 @@ size_t bbbp_b3_conv1_fwd_workspace_bytes() { return (size_t)WFRAG_WORDS * sizeof
 
 int bbbp_b3_conv1_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* y, uint8_t* mask, int B, void* workspace) {
     uint32_t* wf = static_cast<uint32_t*>(workspace);
-    static const int pipe = [] { const char* e = getenv("BBBP_C1_PIPE"); return e ? atoi(e) : 0; }();     // round 4: 1 = the software-pipelined form (0: round 3's kernel)
+    static const int pipe = [] { const char* e = getenv("BBBP_C1_PIPE"); return e ? atoi(e) : 1; }();     // round 4: the software-pipelined form (0: round 3's phase-by-phase kernel)
     hipLaunchKernelGGL(c1_prep_kernel, dim3(3), dim3(256), 0, st, w, wf, pipe ? bias : nullptr);
     BBBP_CHECK_LAUNCH();
     static const int exp_bits = [] { const char* e = getenv("BBBP_C1_EXP"); return e ? atoi(e) : 0; }();

@@ -102,6 +102,14 @@ int fold_outproj_on() {
     if (g_fold_outproj < 0) { const char* e = getenv("BBBP_FOLD_OUTPROJ"); g_fold_outproj = e ? (atoi(e) & 3) : 3; }
     return g_fold_outproj;
 }
+// LayerNorm absorbed by the consuming Linear (gemm.hip: gemm_direct_lna_kernel).  Default OFF: measured SLOWER inside the B = 512 step
+// (profiles/r04_ln_absorb.txt: the encoder's forward chain 0.826 -> 0.857 ms on the device timeline, step 2.487 -> 2.504 ms -- the absorbing
+// GEMMs pay more for their row statistics / gamma / beta work beside the conv kernels than the twelve LayerNorm launches cost).
+int g_ln_absorb = -1;
+int ln_absorb_on() {
+    if (g_ln_absorb < 0) { const char* e = getenv("BBBP_LN_ABSORB"); g_ln_absorb = e ? (atoi(e) != 0) : 0; }
+    return g_ln_absorb;
+}
 int fused_encoder_mode() {
     if (g_fused_encoder < 0) { const char* e = getenv("BBBP_FUSED_ENCODER"); g_fused_encoder = e ? atoi(e) & 7 : 0; }
     return g_fused_encoder;
@@ -550,6 +558,8 @@ extern "C" int bbbp_set_flash_attention(int on) {
     return prev;
 }
 
+extern "C" int bbbp_set_ln_absorb(int on) { const int prev = ln_absorb_on(); g_ln_absorb = on ? 1 : 0; return prev; }
+
 extern "C" int bbbp_set_overlap(int on) { int old = overlap_enabled() ? 1 : 0; g_overlap = on ? 1 : 0; return old; }
 
 // Profiling: enable, run steps, synchronise the stream, then collect {sum of ms, launches} per section.
@@ -607,6 +617,8 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
     }
     Ctx c{static_cast<hipStream_t>(stream), static_cast<char*>(workspace), &plan};
     const PIdx ix(d);
+    // a deferred optimizer slice that is NOT this model's image-FC weight (another model's step, another tensor): wait before anything runs
+    if (bbbp_param_pending_elsewhere(P[ix.ifc_w()])) (void)bbbp_param_wait(c.st, nullptr);
     const int B = plan.B, F = plan.F, NH = plan.NH, D = plan.D, DFF = plan.DFF;
     const int Bk = (int)plan.Bg;            // attention keys: this rank's rows, or every rank's in exact-global-batch mode
     const float p_drop = plan.drop ? d->dropout_p : 0.f;
@@ -637,8 +649,9 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
         // beside a training step's encoder chain the f32 form stays (common.h: g_bbbp_conv1_fwd_f32); screening batches, eval loops and
         // the encoder-less two-branch model take the split-bf16 form when the conv mask selects it (bit 6, default)
         // (the rule looks at the plan only, not at the stream mode: one stream or three give bit-identical steps)
-        // round 4: BBBP_C1_TRAIN=1 runs the software-pipelined split-bf16 kernel (conv_b3c1.hip) in training steps too, ONE work-group per CU
-        static const int c1_train = [] { const char* e = getenv("BBBP_C1_TRAIN"); return e ? atoi(e) : 0; }();
+        // round 4: training steps run the software-pipelined split-bf16 kernel (conv_b3c1.hip) too, ONE work-group per CU beside the chain
+        // (BBBP_C1_TRAIN=0: the f32 kernel of rounds 1-3 there; 2: two work-groups per CU, measured slower for the step)
+        static const int c1_train = [] { const char* e = getenv("BBBP_C1_TRAIN"); return e ? atoi(e) : 1; }();      // default 1: step 2.517 -> 2.487 ms (profiles/r04_c1_pipe.txt)
         const bool beside_chain = !plan.inference && plan.L > 0;
         g_bbbp_conv1_fwd_f32 = (beside_chain && !c1_train) ? 1 : 0;
         g_bbbp_conv1_fwd_per_cu = (beside_chain && c1_train) ? (c1_train >= 2 ? 2 : 1) : 0;      // BBBP_C1_TRAIN=2: two work-groups per CU there too
@@ -654,6 +667,7 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
     }
     {
         Section s3(c.st, SEC_IMGFC_FWD);
+        (void)bbbp_param_wait(c.st, P[ix.ifc_w()]);        // the optimizer's deferred image-FC slice (bbbp_adamw_step_deferred): first read here
         TRY(linear_fwd(c, pool2, IMG_FLAT, P[ix.ifc_w()], P[ix.ifc_b()], comb + FC, COMB, B, FC, IMG_FLAT, BBBP_ACT_RELU));
     }
 
@@ -726,8 +740,7 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
     // move into the epilogue of the GEMM that produces it (same Philox elements), so z1 / z2, y1 / y2 and the row statistics the backward
     // pass reads are the same tensors as before.
     struct { const float* z; const float* gamma; const float* beta; float* y; float* mean; float* rstd; } pend = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    static const int ln_absorb = [] { const char* e = getenv("BBBP_LN_ABSORB"); return e ? atoi(e) : 1; }();
-    const bool lna_ok = ln_absorb && !plan.exact && plan.L > 0 && bbbp_layernorm_linear_preferred(B, DFF, F) && bbbp_layernorm_linear_preferred(B, 3 * F, F) &&
+    const bool lna_ok = ln_absorb_on() && !plan.exact && plan.L > 0 && bbbp_layernorm_linear_preferred(B, DFF, F) && bbbp_layernorm_linear_preferred(B, 3 * F, F) &&
                         bbbp_layernorm_linear_preferred(B, FC, F) &&
                         // training: the producers' dropout rides in the small-product GEMM's epilogue only
                         (!plan.drop || (bbbp_gemm_folds_asum(B, F, DFF, 1) && bbbp_gemm_folds_asum(B, F, plan.fold ? Bk : F, 1)));
@@ -919,6 +932,7 @@ static int backward_enqueue(void* stream, const bbbp_mixed_desc* d, const float*
     SeedScope seed_scope(reinterpret_cast<const unsigned long long*>(static_cast<char*>(workspace) + plan.seed_slot));
     BBBP_CHECK_ARG(P && G && fingerprint && image && dout && workspace, "mixed_backward: null pointer");
     BBBP_CHECK_ARG(!plan.inference, "mixed_backward: the forward call used an inference workspace (desc.inference = 1)");
+    (void)bbbp_param_wait(static_cast<hipStream_t>(stream), nullptr);      // (a deferred optimizer slice: normally consumed by the forward pass already)
     if (workspace_bytes < plan.total) {
         bbbp_set_error("mixed_backward: workspace %zu < %zu bytes", workspace_bytes, plan.total);
         return BBBP_ERR_WORKSPACE;

@@ -8,6 +8,7 @@
 #include "common.h"
 #include "bbbp_hip.h"
 #include <stdlib.h>
+#include <mutex>
 
 namespace {
 
@@ -747,10 +748,57 @@ extern "C" int bbbp_mse(void* stream, const float* pred, const float* target, fl
     return BBBP_OK;
 }
 
+// ---- a slice of the update on a side stream (round 4: the serial stretch between two steps) -------------------------------------
+// The optimizer step is HBM-bound (28 bytes per parameter: 0.065 ms at F = 167) and nothing of the model runs beside it.  62 % of its bytes
+// are the image-FC weight, which the NEXT forward pass does not read before its third kernel (0.8 ms in).  bbbp_adamw_step_deferred updates
+// everything else on the caller's stream and that slice on a library-owned stream, behind an event; bbbp_mixed_forward waits for the event
+// right before the image FC (any other entry point that touches parameters waits at its start: bbbp_param_wait).  Same kernel, same
+// element-wise arithmetic: the parameters are bit-identical to the one-launch step's.
+namespace {
+struct DeferredSlice { hipStream_t stream = nullptr; hipEvent_t ready = nullptr, grads = nullptr; bool pending = false; const char* lo = nullptr; const char* hi = nullptr; };
+DeferredSlice g_deferred[64];
+std::mutex g_deferred_mu;
+}  // namespace
+
+// make `st` wait for a pending deferred slice.  `ptr` != null: only when ptr lies inside the slice (the caller is about to read that tensor);
+// null: unconditionally (the caller may read any parameter).  Returns 1 when a wait was enqueued, 0 when there was nothing to wait for.
+int bbbp_param_wait(hipStream_t st, const void* ptr) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> lock(g_deferred_mu);
+    DeferredSlice& d = g_deferred[dev];
+    if (!d.pending) return 0;
+    if (ptr && !(static_cast<const char*>(ptr) >= d.lo && static_cast<const char*>(ptr) < d.hi)) return 0;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    if (cap != hipStreamCaptureStatusNone) { (void)hipEventSynchronize(d.ready); d.pending = false; return 0; }   // never wait for an outside event inside a capture
+    (void)hipStreamWaitEvent(st, d.ready, 0);
+    d.pending = false;
+    return 1;
+}
+extern "C" int bbbp_param_sync(void* stream) { (void)bbbp_param_wait(static_cast<hipStream_t>(stream), nullptr); return BBBP_OK; }
+// the side stream of the current device (null before the first deferred step): a caller whose allocator is stream-ordered must know that the
+// gradient buffer is in use there (torch: tensor.record_stream)
+extern "C" void* bbbp_param_stream(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_deferred_mu);
+    return g_deferred[dev].stream;
+}
+// is a deferred slice pending that does NOT contain ptr?  (forward: then wait at the start instead of at the image FC)
+bool bbbp_param_pending_elsewhere(const void* ptr) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    std::lock_guard<std::mutex> lock(g_deferred_mu);
+    const DeferredSlice& d = g_deferred[dev];
+    return d.pending && !(static_cast<const char*>(ptr) >= d.lo && static_cast<const char*>(ptr) < d.hi);
+}
+
 extern "C" int bbbp_adamw_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
                                float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale) {
     BBBP_CHECK_ARG(step >= 1, "adamw: step is 1-based, got %d", step);
     if (n == 0) return BBBP_OK;
+    (void)bbbp_param_wait(static_cast<hipStream_t>(stream), nullptr);     // a deferred slice of an earlier step is ordered before this update
     double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     float decay = (float)(1.0 - (double)lr * (double)weight_decay);
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), g_bbbp_small_lds_pad, ST, param, grad, exp_avg, exp_avg_sq, n, decay,
@@ -764,5 +812,51 @@ extern "C" int bbbp_scale(void* stream, float* x, long n, float s) {
     if (n == 0) return BBBP_OK;
     hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), g_bbbp_small_lds_pad, ST, x, n, s);
     BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+extern "C" int bbbp_adamw_step_deferred(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, long lo, long hi,
+                                        float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale) {
+    BBBP_CHECK_ARG(step >= 1, "adamw: step is 1-based, got %d", step);
+    BBBP_CHECK_ARG(n >= 0 && lo >= 0 && lo <= hi && hi <= n, "adamw_deferred: slice [%ld, %ld) of %ld", lo, hi, n);
+    BBBP_CHECK_ARG(n == 0 || (param && grad && exp_avg && exp_avg_sq), "adamw_deferred: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    (void)bbbp_param_wait(st, nullptr);                       // an earlier deferred slice first
+    int dev = 0;
+    BBBP_CHECK_HIP(hipGetDevice(&dev));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    if (hi == lo || dev < 0 || dev >= 64 || cap != hipStreamCaptureStatusNone)
+        return bbbp_adamw_step(stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+    DeferredSlice& d = g_deferred[dev];
+    {
+        std::lock_guard<std::mutex> lock(g_deferred_mu);
+        if (!d.stream) {
+            BBBP_CHECK_HIP(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+            BBBP_CHECK_HIP(hipEventCreateWithFlags(&d.ready, hipEventDisableTiming));
+            BBBP_CHECK_HIP(hipEventCreateWithFlags(&d.grads, hipEventDisableTiming));
+        }
+    }
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const float decay = (float)(1.0 - (double)lr * (double)weight_decay);
+    auto launch = [&](hipStream_t s, long a, long b) {
+        if (b > a)
+            hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(b - a)), dim3(256), g_bbbp_small_lds_pad, s, param + a, grad + a, exp_avg + a, exp_avg_sq + a,
+                               b - a, decay, (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), (float)((double)lr / bc1),
+                               (float)sqrt(bc2), eps, grad_scale);
+    };
+    // the gradients are final at this point of the caller's stream: the side stream starts there
+    BBBP_CHECK_HIP(hipEventRecord(d.grads, st));
+    BBBP_CHECK_HIP(hipStreamWaitEvent(d.stream, d.grads, 0));
+    launch(d.stream, lo, hi);
+    BBBP_CHECK_LAUNCH();
+    BBBP_CHECK_HIP(hipEventRecord(d.ready, d.stream));
+    launch(st, 0, lo);
+    launch(st, hi, n);
+    BBBP_CHECK_LAUNCH();
+    {
+        std::lock_guard<std::mutex> lock(g_deferred_mu);
+        d.pending = true; d.lo = reinterpret_cast<const char*>(param + lo); d.hi = reinterpret_cast<const char*>(param + hi);
+    }
     return BBBP_OK;
 }

@@ -237,6 +237,14 @@ def _pipelined_step(self, optimizer, params, grad_scale: float = 1.0) -> int:
     params = list(params)
     if any(p.grad is None for p in params):
         raise RuntimeError("OverlappedGradAllReduce.step: every parameter must have a gradient (call it right after backward())")
+    # the layout is validated BEFORE the step is counted (begin_flat_step advances every parameter's step counter, and an
+    # error after it left the bias correction one step ahead of the parameters)
+    from .models import flat_view_of as _flat
+    if sum(p.numel() for p in params) != self.total or not params[0].is_cuda:
+        raise RuntimeError("OverlappedGradAllReduce.step: the optimizer's parameters are not this model's")
+    g0 = _flat([p.grad for p in params])
+    if g0 is None or g0.numel() != self.total or not g0.is_cuda:
+        raise RuntimeError("OverlappedGradAllReduce.step: gradients are not the engine's one flat buffer; use allreduce_gradients + optimizer.step()")
     flat = optimizer.begin_flat_step()
     if flat is None:
         raise RuntimeError("OverlappedGradAllReduce.step needs bbbp_amd.optim.AdamW over the model's flat parameter buffer "

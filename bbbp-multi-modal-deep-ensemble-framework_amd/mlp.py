@@ -94,12 +94,17 @@ class GridMLPTrainer:
         return np.concatenate(parts)
 
     def fit(self, configs: Sequence[MLPConfig], epochs_per_launch: int = 8) -> List[FittedMLP]:
+        """Round 4 host side: (i) the fits sit in the device array in order of DECREASING cost (mini-batches per epoch x parameters): the
+        work-groups of a launch are handed out in array order and a work-group is a whole CU, so the few fits that do not get a CU at once
+        (270 fits, 256 CUs) are the cheapest ones instead of whatever the grid's order put last; (ii) the visiting orders of chunk k + 1 --
+        every estimator's own RandomState stream, 270 x epochs shuffles of ~5000 rows on the host -- are drawn WHILE the GPU trains chunk k
+        and travel as one pinned copy on a second stream (they used to sit between two launches: ~20 ms per epoch of the reference grid)."""
         L = _lib.lib()
         nm = len(configs)
         if nm == 0:
             return []
         dev = self.device
-        structs = (_lib.MlpModel * nm)()
+        E = int(epochs_per_launch)
         host = []
         for i, cfg in enumerate(configs):
             if cfg.activation not in _ACT:
@@ -113,60 +118,85 @@ class GridMLPTrainer:
             rs = np.random.RandomState(cfg.random_state)
             p0 = self._init_params(cfg, units, rs)
             bs = min(int(cfg.batch_size), n_train)
+            cost = -(-n_train // bs) * (len(p0) + 4000)          # mini-batches per epoch x (parameters + a per-update constant)
+            host.append(dict(cfg=cfg, rows=rows, rs=rs, idx=np.arange(n_train), units=units, p0=p0, bs=bs, n_train=n_train, cost=cost))
+        slot_of = np.argsort([-h["cost"] for h in host], kind="stable")      # slot k of the device array holds fit slot_of[k]
+        # one device buffer for every fit's visiting orders, two halves (the chunk being trained / the chunk being drawn)
+        offs, tot = [], 0
+        for k in range(nm):
+            offs.append(tot); tot += E * host[slot_of[k]]["n_train"]
+        orders_dev = torch.empty((2, tot), dtype=torch.int32, device=dev)
+        orders_host = [torch.empty(tot, dtype=torch.int32).pin_memory() for _ in range(2)]
+        structs = (_lib.MlpModel * nm)()
+        for k in range(nm):
+            h = host[slot_of[k]]
+            cfg, units, p0, bs, n_train = h["cfg"], h["units"], h["p0"], h["bs"], h["n_train"]
             width = sum(units[1:])
             t = dict(params=torch.from_numpy(p0).to(dev), m=torch.zeros(len(p0), dtype=torch.float64, device=dev),
                      v=torch.zeros(len(p0), dtype=torch.float64, device=dev),
                      g=torch.zeros(len(p0), dtype=torch.float64, device=dev),
                      act=torch.zeros(bs * width, dtype=torch.float64, device=dev),
                      delta=torch.zeros(bs * width, dtype=torch.float64, device=dev),
-                     order=torch.zeros((epochs_per_launch, n_train), dtype=torch.int32, device=dev),
                      curve=torch.zeros(cfg.max_iter, dtype=torch.float64, device=dev))
-            host.append(dict(cfg=cfg, rows=rows, rs=rs, idx=np.arange(n_train), units=units, t=t))
-            s = structs[i]
+            h["t"], h["slot"] = t, k
+            s = structs[k]
             s.n_layers = len(units) - 1
-            for k, u in enumerate(units):
-                s.units[k] = u
+            for q, u in enumerate(units):
+                s.units[q] = u
             s.activation, s.batch_size, s.n_train = _ACT[cfg.activation], bs, n_train
             s.n_iter_no_change, s.max_iter = cfg.n_iter_no_change, cfg.max_iter
             s.lr_init, s.alpha, s.beta1, s.beta2, s.eps, s.tol = (cfg.learning_rate_init, cfg.alpha, cfg.beta_1, cfg.beta_2,
                                                                     cfg.epsilon, cfg.tol)
             s.params, s.adam_m, s.adam_v, s.grads = (t["params"].data_ptr(), t["m"].data_ptr(), t["v"].data_ptr(),
                                                      t["g"].data_ptr())
-            s.act, s.delta, s.order, s.loss_curve = (t["act"].data_ptr(), t["delta"].data_ptr(), t["order"].data_ptr(),
-                                                     t["curve"].data_ptr())
+            s.act, s.delta, s.loss_curve = t["act"].data_ptr(), t["delta"].data_ptr(), t["curve"].data_ptr()
+            s.order = orders_dev[0].data_ptr() + 4 * offs[k]
             s.t, s.best_loss, s.no_improve, s.n_iter, s.done = 0, float("inf"), 0, 0, 0
         nbytes = ctypes.sizeof(structs)
         models_dev = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         staging = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-        live = list(range(nm))
-        first = True
-        while live:
-            # visiting order of the next chunk of epochs, from each estimator's own RandomState stream
-            for i in live:
-                h = host[i]
-                chunk = np.empty((epochs_per_launch, len(h["rows"])), dtype=np.int32)
-                for e in range(epochs_per_launch):
+        copy_stream = torch.cuda.Stream(device=dev)
+
+        def draw(half, live_slots):
+            """the next E epochs' visiting orders of the live fits, from each estimator's own RandomState stream, into half `half`"""
+            buf = orders_host[half].numpy()
+            for k in live_slots:
+                h = host[slot_of[k]]
+                n_train = h["n_train"]
+                for e in range(E):
                     # == sample_idx = sklearn.utils.shuffle(sample_idx, random_state=rs): resample() shuffles arange(n)
                     # with the RandomState and indexes the array with it
-                    perm = np.arange(len(h["idx"]))
+                    perm = np.arange(n_train)
                     h["rs"].shuffle(perm)
                     h["idx"] = h["idx"][perm]
-                    chunk[e] = h["rows"][h["idx"]]
-                h["t"]["order"].copy_(torch.from_numpy(chunk))
-            if first:
-                ctypes.memmove(staging.data_ptr(), ctypes.addressof(structs), nbytes)
-                models_dev.copy_(staging, non_blocking=False)
-                first = False
+                    buf[offs[k] + e * n_train: offs[k] + (e + 1) * n_train] = h["rows"][h["idx"]]
+            with torch.cuda.stream(copy_stream):
+                orders_dev[half].copy_(orders_host[half], non_blocking=True)
+
+        live = list(range(nm))
+        draw(0, live)
+        copy_stream.synchronize()
+        half = 0
+        while live:
+            for k in live:
+                structs[k].order = orders_dev[half].data_ptr() + 4 * offs[k]
+            ctypes.memmove(staging.data_ptr(), ctypes.addressof(structs), nbytes)
+            models_dev.copy_(staging, non_blocking=False)
+            torch.cuda.current_stream(dev).wait_stream(copy_stream)
             _lib.check(L.bbbp_mlp_train_epochs(ops._stream(), models_dev.data_ptr(), nm, self.X.data_ptr(), self.y.data_ptr(),
-                                               self.n_features, epochs_per_launch), "bbbp_mlp_train_epochs")
-            staging.copy_(models_dev)                      # synchronises
+                                               self.n_features, E), "bbbp_mlp_train_epochs")
+            draw(half ^ 1, live)                           # host work + the copy run beside the kernel (fits that finish in this chunk: wasted, harmless)
+            staging.copy_(models_dev)                      # synchronises with the kernel
             ctypes.memmove(ctypes.addressof(structs), staging.data_ptr(), nbytes)
-            live = [i for i in live if not structs[i].done]
+            live = [k for k in live if not structs[k].done]
+            half ^= 1
+        copy_stream.synchronize()
         self._models_dev, self._structs = models_dev, structs
         self._keep = host
+        self._orders = (orders_dev, orders_host)
         out = []
         for i, h in enumerate(host):
-            s, cfg, units = structs[i], h["cfg"], h["units"]
+            s, cfg, units = structs[h["slot"]], h["cfg"], h["units"]
             p = h["t"]["params"].cpu().numpy()
             coefs, inter, off = [], [], 0
             for fan_in, fan_out in zip(units[:-1], units[1:]):
@@ -186,7 +216,7 @@ class GridMLPTrainer:
             raise ValueError(f"X must be [n, {self.n_features}]")
         out = torch.empty(Xd.shape[0], dtype=torch.float64, device=self.device)
         max_units = max(self._keep[index]["units"][1:])
-        _lib.check(_lib.lib().bbbp_mlp_predict_proba(ops._stream(), self._models_dev.data_ptr(), index, Xd.data_ptr(), Xd.shape[0],
+        _lib.check(_lib.lib().bbbp_mlp_predict_proba(ops._stream(), self._models_dev.data_ptr(), self._keep[index]["slot"], Xd.data_ptr(), Xd.shape[0],
                                                      self.n_features, max_units, out.data_ptr()), "bbbp_mlp_predict_proba")
         return out.cpu().numpy()
 

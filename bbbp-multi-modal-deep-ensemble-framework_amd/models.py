@@ -100,11 +100,13 @@ class MultiHeadAttentionFusion(nn.Module):
 
 def _cached_ptrs(model, attr, tensors):
     """ctypes array of the tensors' device pointers, rebuilt only when the storage moved (e.g. after .to())."""
-    key = (tensors[0].data_ptr(), tensors[-1].data_ptr(), len(tensors))
+    # every pointer takes part in the key (ADVICE round 3: first / last only missed a middle parameter whose storage was replaced, e.g.
+    # `p.data = p.data.clone()` on one layer -- the engine then read a stale pointer); ~150 data_ptr() calls, 20 us
+    key = tuple(t.data_ptr() for t in tensors)
     cache = _PTR_CACHE.setdefault(model, {})          # kept off the module so that pickle.dump(model) still works
     hit = cache.get(attr)
     if hit is None or hit[0] != key:
-        hit = (key, _lib.ptr_array([t.data_ptr() for t in tensors]))
+        hit = (key, _lib.ptr_array(list(key)))
         cache[attr] = hit
     return hit[1]
 
@@ -166,6 +168,9 @@ class _CollectiveCall:
 
 _COLLECTIVE_CALLS = {}          # handle (bbbp_mixed_desc.collective_ctx) -> _CollectiveCall; dropped after the backward call
 _COLLECTIVE_NEXT = [1]
+_COLLECTIVE_MAX_PENDING = 64    # exact-batch forward calls that may wait for their backward call at once (gradient accumulation over micro-batches)
+_COLLECTIVE_ERRORS = []         # errors raised inside the callback for handles that have no call object any more
+_COLLECTIVE_DROPPED = set()     # handles evicted above: their backward call gets a clear error instead of 'callback returned 2'
 _COLLECTIVE_FN = []             # ONE ctypes thunk for the process: a thunk per call is a reference cycle that keeps its workspace alive until a GC
 
 
@@ -173,8 +178,10 @@ def _collective_register(call):
     handle = _COLLECTIVE_NEXT[0]
     _COLLECTIVE_NEXT[0] += 1
     _COLLECTIVE_CALLS[handle] = call
-    while len(_COLLECTIVE_CALLS) > 16:            # forward calls whose backward never came (evaluation under autograd): oldest first
-        _COLLECTIVE_CALLS.pop(next(iter(_COLLECTIVE_CALLS)))
+    while len(_COLLECTIVE_CALLS) > _COLLECTIVE_MAX_PENDING:      # forward calls whose backward never came (evaluation under autograd): oldest first
+        dropped = next(iter(_COLLECTIVE_CALLS))
+        _COLLECTIVE_CALLS.pop(dropped)
+        _COLLECTIVE_DROPPED.add(dropped)
     return handle
 
 
@@ -191,6 +198,10 @@ def _collective_fn():
     def cb(handle, op, what, layer, send_off, recv_off, count, stream):
         call = _COLLECTIVE_CALLS.get(handle)
         if call is None:
+            if handle in _COLLECTIVE_DROPPED:
+                _COLLECTIVE_ERRORS.append(RuntimeError(
+                    f"exact-batch mode: more than {_COLLECTIVE_MAX_PENDING} forward calls were waiting for their backward call; this one's "
+                    "collective state was dropped -- call backward() (or run under torch.no_grad()) before issuing that many forwards"))
             return 2
         try:
             ws, group, world, rank = call.ws, call.group, call.world, call.rank
@@ -310,6 +321,8 @@ class _MixedFn(torch.autograd.Function):
             _COLLECTIVE_CALLS.pop(ctx.handle, None)
         if rc and ctx.call is not None and ctx.call.errors:
             raise RuntimeError("bbbp_mixed_backward: collective failed") from ctx.call.errors[0]
+        if rc and _COLLECTIVE_ERRORS:
+            raise _COLLECTIVE_ERRORS.pop()
         _lib.check(rc, "bbbp_mixed_backward")
         return (None, None, None, None, *grads)
 

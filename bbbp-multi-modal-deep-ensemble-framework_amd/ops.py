@@ -359,3 +359,27 @@ def adamw_step_(param, grad, exp_avg, exp_avg_sq, step: int, lr=1e-4, betas=(0.9
     _lib.check(_lib.lib().bbbp_adamw_step(_stream(), param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(),
                                           exp_avg_sq.data_ptr(), param.numel(), lr, betas[0], betas[1], eps, weight_decay,
                                           step, grad_scale), "bbbp_adamw_step")
+
+
+def adamw_step_deferred_(param, grad, exp_avg, exp_avg_sq, step: int, lo: int, hi: int, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5,
+                         grad_scale: float = 1.0) -> None:
+    """``adamw_step_`` with elements [lo, hi) of the flat buffers updated on a library-owned side stream (``bbbp_adamw_step_deferred``):
+    the next ``MixedInputModel`` forward waits for that slice right before it reads it; ``param_sync()`` orders anything else."""
+    for t, n in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _chk(t, n)
+        if not t.is_contiguous():
+            raise RuntimeError(f"adamw: {n} must be contiguous")
+    _lib.check(_lib.lib().bbbp_adamw_step_deferred(_stream(), param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                                   param.numel(), lo, hi, lr, betas[0], betas[1], eps, weight_decay, step, grad_scale),
+               "bbbp_adamw_step_deferred")
+    # torch's caching allocator is stream-ordered: the gradient buffer is usually freed (zero_grad(set_to_none=True)) while the side stream may
+    # still read it -- tell the allocator, or the block could be handed to the next allocation on the current stream too early
+    h = _lib.lib().bbbp_param_stream()
+    if h:
+        side = torch.cuda.ExternalStream(int(h), device=param.device)
+        grad.record_stream(side)                 # (parameters and moments live as long as the optimizer)
+
+
+def param_sync() -> None:
+    """Order the current stream behind a deferred optimizer slice (no-op when none is pending)."""
+    _lib.check(_lib.lib().bbbp_param_sync(_stream()), "bbbp_param_sync")

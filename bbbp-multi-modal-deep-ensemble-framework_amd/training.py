@@ -68,7 +68,10 @@ def train_fold(model, train, test=None, *, epochs: int = 50, batch_size: int = 3
     if not (fp.is_cuda and img.is_cuda and y.is_cuda):
         raise RuntimeError("train_fold expects device-resident tensors")
     y = y.to(torch.float32)
-    opt = optimizer if optimizer is not None else AdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
+    if optimizer is not None:
+        opt = optimizer
+    else:
+        opt = AdamW(model.parameters(), lr=lr, weight_decay=weight_decay)      # (optim.AdamW(defer=...) is opt-in: measured slower on one GPU)
     crit = MSELoss()                      # nn.MSELoss semantics, fused value + gradient kernel
     N = fp.shape[0]
     if scheduler == "cosine_warm_restarts":
@@ -119,6 +122,8 @@ def train_fold(model, train, test=None, *, epochs: int = 50, batch_size: int = 3
             if patience_counter > early_stopping_patience:
                 hist["stopped_epoch"] = epoch
                 break
+    if hasattr(opt, "synchronize"):
+        opt.synchronize()                           # a deferred slice of the last step: the caller may read the parameters any way it likes
     return hist
 
 

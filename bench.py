@@ -321,7 +321,14 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
         model = ExactBatchMixedInputModel(F, 128).to(dev).train(train)
     else:
         model = getattr(bbbp_amd, cfg["model"])(F, 128).to(dev).train(train)
-    opt = AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5) if train else None
+    # round 4, opt-in (BBBP_BENCH_DEFER_ADAMW=1): the image-FC weight's slice of the optimizer step (62 % of its bytes) on a side stream beside the
+    # start of the next forward pass, which reads that weight 0.8 ms in (optim.AdamW(defer=...), bbbp_adamw_step_deferred).  Bit-identical, but
+    # measured SLOWER on one GPU (2.463 / 2.474 -> 2.479 / 2.496 ms, profiles/r04_defer_adamw.txt): the HBM-bound slice takes more from conv1 and the
+    # head of the encoder chain than the 0.04 ms it no longer spends after the pass.  Default: one launch after the pass.
+    defer = None
+    if train and os.environ.get("BBBP_BENCH_DEFER_ADAMW", "0") == "1" and hasattr(model, "image_cnn") and not args.exact_batch:
+        defer = model.image_cnn[7].weight
+    opt = AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, defer=defer) if train else None
     crit = bbbp_amd.MSELoss()             # nn.MSELoss semantics, value + gradient in one kernel
     params = list(model.parameters())
     stack = rf_col = xgb_col = None
@@ -662,7 +669,8 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
         # the metric's "+ optimizer step reported separately": fused AdamW over the flat parameter buffer (one launch,
         # 16 B read + 12 B written per parameter), included in ms_per_step
         result["optimizer"] = ("fused AdamW pipelined into the backward pass, slice by slice (distributed.OverlappedGradAllReduce.step)" if pipelined
-                               else "fused AdamW, one launch after the pass")
+                               else "fused AdamW after the pass; the image-FC weight's slice on a side stream beside the next forward pass (read there 0.8 ms in)"
+                               if defer is not None else "fused AdamW, one launch after the pass")
         result["optimizer_ms_per_step"] = round(sum(a.elapsed_time(b) for a, b in opt_events) / len(opt_events), 4) if opt_events else None
         result["final_loss"] = round(float(last.detach()), 5)
     if world == 1 and not args.no_cpu_baseline:

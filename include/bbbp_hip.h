@@ -193,6 +193,17 @@ int bbbp_fusion_combine_bwd(void* stream, const float* dout, const float* combin
 int bbbp_mse(void* stream, const float* pred, const float* target, float* loss, float* dpred, int n, float grad_scale);
 int bbbp_adamw_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
                     float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale);
+/* The same step with the slice [lo, hi) of the flat buffers updated on a library-owned side stream (round 4).  Everything else is updated on
+ * `stream`; the slice starts once the gradients are final (an event on `stream`) and runs beside whatever `stream` does next.  Readers are
+ * ordered behind it by the library: bbbp_mixed_forward waits right before its first read of a tensor inside the slice (the image-FC weight:
+ * 62 % of the optimizer's bytes, first read 0.8 ms into the next forward pass), every other entry point that reads parameters
+ * (bbbp_adamw_step*, bbbp_mixed_backward) waits at its start, and bbbp_param_sync(stream) orders ANY stream behind it (call it before
+ * reading parameters outside this library: state_dict(), checkpoints).  Element-wise arithmetic: the result is bit-identical to
+ * bbbp_adamw_step's.  Inside a stream capture, or with an empty slice, it IS bbbp_adamw_step. */
+int bbbp_adamw_step_deferred(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, long lo, long hi,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale);
+int bbbp_param_sync(void* stream);
+void* bbbp_param_stream(void);     /* the side stream of the current device (NULL before the first deferred step) */
 int bbbp_scale(void* stream, float* x, long n, float s);
 
 /* ---- input pipeline at the tensor boundary (Descriptors/multi_input_data_preprocess_maccs_opt_IsolationForest_fixed_1.py) ----
@@ -377,6 +388,10 @@ int bbbp_set_gemm_fold_reduce(int on);
  * [0] global-load issue, [1] LDS reads + MFMA block, [2] barrier after it, [3] split + LDS writes, [4] barrier after them, [5] all shader
  * cycles of that wave's K loop and [6] the same span in 100 MHz wall ticks (their ratio is the sustained shader clock). */
 int bbbp_gemm_split_bf16_phases(unsigned long long* phases7);
+/* LayerNorm absorbed by the Linear that consumes it inside bbbp_mixed_forward (bbbp_layernorm_linear_fwd for norm1 -> linear1 and norm2 -> the
+ * next in_proj / fingerprint_fc; dropout + residual move into the producing GEMM's epilogue).  Default 0 (initial value BBBP_LN_ABSORB):
+ * built, parity-tested and measured slower inside the B = 512 step.  Returns the previous setting. */
+int bbbp_set_ln_absorb(int on);
 int bbbp_set_overlap(int on);   /* two/three-stream branch overlap inside bbbp_mixed_forward/backward (default on) */
 /* Data-parallel overlap: the gradient of the image-FC weight (62 % of all gradient bytes at F = 167) is final after the
  * first GEMM of the image branch's backward.  wait_bucket(stream, 0) makes `stream` wait for exactly that point of the
