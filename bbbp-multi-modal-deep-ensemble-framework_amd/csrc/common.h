@@ -113,6 +113,11 @@ int bbbp_wino_last_clock(unsigned long long* shader_cycles, unsigned long long* 
 // conv_b3.hip: the same stage as a direct implicit GEMM on the bf16 matrix pipe with every float32 operand split into three bf16
 // pieces (six products per float32 product, float32 accumulate); workspace = bbbp_b3_workspace_bytes() of pre-split filters
 size_t bbbp_b3_workspace_bytes();
+// round 4: the same kernels for the two large stages of the wide / deep variant (64 -> 128 @ 64 x 64, 128 -> 256 @ 32 x 32)
+bool bbbp_b3_conv_supported(int cin, int cout, int hw);
+size_t bbbp_b3_workspace_bytes(int cin, int cout);
+int bbbp_b3_conv_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* y, uint8_t* mask, int B, int cin, int cout, void* workspace);
+int bbbp_b3_conv_dgrad(hipStream_t st, const float* gy, const uint8_t* gmask, const float* w, float* dx, int B, int cin, int cout, void* workspace);
 int bbbp_b3_conv2_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* y, uint8_t* mask, int B, void* workspace);
 int bbbp_b3_conv2_dgrad(hipStream_t st, const float* gy, const uint8_t* gmask, const float* w, float* dx, int B, void* workspace);
 // form: 0 dense split-bf16, 1 structured-sparse MFMA (8 waves, or 4 beside an encoder chain), 2 structured-sparse, 4 waves

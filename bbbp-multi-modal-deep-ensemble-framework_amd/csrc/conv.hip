@@ -839,6 +839,7 @@ extern "C" size_t bbbp_conv3x3_workspace_bytes(int B, int cin, int cout, int H, 
     // wgrad: (pairs * groups) slabs with pairs * groups <= 2 * 256 work-groups
     size_t slab = (size_t)2 * 256 * ((cin == 3 ? 1024 + 32 : (size_t)64 * 288 + 64)) * sizeof(float);
     size_t m = prep > prep_d ? prep : prep_d;
+    if (bbbp_b3_conv_supported(cin, cout, H) && bbbp_b3_workspace_bytes(cin, cout) > m) m = bbbp_b3_workspace_bytes(cin, cout);      // pre-split filters of the split-bf16 form
     return align_up(m > slab ? m : slab, 256);
 }
 
@@ -854,10 +855,10 @@ extern "C" int bbbp_conv3x3_relu_pool_fwd(void* stream, const float* x, const fl
     BBBP_CHECK_ARG(workspace_bytes >= need, "conv fwd: workspace %zu < %zu", workspace_bytes, need);
     float* wt = static_cast<float*>(workspace);
     g_last_clock_wino = 0;
-    if (cin == 32 && cout == 64 && (winograd_mask() & 4)) {
-        BBBP_CHECK_ARG(workspace_bytes >= bbbp_b3_workspace_bytes(), "conv fwd: workspace too small");
+    if (bbbp_b3_conv_supported(cin, cout, H) && H == W && (winograd_mask() & 4)) {
+        BBBP_CHECK_ARG(workspace_bytes >= bbbp_b3_workspace_bytes(cin, cout), "conv fwd: workspace too small");
         g_last_clock_wino = 2;               // split-bf16 kernel: its own stamps (conv_b3.hip)
-        return bbbp_b3_conv2_fwd(st, x, w, bias, y, mask, B, workspace);
+        return bbbp_b3_conv_fwd(st, x, w, bias, y, mask, B, cin, cout, workspace);
     }
     if (cin == 32 && cout == 64 && (winograd_mask() & 1)) {
         BBBP_CHECK_ARG(workspace_bytes >= (size_t)16 * 32 * 64 * sizeof(float), "conv fwd: workspace too small");
@@ -892,10 +893,10 @@ extern "C" int bbbp_conv3x3_relu_pool_bwd_data(void* stream, const float* gy, co
     BBBP_CHECK_ARG(workspace_bytes >= need, "conv bwd_data: workspace %zu < %zu", workspace_bytes, need);
     float* wt = static_cast<float*>(workspace);
     g_last_clock_wino = 0;
-    if (cin == 32 && cout == 64 && (winograd_mask() & 8)) {
-        BBBP_CHECK_ARG(workspace_bytes >= bbbp_b3_workspace_bytes(), "conv bwd_data: workspace too small");
+    if (bbbp_b3_conv_supported(cin, cout, H) && H == W && (winograd_mask() & 8)) {
+        BBBP_CHECK_ARG(workspace_bytes >= bbbp_b3_workspace_bytes(cin, cout), "conv bwd_data: workspace too small");
         g_last_clock_wino = 2;
-        return bbbp_b3_conv2_dgrad(st, gy, mask, w, dx, B, workspace);
+        return bbbp_b3_conv_dgrad(st, gy, mask, w, dx, B, cin, cout, workspace);
     }
     if (cin == 32 && cout == 64 && (winograd_mask() & 2)) {
         BBBP_CHECK_ARG(workspace_bytes >= (size_t)16 * 32 * 64 * sizeof(float), "conv bwd_data: workspace too small");

@@ -30,7 +30,7 @@ constexpr int CH = 16;                        // channels per stage = K of one M
 constexpr int XPLANE = ROWS * PXW * CH;       // bf16 elements of one plane of one stage
 constexpr int XBUF = 3 * XPLANE;
 constexpr int WSTAGE = 9 * 3 * 2 * 32 * 8;    // bf16 elements: [tap][plane][k-half][m][8]
-constexpr size_t LDS_BYTES = (size_t)(XBUF + WSTAGE) * 2;      // 65.7 KB: two work-groups per CU
+[[maybe_unused]] constexpr size_t LDS_BYTES = (size_t)(XBUF + WSTAGE) * 2;      // 65.7 KB (flagship geometry): two work-groups per CU
 
 struct B3Params {
     const float* x;         // FWD: input [B][32][64][64];  DGRAD: pooled gradient [B][64][32][32]
@@ -40,13 +40,15 @@ struct B3Params {
     float* y;               // FWD: pooled [B][64][32][32];  DGRAD: [B][32][64][64]
     uint8_t* ymask;         // FWD
     int B;
+    int prio;               // wave priority the kernel raises itself to (0: leave it): see conv_bwd_prio()
 };
 
 // filters -> [m-block][chunk][tap][plane][k-half][m 32][8] bf16.
 //   FWD  : m = output channel co (2 blocks of 32), k = input channel ci (2 chunks of 16), tap = kh * 3 + kw
 //   DGRAD: m = input channel ci (1 block), k = output channel co (4 chunks of 16), tap' = the flipped tap
-__global__ void b3_prep_kernel(const float* __restrict__ w, uint16_t* __restrict__ wp, int mode) {
-    const int nmb = mode == B3_FWD ? 2 : 1, nch = mode == B3_FWD ? 2 : 4;
+__global__ void b3_prep_kernel(const float* __restrict__ w, uint16_t* __restrict__ wp, int mode, int cin, int cout) {
+    // FWD  : m-blocks = cout / 32, chunks = cin / 16;   DGRAD: m-blocks = cin / 32, chunks = cout / 16
+    const int nmb = (mode == B3_FWD ? cout : cin) / 32, nch = (mode == B3_FWD ? cin : cout) / 16;
     const int total = nmb * nch * 9 * 2 * 32 * 4;                 // (mb, chunk, tap, half, m, pair-of-k)
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         int r = idx;
@@ -60,8 +62,8 @@ __global__ void b3_prep_kernel(const float* __restrict__ w, uint16_t* __restrict
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int k = chunk * 16 + 8 * h + 2 * pr + e;
-            if (mode == B3_FWD) v[e] = w[((mb * 32 + m) * 32 + k) * 9 + tap];          // W[co][ci][tap]
-            else v[e] = w[(k * 32 + m) * 9 + (8 - tap)];                                // W[co = k][ci = m][flipped tap]
+            if (mode == B3_FWD) v[e] = w[((long)(mb * 32 + m) * cin + k) * 9 + tap];          // W[co][ci][tap]
+            else v[e] = w[((long)k * cin + mb * 32 + m) * 9 + (8 - tap)];                      // W[co = k][ci = mb * 32 + m][flipped tap]
         }
         uint32_t hi, mid, lo;
         split2(v[0], v[1], hi, mid, lo);
@@ -71,6 +73,13 @@ __global__ void b3_prep_kernel(const float* __restrict__ w, uint16_t* __restrict
     }
 }
 
+// The stages this form serves: the flagship's second stage (32 -> 64 @ 64 x 64) and, since round 4, the two large stages of the wide / deep
+// variant (Models/..._opt_20250107_network.py:129-138: 64 -> 128 @ 64 x 64 and 128 -> 256 @ 32 x 32).  A work-group is always 4 waves of
+// 2 rows x 32 columns: 4 rows x 64 pixels on the 64-wide maps, 8 rows x 32 pixels on the 32-wide ones.
+template <int CIN_, int COUT_, int IMGS_>
+struct B3Geom { static constexpr int CIN = CIN_, COUT = COUT_, IMGS = IMGS_; };
+using GeomFlagship = B3Geom<32, 64, 64>;
+
 // phase breakdown of work-group 0 / wave 0 (BBBP_B3_PROBE=1 selects the stamping instantiation; tools/bench_conv2.py prints it): shader
 // cycles in [0] global-load issue, [1] MFMA block of a stage, [2] split + LDS writes + barriers, [3] epilogue
 __device__ unsigned long long g_b3_phase[4];
@@ -78,17 +87,21 @@ __device__ unsigned long long g_b3_phase[4];
 // ratio is the clock the chip sustains under this kernel -- ~1.9 GHz for bf16 MFMA loops on real data, not the 2.4 GHz of the spec
 __device__ unsigned long long g_b3_clock[2];
 
-template <int MODE, bool PROBE>
+template <int MODE, bool PROBE, class G>
 __device__ __forceinline__ void conv_b3_body(const B3Params& p) {
-    constexpr int KIN = MODE == B3_FWD ? 32 : 64;            // reduction channels
+    // geometry of this instantiation (the names shadow the flagship constants above, which the weight-gradient kernels keep using)
+    constexpr int IMG = G::IMGS, R = 256 / IMG, ROWS = R + 2, PXW = IMG + 2, XPLANE = ROWS * PXW * CH, XBUF = 3 * XPLANE;
+    constexpr int KIN = MODE == B3_FWD ? G::CIN : G::COUT;   // reduction channels
     constexpr int NCHUNK = KIN / CH;
-    constexpr int NMB = MODE == B3_FWD ? 2 : 1;              // blocks of 32 produced channels
+    constexpr int NMB = (MODE == B3_FWD ? G::COUT : G::CIN) / 32;      // blocks of 32 produced channels
+    constexpr int NOUT = NMB * 32;                           // produced channels in all
     constexpr int SRC_PLANE = MODE == B3_FWD ? IMG * IMG : (IMG / 2) * (IMG / 2);     // floats per source channel plane
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     uint16_t* Xs = smem;                                     // [plane 3][row][px][16]
     uint16_t* Ws = smem + XBUF;                              // [WSTAGE]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
     const unsigned long long clk_begin = __builtin_readcyclecounter(), wall_begin = wall_clock64();
+    if (p.prio >= 3) __builtin_amdgcn_s_setprio(3); else if (p.prio == 2) __builtin_amdgcn_s_setprio(2); else if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
 
     // the produced-channel block is fixed per work-group; blocks of one strip sit on one XCD (ids w and w + 8: common.h)
     const bool pairs = NMB == 2 && (gridDim.x & 15) == 0;
@@ -103,17 +116,32 @@ __device__ __forceinline__ void conv_b3_body(const B3Params& p) {
 
     // ---- stage loader: item = (channel group of 8, row, pixel); 8 dword loads -> split -> three 16-byte LDS writes.
     //      Everything that does not depend on the strip is computed once: a stage costs one uniform base + 32-bit offsets. ----
-    constexpr int ITEMS = 2 * ROWS * IMG, NIT = ITEMS / 256;
+    constexpr int ITEMS = 2 * ROWS * IMG, NIT = (ITEMS + 255) / 256;       // (32-wide maps: 640 items, the last round half empty)
+    constexpr bool RAGGED = ITEMS % 256 != 0;
     constexpr int WPIECES = WSTAGE * 2 / 16, WIT = (WPIECES + 255) / 256;       // 16-byte pieces of a filter stage per thread
+    // item i of thread t: idx = t + 256 i -> pixel px = t % 64 (the same for every item), row (t / 64 + 4 i) % 6, channel group idx / 384.
+    // RECOMPUTE (round 4, measured, OFF): the flagship's data-gradient kernel stands at 166 + 62 = 228 registers, two work-groups per CU =
+    // 2 x 232 per SIMD, which leaves 48 -- not one 64-register wave of the encoder chain can be placed on ANY SIMD while conv2's data gradient
+    // runs: the chain stalls for the kernel's whole 0.4 ms in every step (profiles/r04_stall_outliers.txt: exactly one chain launch and one leaf
+    // launch of ~400 us per step, both beside conv_b3_kernel<1>: the "stall outliers" of VERDICT round 3).  Recomputing these twelve index
+    // registers per stage from an opaque copy of t brings the kernel to 154 + 62 = 216 and the chain runs beside it (its backward 1.30 -> 1.13-1.19
+    // ms on the device timeline) -- but conv2's data gradient then takes 0.46-0.49 ms instead of 0.40, the weight gradient before it 0.39
+    // instead of 0.37, and the STEP gets slower: 2.453-2.474 -> 2.487-2.496 ms (profiles/r04_dgrad_registers.txt).  Time-slicing this one
+    // kernel against the chain beats co-running them; the stall is the better schedule, so the twelve registers stay.
+    constexpr bool RECOMPUTE = false;
     int goff[NIT], loff[NIT], irow[NIT], ipar[NIT];
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-        const int idx = t + i * 256;
+    auto item = [&](int tt, int i, int& g, int& l, int& rw, int& pr) __attribute__((always_inline)) {
+        const int idx = RAGGED ? min(tt + i * 256, ITEMS - 1) : tt + i * 256;        // (clamped: a ragged item loads valid memory and is never stored)
         const int px = idx % IMG, row = (idx / IMG) % ROWS, cg = idx / (IMG * ROWS);
-        goff[i] = cg * 8 * SRC_PLANE + (MODE == B3_FWD ? px : px >> 1);
-        loff[i] = (row * PXW + px + 1) * CH + cg * 8;
-        irow[i] = row; ipar[i] = px & 1;
+        g = cg * 8 * SRC_PLANE + (MODE == B3_FWD ? px : px >> 1);
+        l = (row * PXW + px + 1) * CH + cg * 8;
+        rw = row; pr = px & 1;
+    };
+    if (!RECOMPUTE) {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) item(t, i, goff[i], loff[i], irow[i], ipar[i]);
     }
+    auto opaque_t = [&]() __attribute__((always_inline)) { int tt = t; asm volatile("" : "+v"(tt)); return tt; };
     float xr[NIT][8];
     uint32_t mr[NIT][2];                                     // DGRAD: the eight mask bytes of an item
     u32x4 wr[WIT];
@@ -123,12 +151,15 @@ __device__ __forceinline__ void conv_b3_body(const B3Params& p) {
         const char* xb = reinterpret_cast<const char*>(p.x + ((long)b * KIN + chunk * CH) * SRC_PLANE);
         const uint8_t* mbp = MODE == B3_DGRAD ? p.xmask + ((long)b * KIN + chunk * CH) * SRC_PLANE : nullptr;
         okbits = 0;
+        const int tl = RECOMPUTE ? opaque_t() : t;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int yr = h0 - 1 + irow[i];
+            int gi = 0, li = 0, ri = 0, pi = 0;
+            if (RECOMPUTE) item(tl, i, gi, li, ri, pi); else { gi = goff[i]; ri = irow[i]; }
+            const int yr = h0 - 1 + ri;
             const int yy = min(max(yr, 0), IMG - 1);
             okbits |= (yr >= 0 && yr < IMG ? 1u : 0u) << i;
-            const unsigned o = goff[i] + (MODE == B3_FWD ? yy * IMG : (yy >> 1) * (IMG / 2));
+            const unsigned o = gi + (MODE == B3_FWD ? yy * IMG : (yy >> 1) * (IMG / 2));
 #pragma unroll
             for (int j = 0; j < 8; ++j) xr[i][j] = *reinterpret_cast<const float*>(xb + (size_t)(4u * (o + j * SRC_PLANE)));
             if (MODE == B3_DGRAD) {
@@ -144,25 +175,30 @@ __device__ __forceinline__ void conv_b3_body(const B3Params& p) {
     };
     auto store_stage = [&](int strip) __attribute__((always_inline)) {
         const int h0 = (strip % (IMG / R)) * R;
+        const int ts = RECOMPUTE ? opaque_t() : t;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const bool ok = (okbits >> i) & 1u;
+            int gi = 0, li = 0, ri = 0, pi = 0;
+            if (RECOMPUTE) item(ts, i, gi, li, ri, pi); else { li = loff[i]; ri = irow[i]; pi = ipar[i]; }
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if (MODE == B3_FWD) v[j] = ok ? xr[i][j] : 0.f;
                 else {
-                    const uint32_t want = (uint32_t)(((h0 - 1 + irow[i]) & 1) * 2 + ipar[i]);
+                    const uint32_t want = (uint32_t)(((h0 - 1 + ri) & 1) * 2 + pi);
                     v[j] = (ok && ((mr[i][j >> 2] >> (8 * (j & 3))) & 0xff) == want) ? xr[i][j] : 0.f;
                 }
             }
             uint32_t hi[4], mid[4], lo[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], hi[j], mid[j], lo[j]);
-            uint16_t* d = Xs + loff[i];
-            *reinterpret_cast<u32x4*>(d) = u32x4{hi[0], hi[1], hi[2], hi[3]};
-            *reinterpret_cast<u32x4*>(d + XPLANE) = u32x4{mid[0], mid[1], mid[2], mid[3]};
-            *reinterpret_cast<u32x4*>(d + 2 * XPLANE) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+            uint16_t* d = Xs + li;
+            if (!RAGGED || t + i * 256 < ITEMS) {
+                *reinterpret_cast<u32x4*>(d) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+                *reinterpret_cast<u32x4*>(d + XPLANE) = u32x4{mid[0], mid[1], mid[2], mid[3]};
+                *reinterpret_cast<u32x4*>(d + 2 * XPLANE) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+            }
         }
         u32x4* wd = reinterpret_cast<u32x4*>(Ws);
 #pragma unroll
@@ -171,7 +207,8 @@ __device__ __forceinline__ void conv_b3_body(const B3Params& p) {
     };
 
     // this wave's two accumulator tiles: rows y0, y0 + 1 of the strip, columns cb .. cb + 31
-    const int y0 = (wave >> 1) * 2, cb = (wave & 1) * 32;
+    constexpr int WPR = IMG / 32;                            // waves per row pair
+    const int y0 = (wave / WPR) * 2, cb = (wave % WPR) * 32;
     unsigned long long ph[4] = {0, 0, 0, 0}, tprev = PROBE ? __builtin_readcyclecounter() : 0;
     auto mark = [&](int k) __attribute__((always_inline)) {
         if (PROBE) { const unsigned long long now = __builtin_readcyclecounter(); ph[k] += now - tprev; tprev = now; }
@@ -266,7 +303,7 @@ __device__ __forceinline__ void conv_b3_body(const B3Params& p) {
                 if (v3 > best) { best = v3; arg = 3; }
                 const bool act = best > 0.f;
                 const int co = mb * 32 + mfma_row(mine, lane);
-                const long o = (((long)b * 64 + co) * (IMG / 2) + ph2) * (IMG / 2) + pw;
+                const long o = (((long)b * NOUT + co) * (IMG / 2) + ph2) * (IMG / 2) + pw;
                 p.y[o] = act ? best : 0.f;
                 if (p.ymask) p.ymask[o] = act ? (uint8_t)arg : (uint8_t)4;        // null: a forward-only plan keeps no decisions
             }
@@ -275,8 +312,8 @@ __device__ __forceinline__ void conv_b3_body(const B3Params& p) {
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    const int ci = mfma_row(q, lane);
-                    p.y[(((long)b * 32 + ci) * IMG + (h0 + y0 + nt)) * IMG + x] = acc[nt][q];
+                    const int ci = mb * 32 + mfma_row(q, lane);
+                    p.y[(((long)b * NOUT + ci) * IMG + (h0 + y0 + nt)) * IMG + x] = acc[nt][q];
                 }
         }
         mark(3);
@@ -288,10 +325,10 @@ __device__ __forceinline__ void conv_b3_body(const B3Params& p) {
     if (blockIdx.x == 0 && t == 0) { g_b3_clock[0] = __builtin_readcyclecounter() - clk_begin; g_b3_clock[1] = wall_clock64() - wall_begin; }
 }
 
+template <int MODE, class G = GeomFlagship>
+__global__ __launch_bounds__(256) void conv_b3_kernel(B3Params p) { conv_b3_body<MODE, false, G>(p); }
 template <int MODE>
-__global__ __launch_bounds__(256) void conv_b3_kernel(B3Params p) { conv_b3_body<MODE, false>(p); }
-template <int MODE>
-__global__ __launch_bounds__(256) void conv_b3_probe_kernel(B3Params p) { conv_b3_body<MODE, true>(p); }
+__global__ __launch_bounds__(256) void conv_b3_probe_kernel(B3Params p) { conv_b3_body<MODE, true, GeomFlagship>(p); }
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Weight gradient of the same stage: dW[co][ci][tap] = sum_{b, y, x} dY[b][co][y][x] X[b][ci][y + dy][x + dx] with dY the pooled
@@ -318,6 +355,7 @@ struct B3WgradParams {
     float* slab;            // [grid][64][288]
     float* bslab;           // [grid][64]
     int B;
+    int prio;
 };
 
 __global__ __launch_bounds__(256) void conv_b3_wgrad_kernel(B3WgradParams p) {
@@ -511,6 +549,7 @@ typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void conv_b3_wgrad_sp_kernel(B3WgradParams p) {
+    if (p.prio >= 3) __builtin_amdgcn_s_setprio(3); else if (p.prio == 2) __builtin_amdgcn_s_setprio(2); else if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
     constexpr int NTH = 64 * NW, NA = 512 / NTH, NX = 1024 / NTH, NKB = 8 / NW;          // items per thread, k-blocks per wave
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     uint16_t* XsW = smem;                        // [plane][ci][row 4][XROW]
@@ -716,9 +755,11 @@ struct B3Wgrad3Params {
     float* slab;            // [grid][32][32]
     float* bslab;           // [grid][32]
     int B;
+    int prio;
 };
 
 __global__ __launch_bounds__(256) void conv_b3_wgrad3_kernel(B3Wgrad3Params p) {
+    if (p.prio >= 3) __builtin_amdgcn_s_setprio(3); else if (p.prio == 2) __builtin_amdgcn_s_setprio(2); else if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     uint16_t* DYs = smem;                        // [plane][co 32][row 2][128]
     uint16_t* X1s = smem + 3 * DY1PLANE;         // [plane][ci 3][row 4][X1ROW]
@@ -869,41 +910,69 @@ __global__ __launch_bounds__(256) void conv_b3_wgrad3_kernel(B3Wgrad3Params p) {
     }
 }
 
-template <int MODE>
+template <int MODE, class G>
 int launch_b3(const B3Params& p, hipStream_t st) {
     static const int probe = [] { const char* e = getenv("BBBP_B3_PROBE"); return e ? atoi(e) : 0; }();
-    auto kernel = probe ? conv_b3_probe_kernel<MODE> : conv_b3_kernel<MODE>;
-    { int rc_ = bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(kernel), (size_t)LDS_BYTES); if (rc_) return rc_; }
-    constexpr int NMB = MODE == B3_FWD ? 2 : 1;
-    const int nwork = p.B * (IMG / R) * NMB;
+    constexpr bool flagship = G::CIN == 32 && G::COUT == 64 && G::IMGS == 64;
+    auto kernel = conv_b3_kernel<MODE, G>;
+    if constexpr (flagship) { if (probe) kernel = conv_b3_probe_kernel<MODE>; }
+    constexpr int IMGL = G::IMGS, RL = 256 / IMGL;
+    constexpr size_t lds = (size_t)(3 * (RL + 2) * (IMGL + 2) * CH + WSTAGE) * 2;
+    { int rc_ = bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(kernel), lds); if (rc_) return rc_; }
+    constexpr int NMB = (MODE == B3_FWD ? G::COUT : G::CIN) / 32;
+    const int nwork = p.B * (IMGL / RL) * NMB;
     static const int per_cu = [] { const char* e = getenv("BBBP_B3_PER_CU"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 2 ? 2 : v); }();
     int grid = bbbp_num_cus() * per_cu;
     if (grid >= 8 * NMB) grid -= grid % (8 * NMB);
     if (grid > nwork) grid = nwork - nwork % NMB;
     if (grid < NMB) grid = NMB;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), LDS_BYTES, st, p);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, st, p);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }
 
 }  // namespace
 
-// conv.hip dispatches the 32 -> 64 @ 64x64 stage here when the split-bf16 form is selected (bbbp_set_conv_algo).
-// workspace: 2 * 2 * WSTAGE (forward) / 4 * WSTAGE (data gradient) bf16 of pre-split filters = 110 KB.
-size_t bbbp_b3_workspace_bytes() { return (size_t)4 * WSTAGE * 2; }
+// conv.hip dispatches the stages this form serves here when the split-bf16 form is selected (bbbp_set_conv_winograd bits 2 / 3).
+// workspace: (cin / 16) * (cout / 32) [forward] or (cout / 16) * (cin / 32) [data gradient] stages of WSTAGE pre-split bf16 filters.
+bool bbbp_b3_conv_supported(int cin, int cout, int hw) {
+    return (cin == 32 && cout == 64 && hw == 64) || (cin == 64 && cout == 128 && hw == 64) || (cin == 128 && cout == 256 && hw == 32);
+}
+size_t bbbp_b3_workspace_bytes(int cin, int cout) { return (size_t)(cin / 16) * (cout / 32) * WSTAGE * 2 > (size_t)(cout / 16) * (cin / 32) * WSTAGE * 2
+                                                             ? (size_t)(cin / 16) * (cout / 32) * WSTAGE * 2 : (size_t)(cout / 16) * (cin / 32) * WSTAGE * 2; }
+size_t bbbp_b3_workspace_bytes() { return bbbp_b3_workspace_bytes(32, 64); }
 
-int bbbp_b3_conv2_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* y, uint8_t* mask, int B, void* workspace) {
-    hipLaunchKernelGGL(b3_prep_kernel, dim3(72), dim3(256), 0, st, w, static_cast<uint16_t*>(workspace), B3_FWD);
-    BBBP_CHECK_LAUNCH();
-    B3Params p{x, nullptr, static_cast<const uint16_t*>(workspace), bias, y, mask, B};
-    return launch_b3<B3_FWD>(p, st);
+// Wave priority of the BACKWARD conv kernels (BBBP_CONV_BWD_PRIO, default 0).  The encoder chain's small kernels raise themselves to 3 so that
+// they win issue arbitration against the older conv waves; since round 4 the data-gradient kernel leaves the chain a wave slot per SIMD
+// (<= 224 registers), the image branch is the longer pole of the backward pass, and equal priority (3: the older conv waves then go first)
+// hands the arbitration back to it.
+static int conv_bwd_prio() {
+    static const int v = [] { const char* e = getenv("BBBP_CONV_BWD_PRIO"); const int x = e ? atoi(e) : 0; return x < 0 ? 0 : (x > 3 ? 3 : x); }();
+    return v;
 }
 
-int bbbp_b3_conv2_dgrad(hipStream_t st, const float* gy, const uint8_t* gmask, const float* w, float* dx, int B, void* workspace) {
-    hipLaunchKernelGGL(b3_prep_kernel, dim3(72), dim3(256), 0, st, w, static_cast<uint16_t*>(workspace), B3_DGRAD);
+int bbbp_b3_conv_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* y, uint8_t* mask, int B, int cin, int cout, void* workspace) {
+    hipLaunchKernelGGL(b3_prep_kernel, dim3(cin * cout >= 64 * 128 ? 288 : 72), dim3(256), 0, st, w, static_cast<uint16_t*>(workspace), B3_FWD, cin, cout);
     BBBP_CHECK_LAUNCH();
-    B3Params p{gy, gmask, static_cast<const uint16_t*>(workspace), nullptr, dx, nullptr, B};
-    return launch_b3<B3_DGRAD>(p, st);
+    B3Params p{x, nullptr, static_cast<const uint16_t*>(workspace), bias, y, mask, B, 0};
+    if (cin == 32) return launch_b3<B3_FWD, GeomFlagship>(p, st);
+    if (cin == 64) return launch_b3<B3_FWD, B3Geom<64, 128, 64>>(p, st);
+    return launch_b3<B3_FWD, B3Geom<128, 256, 32>>(p, st);
+}
+int bbbp_b3_conv2_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* y, uint8_t* mask, int B, void* workspace) {
+    return bbbp_b3_conv_fwd(st, x, w, bias, y, mask, B, 32, 64, workspace);
+}
+
+int bbbp_b3_conv_dgrad(hipStream_t st, const float* gy, const uint8_t* gmask, const float* w, float* dx, int B, int cin, int cout, void* workspace) {
+    hipLaunchKernelGGL(b3_prep_kernel, dim3(cin * cout >= 64 * 128 ? 288 : 72), dim3(256), 0, st, w, static_cast<uint16_t*>(workspace), B3_DGRAD, cin, cout);
+    BBBP_CHECK_LAUNCH();
+    B3Params p{gy, gmask, static_cast<const uint16_t*>(workspace), nullptr, dx, nullptr, B, conv_bwd_prio()};
+    if (cin == 32) return launch_b3<B3_DGRAD, GeomFlagship>(p, st);
+    if (cin == 64) return launch_b3<B3_DGRAD, B3Geom<64, 128, 64>>(p, st);
+    return launch_b3<B3_DGRAD, B3Geom<128, 256, 32>>(p, st);
+}
+int bbbp_b3_conv2_dgrad(hipStream_t st, const float* gy, const uint8_t* gmask, const float* w, float* dx, int B, void* workspace) {
+    return bbbp_b3_conv_dgrad(st, gy, gmask, w, dx, B, 32, 64, workspace);
 }
 
 extern "C" int bbbp_conv_b3_phases(unsigned long long* phases4) {
@@ -914,7 +983,7 @@ extern "C" int bbbp_conv_b3_phases(unsigned long long* phases4) {
 
 // grid work-groups, each writes slab[g][64][288] and bslab[g][64] (conv.hip: conv_wgrad32_reduce_kernel finishes)
 int bbbp_b3_conv2_wgrad(hipStream_t st, const float* x, const float* gy, const uint8_t* mask, float* slab, float* bslab, int B, int grid, int form) {
-    B3WgradParams p{x, gy, mask, slab, bslab, B};
+    B3WgradParams p{x, gy, mask, slab, bslab, B, conv_bwd_prio()};
     const bool sparse = form != 0;
     static const int waves_env = [] { const char* e = getenv("BBBP_C2_WGRAD_SPARSE_WAVES"); return e ? atoi(e) : 0; }();
     const int waves = waves_env ? waves_env : ((form == 2 || g_bbbp_conv_wgrad_beside_encoder) ? 4 : 8);
@@ -939,7 +1008,7 @@ int bbbp_b3_conv2_wgrad(hipStream_t st, const float* x, const float* gy, const u
 // 3 -> 32 @ 128x128 weight gradient: grid work-groups, each writes slab[g][32][32] and bslab[g][32] (conv.hip: conv_wgrad3_reduce_kernel)
 int bbbp_b3_conv1_wgrad(hipStream_t st, const float* x, const float* gy, const uint8_t* mask, float* slab, float* bslab, int B, int grid) {
     { int rc_ = bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(conv_b3_wgrad3_kernel), (size_t)WG3_LDS_BYTES); if (rc_) return rc_; }
-    B3Wgrad3Params p{x, gy, mask, slab, bslab, B};
+    B3Wgrad3Params p{x, gy, mask, slab, bslab, B, conv_bwd_prio()};
     hipLaunchKernelGGL(conv_b3_wgrad3_kernel, dim3(grid), dim3(256), WG3_LDS_BYTES, st, p);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;

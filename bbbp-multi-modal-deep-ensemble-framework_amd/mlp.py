@@ -127,17 +127,26 @@ class GridMLPTrainer:
             offs.append(tot); tot += E * host[slot_of[k]]["n_train"]
         orders_dev = torch.empty((2, tot), dtype=torch.int32, device=dev)
         orders_host = [torch.empty(tot, dtype=torch.int32).pin_memory() for _ in range(2)]
+        # one device buffer per kind for ALL fits (270 fits x 7 small tensors were 1900 allocations and 270 host-to-device copies per fit() call)
+        p_off, a_off, c_off, ptot, atot, ctot = [], [], [], 0, 0, 0
+        for k in range(nm):
+            h = host[slot_of[k]]
+            p_off.append(ptot); ptot += len(h["p0"])
+            a_off.append(atot); atot += h["bs"] * sum(h["units"][1:])
+            c_off.append(ctot); ctot += h["cfg"].max_iter
+        params_all = torch.from_numpy(np.concatenate([host[slot_of[k]]["p0"] for k in range(nm)])).to(dev)
+        m_all, v_all, g_all = (torch.zeros(ptot, dtype=torch.float64, device=dev) for _ in range(3))
+        act_all, delta_all = (torch.zeros(atot, dtype=torch.float64, device=dev) for _ in range(2))
+        curve_all = torch.zeros(ctot, dtype=torch.float64, device=dev)
+        self._buffers = (params_all, m_all, v_all, g_all, act_all, delta_all, curve_all)
         structs = (_lib.MlpModel * nm)()
         for k in range(nm):
             h = host[slot_of[k]]
             cfg, units, p0, bs, n_train = h["cfg"], h["units"], h["p0"], h["bs"], h["n_train"]
-            width = sum(units[1:])
-            t = dict(params=torch.from_numpy(p0).to(dev), m=torch.zeros(len(p0), dtype=torch.float64, device=dev),
-                     v=torch.zeros(len(p0), dtype=torch.float64, device=dev),
-                     g=torch.zeros(len(p0), dtype=torch.float64, device=dev),
-                     act=torch.zeros(bs * width, dtype=torch.float64, device=dev),
-                     delta=torch.zeros(bs * width, dtype=torch.float64, device=dev),
-                     curve=torch.zeros(cfg.max_iter, dtype=torch.float64, device=dev))
+            np_, na = len(p0), bs * sum(units[1:])
+            t = dict(params=params_all[p_off[k]:p_off[k] + np_], m=m_all[p_off[k]:p_off[k] + np_], v=v_all[p_off[k]:p_off[k] + np_],
+                     g=g_all[p_off[k]:p_off[k] + np_], act=act_all[a_off[k]:a_off[k] + na], delta=delta_all[a_off[k]:a_off[k] + na],
+                     curve=curve_all[c_off[k]:c_off[k] + cfg.max_iter])
             h["t"], h["slot"] = t, k
             s = structs[k]
             s.n_layers = len(units) - 1
@@ -195,14 +204,15 @@ class GridMLPTrainer:
         self._keep = host
         self._orders = (orders_dev, orders_host)
         out = []
+        params_host, curve_host = params_all.cpu().numpy(), curve_all.cpu().numpy()
         for i, h in enumerate(host):
             s, cfg, units = structs[h["slot"]], h["cfg"], h["units"]
-            p = h["t"]["params"].cpu().numpy()
+            p = params_host[p_off[h["slot"]]:p_off[h["slot"]] + len(h["p0"])]
             coefs, inter, off = [], [], 0
             for fan_in, fan_out in zip(units[:-1], units[1:]):
                 coefs.append(p[off:off + fan_in * fan_out].reshape(fan_in, fan_out).copy()); off += fan_in * fan_out
                 inter.append(p[off:off + fan_out].copy()); off += fan_out
-            curve = h["t"]["curve"].cpu().numpy()[:s.n_iter].tolist()
+            curve = curve_host[c_off[h["slot"]]:c_off[h["slot"]] + s.n_iter].tolist()
             out.append(FittedMLP(config=cfg, coefs_=coefs, intercepts_=inter, n_iter_=int(s.n_iter), loss_=curve[-1] if curve else float("nan"),
                                  best_loss_=float(s.best_loss), loss_curve_=curve, converged_=bool(s.no_improve > cfg.n_iter_no_change),
                                  _trainer=self, _index=i))

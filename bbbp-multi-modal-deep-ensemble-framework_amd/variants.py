@@ -14,6 +14,8 @@ the HIP GEMM / BatchNorm / dropout / fusion ops through per-op autograd nodes.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -166,6 +168,17 @@ class MultiModalAttentionFusion(nn.Module):
         return torch.cat((fpw, imgw, cross), dim=1)
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """One side stream per device for the variants that overlap their branches at the Python level."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 class WideDeepMixedInputModel(nn.Module):
     """The wide/deep ``MixedInputModel`` (same file, :109-174): 12-layer encoder (nhead search from 8 down), 3-stage CNN
     64/128/256, Linear(65536,512), Dropout 0.3, MultiModalAttentionFusion(512,512), 6-layer BatchNorm head from 1536."""
@@ -203,14 +216,31 @@ class WideDeepMixedInputModel(nn.Module):
     def forward(self, fingerprint, image):
         from .functional import conv3x3_relu_pool, transformer_encoder
         _need_cuda(fingerprint)
-        x = transformer_encoder(fingerprint.float(), self.fingerprint_transformer, self.nhead, self.training)
-        fp_out = run_sequential(self.fingerprint_fc, x)
+        # round 4: the two branches are independent up to the fusion block, and they are opposites -- the 12-layer encoder is ~250 small
+        # launches bound by latency, the CNN three persistent conv stages bound by the matrix pipe -- so the encoder runs on a side stream
+        # beside the CNN (the flagship's engine does the same inside its C call).  Autograd replays every node on the stream its forward ran
+        # on and synchronises at the boundaries, so the backward pass overlaps the same way.  BBBP_WIDE_OVERLAP=0: one stream.
+        cur = torch.cuda.current_stream(fingerprint.device)
+        side = _side_stream(fingerprint.device) if os.environ.get("BBBP_WIDE_OVERLAP", "1") != "0" else None
+        fingerprint = fingerprint.float()
+        if side is not None:
+            side.wait_stream(cur)
+            fingerprint.record_stream(side)
+            with torch.cuda.stream(side):
+                x = transformer_encoder(fingerprint, self.fingerprint_transformer, self.nhead, self.training)
+                fp_out = run_sequential(self.fingerprint_fc, x)
+        else:
+            x = transformer_encoder(fingerprint, self.fingerprint_transformer, self.nhead, self.training)
+            fp_out = run_sequential(self.fingerprint_fc, x)
         img = image.float().contiguous().view(-1, 3, 128, 128)
         cnn = self.image_cnn
         h = conv3x3_relu_pool(img, cnn[0])
         h = conv3x3_relu_pool(h, cnn[3])
         h = conv3x3_relu_pool(h, cnn[6])
         img_out = run_sequential(nn.Sequential(*list(cnn)[10:]), h.flatten(1))
+        if side is not None:
+            cur.wait_stream(side)
+            fp_out.record_stream(cur)
         return run_sequential(self.fc, self.attention_fusion(fp_out, img_out))
 
 

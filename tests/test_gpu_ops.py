@@ -237,16 +237,30 @@ def _conv_case(dev, B, cin, cout, hw, seed, uniform_patches=False):
     b = rnd(cout, seed=seed + 2, scale=0.1)
     # float64 oracle: torch's own fp32 CPU weight-gradient carries ~2e-3 (of max) summation error at these sizes
     xr, wr, br = (t_.double().clone().requires_grad_(True) for t_ in (x, w, b))
-    yr = oracle.conv3x3_relu_pool(xr, wr, br)
+    y, mask = ops.conv3x3_relu_pool_fwd(x.to(dev), w.to(dev), b.to(dev))
+    assert int(mask.max()) <= 4
+    # The gradients are sums over POOLING DECISIONS (which of four pre-activations is the maximum; whether it is positive).  A window whose
+    # two largest values agree to float32 rounding may legitimately route its gradient to either -- ONE such window moves 9 * cin entries of
+    # dw by |gy * x| (round 4: the 128 -> 256 stage at B = 20 on the split-bf16 forward has one in 1.3 M windows).  So, as
+    # tests/test_gpu_parity_sizes.py does at B = 512: (i) the kernel's decisions may differ from float64's own only at near-ties -- the value
+    # it picked within 1e-5 (of the mean |pre-activation|) of float64's maximum, at < 1e-4 of the windows; (ii) the oracle then takes the
+    # kernel's decisions, and every gradient element is compared.
+    pre = []
+    with torch.no_grad():
+        own = oracle.conv3x3_relu_pool(xr, wr, br, pre=pre)
+    dec64 = oracle.pool_decisions(pre[0])
+    m_cpu = mask.cpu()
+    differ = m_cpu != dec64
+    if differ.any():
+        win = oracle.pool_windows(pre[0])
+        picked = torch.where(m_cpu < 4, win.gather(-1, m_cpu.clamp(max=3).long().unsqueeze(-1)).squeeze(-1), torch.zeros_like(own))
+        gap = (own - picked).abs()[differ]
+        assert float(gap.max()) <= 1e-5 * float(pre[0].abs().mean()) + 1e-12, float(gap.max())
+        assert float(differ.float().mean()) < 1e-4
+    yr = oracle.conv3x3_relu_pool(xr, wr, br, pool_mask=m_cpu)
     gy = rnd(*yr.shape, seed=seed + 3)
     yr.backward(gy.double())
-    y, mask = ops.conv3x3_relu_pool_fwd(x.to(dev), w.to(dev), b.to(dev))
     assert_close(y.cpu().numpy(), yr.detach().numpy(), rtol=1e-5, atol_frac=1e-6, what="conv fwd")
-    assert int(mask.max()) <= 4
-    # mask 4 <=> ReLU inactive; a pre-activation within rounding of 0 may legitimately fall either way
-    disagree = (mask == 4).cpu() != (yr.detach() == 0)
-    assert float(torch.maximum(y.cpu().abs(), yr.detach().abs())[disagree].max() if disagree.any() else 0.0) < 1e-5
-    assert float(disagree.float().mean()) < 1e-4
     dw, db = ops.conv3x3_relu_pool_bwd_weight(x.to(dev), gy.to(dev), mask)
     assert_close(dw.cpu().numpy(), wr.grad.numpy(), rtol=1e-4, atol_frac=2e-5, what="conv dw")
     assert_close(db.cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol_frac=2e-5, what="conv db")

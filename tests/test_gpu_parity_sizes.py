@@ -174,6 +174,10 @@ def test_hip_adamw_follows_the_reference_trajectory(dev):
                     check_summary_adam(g, f"adamw/B{B}/step{step}/{k}", q, lr=1e-4, steps=step,
                                        tight_lr_frac=0.02 if step == 1 else 0.6, min_frac=0.9 if step == 1 else 0.75)
             sd = m.state_dict()
+            # step 3: measured yardstick (round 4, CPU): the float32 ORACLE itself sits 2.4e-3 (absolute, at a scale of 0.49) from the reference's
+            # float32 golden on running_mean after three AdamW steps, its half-ulp-perturbed variants 2.4 .. 3.1e-3 (the float64 oracle 6e-5:
+            # three steps of sign-normalised updates amplify float32 rounding) -- the band is twice the worst of those
             for k in ("fc.2.running_mean", "fc.2.running_var"):
-                assert_close(sd[k].cpu().numpy(), g[f"adamw/B{B}/step{step}/bn/{k}"], rtol=2e-4 if step == 1 else 5e-3, atol_frac=2e-4, what=k)
+                assert_close(sd[k].cpu().numpy(), g[f"adamw/B{B}/step{step}/bn/{k}"], rtol=2e-4 if step == 1 else 5e-3,
+                             atol_frac=2e-4 if step == 1 else 1.3e-2, what=k)
     assert opt.state[next(iter(m.parameters()))]["step"] == 3
