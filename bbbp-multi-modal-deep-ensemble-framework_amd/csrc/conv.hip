@@ -973,8 +973,11 @@ extern "C" int bbbp_conv3x3_relu_pool_bwd_weight(void* stream, const float* x, c
         p.groups = groups;
         p.bslab = slab + (size_t)grid * 64 * 288;
         int rc;
-        if (cin == 32 && cout == 64 && (winograd_mask() & 16))
-            rc = bbbp_b3_conv2_wgrad(st, x, gy, mask, slab, p.bslab, B, grid, (winograd_mask() & 128) ? ((winograd_mask() & 256) ? 2 : 1) : 0);
+        // split-bf16 weight gradient (dense or on the structured-sparse MFMA): 64 x 64 maps, (32 ci, 64 co) block pairs -- the flagship's
+        // second stage (one pair) and, round 4, the wide / deep variant's 64 -> 128 stage (four pairs)
+        if (W == 64 && H == 64 && ((cin == 32 && cout == 64) || (cin == 64 && cout == 128)) && (winograd_mask() & 16))
+            rc = bbbp_b3_conv2_wgrad(st, x, gy, mask, slab, p.bslab, B, grid, (winograd_mask() & 128) ? ((winograd_mask() & 256) ? 2 : 1) : 0,
+                                     cin, cout, groups);
         else rc = cin == 32 ? launch_wgrad32<64, 32, 64>(p, grid, st)
                : cin == 64 ? launch_wgrad32<64, 64, 128>(p, grid, st) : launch_wgrad32<32, 128, 256>(p, grid, st);
         if (rc) return rc;

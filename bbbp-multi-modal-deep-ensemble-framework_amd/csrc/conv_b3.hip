@@ -356,6 +356,9 @@ struct B3WgradParams {
     float* bslab;           // [grid][64]
     int B;
     int prio;
+    // round 4: the kernel handles ONE (32-input-channel, 64-output-channel) block pair of a stage with cin_total / cout_total channels on
+    // 64 x 64 maps (the wide / deep variant's 64 -> 128 stage: four pairs); blockIdx.x = pair * groups + g, like conv_wgrad32_kernel
+    int cin_total, cout_total, groups;
 };
 
 __global__ __launch_bounds__(256) void conv_b3_wgrad_kernel(B3WgradParams p) {
@@ -365,6 +368,12 @@ __global__ __launch_bounds__(256) void conv_b3_wgrad_kernel(B3WgradParams p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
     const int mt = wave & 1, kg = wave >> 1;
     const int nstrips = p.B * (IMG / 2);
+    const int pair = blockIdx.x / p.groups, grp = blockIdx.x % p.groups, ncib = p.cin_total / 32;
+    // this pair's channel blocks as uniform base pointers + per-image strides (scalar registers: the loaders' vector arithmetic is unchanged)
+    const float* const gyb = p.gy + (long)(pair / ncib) * 64 * (IMG / 2) * (IMG / 2);
+    const uint8_t* const mkb = p.mask + (long)(pair / ncib) * 64 * (IMG / 2) * (IMG / 2);
+    const float* const xbk = p.x + (long)(pair % ncib) * 32 * IMG * IMG;
+    const long gy_img = (long)p.cout_total * (IMG / 2) * (IMG / 2), x_img = (long)p.cin_total * IMG * IMG;
     for (int i = t * 8; i < 3 * DYPLANE + 3 * WXPLANE; i += 256 * 8) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0, 0, 0, 0};
 
     // ---- loader: dY items (co, quad of 4 pooled px) x 2 per thread; X items (ci, row, 8 px) x 4 per thread ----
@@ -376,9 +385,9 @@ __global__ __launch_bounds__(256) void conv_b3_wgrad_kernel(B3WgradParams p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = t + i * 256, q = idx & 7, co = idx >> 3;
-            const long off = (((long)b * 64 + co) * (IMG / 2) + ph) * (IMG / 2) + q * 4;
-            gq[i] = *reinterpret_cast<const f32x4*>(p.gy + off);
-            mq[i] = *reinterpret_cast<const uint32_t*>(p.mask + off);
+            const long off = (long)b * gy_img + (co * (IMG / 2) + ph) * (IMG / 2) + q * 4;
+            gq[i] = *reinterpret_cast<const f32x4*>(gyb + off);
+            mq[i] = *reinterpret_cast<const uint32_t*>(mkb + off);
         }
         okx = 0;
 #pragma unroll
@@ -386,7 +395,7 @@ __global__ __launch_bounds__(256) void conv_b3_wgrad_kernel(B3WgradParams p) {
             const int idx = t + i * 256, q = idx & 7, row = (idx >> 3) & 3, ci = idx >> 5;
             const int yr = 2 * ph - 1 + row;
             okx |= (yr >= 0 && yr < IMG ? 1u : 0u) << i;
-            const float* src = p.x + (((long)b * 32 + ci) * IMG + min(max(yr, 0), IMG - 1)) * IMG + q * 8;
+            const float* src = xbk + (long)b * x_img + (ci * IMG + min(max(yr, 0), IMG - 1)) * IMG + q * 8;
             xq[i][0] = *reinterpret_cast<const f32x4*>(src);
             xq[i][1] = *reinterpret_cast<const f32x4*>(src + 4);
         }
@@ -440,13 +449,13 @@ __global__ __launch_bounds__(256) void conv_b3_wgrad_kernel(B3WgradParams p) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
 
-    int strip = xcd_adjacent(blockIdx.x, gridDim.x);
+    int strip = xcd_adjacent(grp, p.groups);
     __syncthreads();
     if (strip < nstrips) { load_stage(strip); store_stage(); }
     const uint16_t* abase = DYs + (mt * 32 + r) * DYCO + 8 * h;
     const uint16_t* bbase = XsW + r * XCI + 8 + 8 * h;
-    for (; strip < nstrips; strip += gridDim.x) {
-        const int nstrip = strip + gridDim.x;
+    for (; strip < nstrips; strip += p.groups) {
+        const int nstrip = strip + p.groups;
         __syncthreads();                                     // this stage's LDS image is complete
         if (nstrip < nstrips) load_stage(nstrip);
 #pragma unroll
@@ -559,6 +568,12 @@ __global__ __launch_bounds__(64 * NW) void conv_b3_wgrad_sp_kernel(B3WgradParams
     const int mt = wave & 1, kq = wave >> 1;                 // k-group: NW = 8: one k-block (row kq >> 1, half kq & 1); NW = 4: row kq, both halves
     const int rr = NW == 8 ? kq >> 1 : kq;
     const int nstrips = p.B * (IMG / 2);
+    const int pair = blockIdx.x / p.groups, grp = blockIdx.x % p.groups, ncib = p.cin_total / 32;
+    // this pair's channel blocks as uniform base pointers + per-image strides (scalar registers: the loaders' vector arithmetic is unchanged)
+    const float* const gyb = p.gy + (long)(pair / ncib) * 64 * (IMG / 2) * (IMG / 2);
+    const uint8_t* const mkb = p.mask + (long)(pair / ncib) * 64 * (IMG / 2) * (IMG / 2);
+    const float* const xbk = p.x + (long)(pair % ncib) * 32 * IMG * IMG;
+    const long gy_img = (long)p.cout_total * (IMG / 2) * (IMG / 2), x_img = (long)p.cin_total * IMG * IMG;
     for (int i = t * 8; i < 3 * WXPLANE + 2 * ASP_RR + 64 * 4; i += NTH * 8) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0, 0, 0, 0};
 
     // ---- loader: NA dY items (co, quad of 4 pooled px) and NX X items (ci, row, 8 px) per thread ----
@@ -572,9 +587,9 @@ __global__ __launch_bounds__(64 * NW) void conv_b3_wgrad_sp_kernel(B3WgradParams
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int idx = t + i * NTH, a_q = idx & 7, a_co = idx >> 3;
-            const long off = (((long)b * 64 + a_co) * (IMG / 2) + ph) * (IMG / 2) + a_q * 4;
-            gq[i] = *reinterpret_cast<const f32x4*>(p.gy + off);
-            mq[i] = *reinterpret_cast<const uint32_t*>(p.mask + off);
+            const long off = (long)b * gy_img + (a_co * (IMG / 2) + ph) * (IMG / 2) + a_q * 4;
+            gq[i] = *reinterpret_cast<const f32x4*>(gyb + off);
+            mq[i] = *reinterpret_cast<const uint32_t*>(mkb + off);
         }
         okx = 0;
 #pragma unroll
@@ -582,7 +597,7 @@ __global__ __launch_bounds__(64 * NW) void conv_b3_wgrad_sp_kernel(B3WgradParams
             const int idx = t + i * NTH, q = idx & 7, row = (idx >> 3) & 3, ci = idx >> 5;
             const int yr = 2 * ph - 1 + row;
             okx |= (yr >= 0 && yr < IMG ? 1u : 0u) << i;
-            const float* src = p.x + (((long)b * 32 + ci) * IMG + min(max(yr, 0), IMG - 1)) * IMG + q * 8;
+            const float* src = xbk + (long)b * x_img + (ci * IMG + min(max(yr, 0), IMG - 1)) * IMG + q * 8;
             xq[i][0] = *reinterpret_cast<const f32x4*>(src);
             xq[i][1] = *reinterpret_cast<const f32x4*>(src + 4);
         }
@@ -636,12 +651,12 @@ __global__ __launch_bounds__(64 * NW) void conv_b3_wgrad_sp_kernel(B3WgradParams
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
 
-    int strip = xcd_adjacent(blockIdx.x, gridDim.x);
+    int strip = xcd_adjacent(grp, p.groups);
     __syncthreads();
     if (strip < nstrips) { load_stage(strip); store_stage(); }
     const int co = mt * 32 + r;
-    for (; strip < nstrips; strip += gridDim.x) {
-        const int nstrip = strip + gridDim.x;
+    for (; strip < nstrips; strip += p.groups) {
+        const int nstrip = strip + p.groups;
         __syncthreads();                                     // this stage's LDS image is complete
         if (nstrip < nstrips) load_stage(nstrip);
 #pragma unroll
@@ -982,8 +997,9 @@ extern "C" int bbbp_conv_b3_phases(unsigned long long* phases4) {
 }
 
 // grid work-groups, each writes slab[g][64][288] and bslab[g][64] (conv.hip: conv_wgrad32_reduce_kernel finishes)
-int bbbp_b3_conv2_wgrad(hipStream_t st, const float* x, const float* gy, const uint8_t* mask, float* slab, float* bslab, int B, int grid, int form) {
-    B3WgradParams p{x, gy, mask, slab, bslab, B, conv_bwd_prio()};
+int bbbp_b3_conv2_wgrad(hipStream_t st, const float* x, const float* gy, const uint8_t* mask, float* slab, float* bslab, int B, int grid, int form,
+                        int cin_total, int cout_total, int groups) {
+    B3WgradParams p{x, gy, mask, slab, bslab, B, conv_bwd_prio(), cin_total, cout_total, groups > 0 ? groups : grid};
     const bool sparse = form != 0;
     static const int waves_env = [] { const char* e = getenv("BBBP_C2_WGRAD_SPARSE_WAVES"); return e ? atoi(e) : 0; }();
     const int waves = waves_env ? waves_env : ((form == 2 || g_bbbp_conv_wgrad_beside_encoder) ? 4 : 8);

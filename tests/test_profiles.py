@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
-ROUND = "r03"
+ROUND = "r04"
 # compulsory HBM bytes per launch of the conv kernels at batch B (fp32 NCHW, u8 masks)
 CONV_BYTES = {"conv2_fwd": lambda B: B * (32 * 64 * 64 * 4 + 64 * 32 * 32 * 5), "conv1_fwd": lambda B: B * (3 * 128 * 128 * 4 + 32 * 64 * 64 * 5)}
 
@@ -74,13 +74,14 @@ def test_rocprof_kernel_table_agrees_with_the_bench_line(config):
     launch in the table is an in-step one), and the PMC traffic quoted in the line is the committed pass of that configuration."""
     d = bench(config)
     r = d["roofline"]
-    pattern = {"conv2_wgrad": "conv_b3_wgrad_", "conv2_fwd": "conv_b3_kernel<0>", "conv2_dgrad": "conv_b3_kernel<1>"}[r["kernel"]]
+    # (round 4: the kernel is templated over its geometry -- "conv_b3_kernel<0, B3Geom<32, 64, 64> >")
+    pattern = {"conv2_wgrad": "conv_b3_wgrad_", "conv2_fwd": "conv_b3_kernel<0", "conv2_dgrad": "conv_b3_kernel<1"}[r["kernel"]]
     rows = [x for x in csv.DictReader(open(os.path.join(PROF, f"{ROUND}_kernel_stats_config{config}.csv"))) if pattern in x["Name"]]
     assert len(rows) == 1
     avg_ms = float(rows[0]["AverageNs"]) * 1e-6
     # config 5 (B = 4096 inference): 13 launches of 3.2 .. 5.6 ms depending on what the encoder stream runs beside them -- two short
     # runs' averages agree to ~15 %; the training configurations (tens of launches of one repeating step) to 5-8 % (the bench line is a
-    # separate run of the same command on the same box: round 3's pair differs by 6 %)
+    # separate run of the same command on the same box: round 3's pair differs by 6 %, which is why the band went from 5 to 8 % in round 3)
     tol = 0.15 if config == 5 else 0.08
     assert abs(avg_ms - r["ms_per_launch"]) <= tol * r["ms_per_launch"], (avg_ms, r["ms_per_launch"])
     t = json.load(open(os.path.join(PROF, f"{ROUND}_pmc_traffic_config{config}.json")))
@@ -88,7 +89,8 @@ def test_rocprof_kernel_table_agrees_with_the_bench_line(config):
     assert abs(t[r["kernel"]] - r["traffic"]) <= 1e-6 * r["traffic"]
     # traffic close to the algorithmic bytes: nothing is re-read from HBM
     B = d["config"]["per_gpu_batch"]
-    conv2_bytes = B * (32 * 64 * 64 * 4 + 64 * 32 * 32 * 5)
+    # (round 4: forward-only plans -- config 5 -- keep no pooling decisions: 4 bytes per pooled element instead of 5)
+    conv2_bytes = B * (32 * 64 * 64 * 4 + 64 * 32 * 32 * (4 if config == 5 else 5))
     assert conv2_bytes <= r["traffic"] < 1.12 * conv2_bytes, (r["traffic"], conv2_bytes)
 
 

@@ -12,4 +12,8 @@ python3 tools/stall_outliers.py $(find $O/r04_trace3 -name '*kernel_trace.csv' |
 python3 tools/trace_timeline.py $(find $O/r04_trace3 -name '*kernel_trace.csv' | head -1) > $O/r04_trace_timeline.txt 2>&1
 rm -rf $O/r04_trace3
 python3 tools/step_timeline.py > $O/r04_step_timeline.txt 2>&1
-tail -5 $O/r04_stall_outliers.txt
+python3 tools/exp_b3db_r2.py > $O/r04_b3db_r2.log 2>&1 || tail -5 $O/r04_b3db_r2.log
+python3 tools/bench_wide_deep.py > $O/r04_wide_deep.log 2>&1
+BBBP_WIDE_OVERLAP=0 BBBP_CONV_WINOGRAD=224 python3 tools/bench_wide_deep.py >> $O/r04_wide_deep.log 2>&1
+for B in 32 64 128; do python3 bench.py --batch $B --no-cpu-baseline --no-isolated > $O/r04_bench_batch$B.log 2>&1 && tail -1 $O/r04_bench_batch$B.log > $O/r04_bench_batch$B.json; done
+tail -5 $O/r04_stall_outliers.txt; tail -3 $O/r04_wide_deep.log
