@@ -120,6 +120,8 @@ _SIGNATURES = {
     "bbbp_mse": (c_int, [c_void_p, _FP, _FP, _FP, _FP, c_int, c_float]),
     "bbbp_adamw_step": (c_int, [c_void_p, _FP, _FP, _FP, _FP, c_long, c_float, c_float, c_float, c_float, c_float, c_int,
                                 c_float]),
+    "bbbp_adamw_step_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
+    "bbbp_adamw_hyper_store": (c_int, [c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float, c_int, c_float]),
     "bbbp_adamw_step_deferred": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_long, c_float, c_float, c_float, c_float, c_float, c_int, c_float]),
     "bbbp_param_sync": (c_int, [c_void_p]),
     "bbbp_param_stream": (c_void_p, []),

@@ -552,6 +552,60 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
     }
 }
 
+// ---- multi-tensor form (round 4): parameters and moments are ONE flat buffer, the gradients are separate tensors (what autograd leaves behind when
+// the model is a per-op composition: 180 tensors in the wide/deep variant = 180 launches and 2.7 ms of host time per step before this).  `offs`
+// (nt + 1 element offsets into the flat buffer, offs[0] = 0, offs[nt] = n) and `grads` (nt device pointers) live in device memory; the hyper-
+// parameters come by value or, when `hyper_dev` is set, from eight floats in device memory (a captured step replays with the values of the
+// day).  Same per-element expressions as adamw_kernel: bit-identical to nt single launches.
+struct AdamHyper { float decay, omb1, beta2, omb2, step_size, bc2_sqrt, eps, gscale; };
+
+__device__ __forceinline__ void adamw_element(float& p, float g, float& m, float& v, const AdamHyper& h) {
+    float gi = g * h.gscale;
+    float pi = p * h.decay;
+    float mi = m + h.omb1 * (gi - m);
+    float vi = v * h.beta2 + h.omb2 * gi * gi;
+    float denom = sqrtf(vi) / h.bc2_sqrt + h.eps;
+    p = pi - h.step_size * (mi / denom);
+    m = mi; v = vi;
+}
+
+__global__ void adamw_hyper_store_kernel(float* out, AdamHyper h) {
+    if (threadIdx.x == 0) { out[0] = h.decay; out[1] = h.omb1; out[2] = h.beta2; out[3] = h.omb2; out[4] = h.step_size; out[5] = h.bc2_sqrt; out[6] = h.eps; out[7] = h.gscale; }
+}
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, long n,
+                                                         const long* __restrict__ offs, const float* const* __restrict__ grads, int nt,
+                                                         AdamHyper h, const float* __restrict__ hyper_dev) {
+    BBBP_HIGH_PRIO();
+    if (hyper_dev) {
+        h.decay = hyper_dev[0]; h.omb1 = hyper_dev[1]; h.beta2 = hyper_dev[2]; h.omb2 = hyper_dev[3];
+        h.step_size = hyper_dev[4]; h.bc2_sqrt = hyper_dev[5]; h.eps = hyper_dev[6]; h.gscale = hyper_dev[7];
+    }
+    const long n4 = n & ~3L;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        int lo = 0, hi = nt;                                   // the tensor holding element i: offs[lo] <= i < offs[lo + 1]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= i) lo = mid; else hi = mid; }
+        long base = offs[lo], end = offs[lo + 1];
+        if (i < n4 && i + 4 <= end) {
+            const float* gp = grads[lo] + (i - base);
+            float4 pv = *reinterpret_cast<const float4*>(p + i), mv = *reinterpret_cast<const float4*>(m + i), vv = *reinterpret_cast<const float4*>(v + i);
+            float g0, g1, g2, g3;
+            if ((reinterpret_cast<uintptr_t>(gp) & 15) == 0) { const float4 gv = *reinterpret_cast<const float4*>(gp); g0 = gv.x; g1 = gv.y; g2 = gv.z; g3 = gv.w; }
+            else { g0 = gp[0]; g1 = gp[1]; g2 = gp[2]; g3 = gp[3]; }
+            adamw_element(pv.x, g0, mv.x, vv.x, h); adamw_element(pv.y, g1, mv.y, vv.y, h);
+            adamw_element(pv.z, g2, mv.z, vv.z, h); adamw_element(pv.w, g3, mv.w, vv.w, h);
+            *reinterpret_cast<float4*>(p + i) = pv; *reinterpret_cast<float4*>(m + i) = mv; *reinterpret_cast<float4*>(v + i) = vv;
+        } else {
+            for (long j = i; j < i + 4 && j < n; ++j) {
+                while (j >= end) { ++lo; base = offs[lo]; end = offs[lo + 1]; }          // also steps over empty tensors
+                float pj = p[j], mj = m[j], vj = v[j];
+                adamw_element(pj, grads[lo][j - base], mj, vj, h);
+                p[j] = pj; m[j] = mj; v[j] = vj;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void scale_kernel(float* x, long n, float s) {
     BBBP_HIGH_PRIO();
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] *= s;
@@ -804,6 +858,47 @@ extern "C" int bbbp_adamw_step(void* stream, float* param, const float* grad, fl
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), g_bbbp_small_lds_pad, ST, param, grad, exp_avg, exp_avg_sq, n, decay,
                        (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), (float)((double)lr / bc1),
                        (float)sqrt(bc2), eps, grad_scale);
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+namespace {
+AdamHyper adam_hyper(float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale) {
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    return AdamHyper{(float)(1.0 - (double)lr * (double)weight_decay), (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2),
+                     (float)((double)lr / bc1), (float)sqrt(bc2), eps, grad_scale};
+}
+}  // namespace
+
+// the eight derived floats the kernels compute with (decay, 1-beta1, beta2, 1-beta2, lr / bias-correction-1, sqrt(bias-correction-2), eps,
+// gradient scale) stored to device memory in stream order (`hyper_dev` below): the values travel as kernel arguments, so the host may call
+// this again for the next step at once
+extern "C" int bbbp_adamw_hyper_store(void* stream, float* hyper_dev, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                      float grad_scale) {
+    BBBP_CHECK_ARG(step >= 1 && hyper_dev, "adamw_hyper_store: step is 1-based (got %d), hyper_dev must not be null", step);
+    hipLaunchKernelGGL(adamw_hyper_store_kernel, dim3(1), dim3(64), 0, ST, hyper_dev, adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale));
+    BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+// One launch for a flat parameter / moment buffer whose gradients are `n_tensors` separate device tensors.  `table_dev` (device memory, owned
+// by the caller, read on `stream`): long offsets[n_tensors + 1] followed by const float* grads[n_tensors].  `hyper_dev` (nullable): eight
+// floats in device memory as bbbp_adamw_hyper_store writes them -- then lr ... grad_scale are ignored and `step` is not checked.
+extern "C" int bbbp_adamw_step_multi(void* stream, float* param, float* exp_avg, float* exp_avg_sq, long n, const void* table_dev, int n_tensors,
+                                     float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                                     const float* hyper_dev) {
+    BBBP_CHECK_ARG(hyper_dev || step >= 1, "adamw_multi: step is 1-based, got %d", step);
+    BBBP_CHECK_ARG(n >= 0 && n_tensors >= 1, "adamw_multi: n = %ld, n_tensors = %d", n, n_tensors);
+    if (n == 0) return BBBP_OK;
+    BBBP_CHECK_ARG(param && exp_avg && exp_avg_sq && table_dev, "adamw_multi: null pointer");
+    BBBP_CHECK_ARG(((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(table_dev) & 7) == 0, "adamw_multi: flat buffers must be 16-byte aligned, the table 8-byte aligned");
+    (void)bbbp_param_wait(static_cast<hipStream_t>(stream), nullptr);
+    const long* offs = static_cast<const long*>(table_dev);
+    const float* const* grads = reinterpret_cast<const float* const*>(offs + n_tensors + 1);
+    const AdamHyper h = hyper_dev ? AdamHyper{} : adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), g_bbbp_small_lds_pad, ST, param, exp_avg, exp_avg_sq, n, offs, grads,
+                       n_tensors, h, hyper_dev);
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }

@@ -380,6 +380,34 @@ def adamw_step_deferred_(param, grad, exp_avg, exp_avg_sq, step: int, lo: int, h
         grad.record_stream(side)                 # (parameters and moments live as long as the optimizer)
 
 
+def adamw_hyper_store_(hyper, step: int, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, grad_scale: float = 1.0) -> None:
+    """Store the eight derived floats the AdamW kernels compute with into the 8-float device tensor ``hyper``, in stream order
+    (``bbbp_adamw_hyper_store``)."""
+    _chk(hyper, "hyper")
+    if hyper.numel() != 8 or not hyper.is_contiguous():
+        raise RuntimeError("adamw_hyper_store: hyper must be 8 contiguous float32 values")
+    _lib.check(_lib.lib().bbbp_adamw_hyper_store(_stream(), hyper.data_ptr(), lr, betas[0], betas[1], eps, weight_decay, step, grad_scale),
+               "bbbp_adamw_hyper_store")
+
+
+def adamw_step_multi_(param, exp_avg, exp_avg_sq, table, n_tensors: int, step: int, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5,
+                      grad_scale: float = 1.0, hyper=None) -> None:
+    """One launch over a flat parameter / moment buffer whose gradients are ``n_tensors`` separate tensors (``bbbp_adamw_step_multi``).
+    ``table``: int64 device tensor, ``n_tensors + 1`` element offsets followed by ``n_tensors`` gradient addresses.  ``hyper``: optional
+    8-float device tensor (``adamw_hyper_store_``) read by the kernel instead of the scalar arguments."""
+    for t, n in ((param, "param"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _chk(t, n)
+        if not t.is_contiguous():
+            raise RuntimeError(f"adamw: {n} must be contiguous")
+    if table.dtype != torch.int64 or not table.is_cuda or table.numel() != 2 * n_tensors + 1 or not table.is_contiguous():
+        raise RuntimeError("adamw_multi: table must be a contiguous int64 CUDA tensor of 2 * n_tensors + 1 entries")
+    if hyper is not None and (hyper.dtype != torch.float32 or not hyper.is_cuda or hyper.numel() != 8):
+        raise RuntimeError("adamw_multi: hyper must be 8 float32 values on the device")
+    _lib.check(_lib.lib().bbbp_adamw_step_multi(_stream(), param.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), param.numel(),
+                                                table.data_ptr(), n_tensors, lr, betas[0], betas[1], eps, weight_decay, step, grad_scale,
+                                                hyper.data_ptr() if hyper is not None else None), "bbbp_adamw_step_multi")
+
+
 def param_sync() -> None:
     """Order the current stream behind a deferred optimizer slice (no-op when none is pending)."""
     _lib.check(_lib.lib().bbbp_param_sync(_stream()), "bbbp_param_sync")

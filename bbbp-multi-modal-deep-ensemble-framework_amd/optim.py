@@ -3,8 +3,9 @@ as the reference uses it (Models/multi_input_data_regression_opt_transformer_cnn
 ``optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5)``), run by ``bbbp_adamw_step``.
 
 When the parameters (and their gradients) are consecutive views of one flat buffer -- which
-``MixedInputModel`` arranges -- a whole step is ONE kernel launch over 13.5 M elements; otherwise one
-launch per tensor.  State tensors are exposed per parameter (``exp_avg``, ``exp_avg_sq``, ``step``) like
+``MixedInputModel`` arranges -- a whole step is ONE kernel launch over 13.5 M elements.  When only the parameters are flat and the gradients are
+separate tensors (what autograd leaves behind for the per-op variants) it is still one launch, through a device table of gradient addresses
+(``bbbp_adamw_step_multi``, round 4); otherwise one launch per tensor.  State tensors are exposed per parameter (``exp_avg``, ``exp_avg_sq``, ``step``) like
 torch's, so ``state_dict()`` has the familiar shape.
 """
 from __future__ import annotations
@@ -16,8 +17,12 @@ from .models import flat_view_of
 
 
 class AdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, defer=None):
-        """``defer`` (round 4, opt-in): one parameter -- the image-FC weight of a ``MixedInputModel``, 62 % of the optimizer's bytes -- whose
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, defer=None, capturable=False):
+        """``capturable`` (round 4): the step can be captured into a HIP graph (``training.GraphedTrainStep``) -- the step-dependent scalars
+        (bias corrections, the scheduler's lr) are read from device memory, where ``step()`` stores them in stream order before its launch;
+        a call made while the stream is capturing records the launch only, and ``advance()`` is what a replay loop calls before each replay.
+
+        ``defer`` (round 4, opt-in): one parameter -- the image-FC weight of a ``MixedInputModel``, 62 % of the optimizer's bytes -- whose
         slice of the flat update runs on a library-owned side stream beside the start of the NEXT forward pass, which does not read it
         before its third kernel (``bbbp_adamw_step_deferred``).  The model's forward orders itself behind the slice; anything that reads
         that parameter outside a forward call (``state_dict()``, checkpoints, ``.cpu()``) must call ``synchronize()`` first.  The
@@ -28,6 +33,49 @@ class AdamW(torch.optim.Optimizer):
         self._flat_state = {}
         self._flat_params = {}
         self._defer = defer
+        self._capturable = bool(capturable)
+        self._hyper = {}                # group index -> 8-float device tensor (capturable)
+        self._tables = {}               # group index -> {gradient addresses: (device table, pinned host copy)}
+
+    def _hyper_of(self, gi, device):
+        h = self._hyper.get(gi)
+        if h is None or h.device != device:
+            h = torch.zeros(8, dtype=torch.float32, device=device)
+            self._hyper[gi] = h
+        return h
+
+    @torch.no_grad()
+    def advance(self, grad_scale: float = 1.0) -> None:
+        """capturable: count one step for every parameter and store its scalars to device memory (what ``step()`` does before its launch
+        when it is not being captured).  Call before each replay of a captured step."""
+        for gi, group in enumerate(self.param_groups):
+            params = group["params"]
+            if not params:
+                continue
+            if not self._state_is_flat(gi, params):
+                self._init_group_state(gi, list(params))
+            for p in params:
+                self.state[p]["step"] += 1
+            ops.adamw_hyper_store_(self._hyper_of(gi, params[0].device), self.state[params[0]]["step"], lr=group["lr"], betas=group["betas"],
+                                   eps=group["eps"], weight_decay=group["weight_decay"], grad_scale=grad_scale)
+
+    def _grad_table(self, gi, params):
+        """Device table for ``bbbp_adamw_step_multi``: element offsets of the parameters in their flat buffer + the addresses of their
+        gradients.  Cached by the addresses (the caching allocator hands a steady training loop the same blocks again and again); the
+        pinned host copy stays alive with the entry because the upload is asynchronous (and, inside a capture, a node of the graph)."""
+        key = tuple(p.grad.data_ptr() for p in params)
+        cache = self._tables.setdefault(gi, {})
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) >= 16 and not torch.cuda.is_current_stream_capturing():
+                cache.clear()
+            offs = [0]
+            for p in params:
+                offs.append(offs[-1] + p.numel())
+            host = torch.tensor(offs + list(key), dtype=torch.int64).pin_memory()
+            hit = (host.to(params[0].device, non_blocking=True), host)
+            cache[key] = hit
+        return hit[0]
 
     def synchronize(self) -> None:
         """Order the current stream behind a deferred slice (see ``defer``); a no-op when nothing is pending."""
@@ -122,8 +170,10 @@ class AdamW(torch.optim.Optimizer):
             if not self._state_is_flat(gi, group["params"]):
                 self._init_group_state(gi, [p for p in group["params"]])
             hp = dict(lr=group["lr"], betas=group["betas"], eps=group["eps"], weight_decay=group["weight_decay"])
-            for p in params:
-                self.state[p]["step"] += 1
+            capturing = self._capturable and torch.cuda.is_current_stream_capturing()
+            if not capturing:                   # a captured call only records the launch; advance() counts the replays
+                for p in params:
+                    self.state[p]["step"] += 1
             step = self.state[params[0]]["step"]
             all_params = group["params"]
             pflat = gflat = None
@@ -152,7 +202,15 @@ class AdamW(torch.optim.Optimizer):
                     if gflat is None:
                         gflat = flat_view_of([q.grad for q in all_params])
             same_step = all(self.state[p]["step"] == step for p in params)
-            if pflat is not None and gflat is not None and same_step:
+            hyper = None
+            if self._capturable and pflat is not None and same_step:
+                hyper = self._hyper_of(gi, pflat.device)
+                if not capturing:
+                    ops.adamw_hyper_store_(hyper, step, grad_scale=grad_scale, **hp)
+            elif self._capturable:
+                raise RuntimeError("AdamW(capturable=True) needs every parameter of a group in one flat buffer (models.flatten_parameters), "
+                                   "a gradient for each, and equal step counts")
+            if pflat is not None and gflat is not None and same_step and hyper is None:
                 m, v = self._flat_state[gi]
                 d = self._defer
                 lo = -1
@@ -164,6 +222,14 @@ class AdamW(torch.optim.Optimizer):
                     ops.adamw_step_deferred_(pflat, gflat, m, v, step, lo, lo + d.numel(), grad_scale=grad_scale, **hp)
                 else:
                     ops.adamw_step_(pflat, gflat, m, v, step, grad_scale=grad_scale, **hp)
+            elif (pflat is not None and same_step and pflat.data_ptr() % 16 == 0
+                  and all(q.grad.is_contiguous() and q.grad.dtype == torch.float32 and q.grad.is_cuda for q in all_params)):
+                # flat parameters, separate gradient tensors: one launch through a table of gradient addresses
+                m, v = self._flat_state[gi]
+                ops.adamw_step_multi_(pflat, m, v, self._grad_table(gi, all_params), len(all_params), max(step, 1), grad_scale=grad_scale,
+                                      hyper=hyper, **hp)
+            elif hyper is not None:
+                raise RuntimeError("AdamW(capturable=True): gradients must be contiguous float32 device tensors")
             else:
                 for p in params:
                     st = self.state[p]

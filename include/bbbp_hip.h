@@ -202,6 +202,16 @@ int bbbp_adamw_step(void* stream, float* param, const float* grad, float* exp_av
  * bbbp_adamw_step's.  Inside a stream capture, or with an empty slice, it IS bbbp_adamw_step. */
 int bbbp_adamw_step_deferred(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, long lo, long hi,
                              float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale);
+/* Multi-tensor form (round 4): parameters and moments are ONE flat buffer of n elements, the gradients are n_tensors separate device tensors
+ * (what autograd leaves behind for a per-op model: torch.optim.AdamW's foreach path, here one launch).  `table_dev`: device memory owned by the
+ * caller and read on `stream` -- long offsets[n_tensors + 1] (element offsets into the flat buffer, offsets[0] = 0, offsets[n_tensors] = n)
+ * followed by const float* grads[n_tensors].  `hyper_dev` (nullable): eight floats in device memory as bbbp_adamw_hyper_store writes them; then
+ * lr ... grad_scale are ignored -- a step captured into a HIP graph replays with whatever the caller stored there before the launch.
+ * Same per-element expressions as bbbp_adamw_step: bit-identical to n_tensors single launches. */
+int bbbp_adamw_step_multi(void* stream, float* param, float* exp_avg, float* exp_avg_sq, long n, const void* table_dev, int n_tensors,
+                          float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, const float* hyper_dev);
+/* stores those eight floats (derived on the host in double, as bbbp_adamw_step derives them) to device memory in stream order */
+int bbbp_adamw_hyper_store(void* stream, float* hyper_dev, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale);
 int bbbp_param_sync(void* stream);
 void* bbbp_param_stream(void);     /* the side stream of the current device (NULL before the first deferred step) */
 int bbbp_scale(void* stream, float* x, long n, float s);
