@@ -468,8 +468,9 @@ uint64_t site_seed(uint64_t /*seed: lives in the workspace*/, int layer, int sit
 __global__ void set_seed_kernel(unsigned long long* slot, unsigned long long seed) { *slot = seed; }
 
 struct SeedScope {
-    explicit SeedScope(const unsigned long long* slot) { g_bbbp_seed_base = slot; }
-    ~SeedScope() { g_bbbp_seed_base = nullptr; }
+    const unsigned long long* prev;
+    explicit SeedScope(const unsigned long long* slot) : prev(g_bbbp_seed_base) { g_bbbp_seed_base = slot; }
+    ~SeedScope() { g_bbbp_seed_base = prev; }        // (the op-level base a caller set with bbbp_set_seed_base survives a whole-model call)
 };
 
 // ---- HIP-graph replay of the two whole-model calls ---------------------------------------------------------------

@@ -537,18 +537,32 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* pred, const float
 // ---------------------------------------------------------------------------------------------
 // AdamW, torch.optim.AdamW arithmetic (decoupled decay, no amsgrad): one flat launch.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, long n, float decay,
-                                                   float omb1, float beta2, float omb2, float step_size, float bc2_sqrt,
-                                                   float eps, float gscale) {
+// One element of the update.  Every rounding is spelled out (no contraction left to the compiler) so that all launch forms of the step --
+// flat, sliced, multi-tensor, vectorised or not -- produce the same bits for the same element.
+struct AdamHyper { float decay, omb1, beta2, omb2, step_size, bc2_sqrt, eps, gscale; };
+
+__device__ __forceinline__ void adamw_element(float& p, float g, float& m, float& v, const AdamHyper& h) {
+    const float gi = __fmul_rn(g, h.gscale);
+    const float pi = __fmul_rn(p, h.decay);
+    const float mi = __fmaf_rn(h.omb1, __fsub_rn(gi, m), m);
+    const float vi = __fmaf_rn(v, h.beta2, __fmul_rn(__fmul_rn(h.omb2, gi), gi));
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), h.bc2_sqrt), h.eps);
+    p = __fmaf_rn(-h.step_size, __fdiv_rn(mi, denom), pi);
+    m = mi; v = vi;
+}
+
+AdamHyper adam_hyper(float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale) {
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    return AdamHyper{(float)(1.0 - (double)lr * (double)weight_decay), (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2),
+                     (float)((double)lr / bc1), (float)sqrt(bc2), eps, grad_scale};
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, long n, AdamHyper h) {
     BBBP_HIGH_PRIO();
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        float gi = g[i] * gscale;
-        float pi = p[i] * decay;
-        float mi = m[i] + omb1 * (gi - m[i]);
-        float vi = v[i] * beta2 + omb2 * gi * gi;
-        float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] = pi - step_size * (mi / denom);
-        m[i] = mi; v[i] = vi;
+        float pi = p[i], mi = m[i], vi = v[i];
+        adamw_element(pi, g[i], mi, vi, h);
+        p[i] = pi; m[i] = mi; v[i] = vi;
     }
 }
 
@@ -556,19 +570,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
 // the model is a per-op composition: 180 tensors in the wide/deep variant = 180 launches and 2.7 ms of host time per step before this).  `offs`
 // (nt + 1 element offsets into the flat buffer, offs[0] = 0, offs[nt] = n) and `grads` (nt device pointers) live in device memory; the hyper-
 // parameters come by value or, when `hyper_dev` is set, from eight floats in device memory (a captured step replays with the values of the
-// day).  Same per-element expressions as adamw_kernel: bit-identical to nt single launches.
-struct AdamHyper { float decay, omb1, beta2, omb2, step_size, bc2_sqrt, eps, gscale; };
-
-__device__ __forceinline__ void adamw_element(float& p, float g, float& m, float& v, const AdamHyper& h) {
-    float gi = g * h.gscale;
-    float pi = p * h.decay;
-    float mi = m + h.omb1 * (gi - m);
-    float vi = v * h.beta2 + h.omb2 * gi * gi;
-    float denom = sqrtf(vi) / h.bc2_sqrt + h.eps;
-    p = pi - h.step_size * (mi / denom);
-    m = mi; v = vi;
-}
-
+// day).  Same adamw_element as adamw_kernel: bit-identical to nt single launches.
 __global__ void adamw_hyper_store_kernel(float* out, AdamHyper h) {
     if (threadIdx.x == 0) { out[0] = h.decay; out[1] = h.omb1; out[2] = h.beta2; out[3] = h.omb2; out[4] = h.step_size; out[5] = h.bc2_sqrt; out[6] = h.eps; out[7] = h.gscale; }
 }
@@ -853,22 +855,11 @@ extern "C" int bbbp_adamw_step(void* stream, float* param, const float* grad, fl
     BBBP_CHECK_ARG(step >= 1, "adamw: step is 1-based, got %d", step);
     if (n == 0) return BBBP_OK;
     (void)bbbp_param_wait(static_cast<hipStream_t>(stream), nullptr);     // a deferred slice of an earlier step is ordered before this update
-    double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    float decay = (float)(1.0 - (double)lr * (double)weight_decay);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), g_bbbp_small_lds_pad, ST, param, grad, exp_avg, exp_avg_sq, n, decay,
-                       (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), (float)((double)lr / bc1),
-                       (float)sqrt(bc2), eps, grad_scale);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), g_bbbp_small_lds_pad, ST, param, grad, exp_avg, exp_avg_sq, n,
+                       adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale));
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
 }
-
-namespace {
-AdamHyper adam_hyper(float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale) {
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    return AdamHyper{(float)(1.0 - (double)lr * (double)weight_decay), (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2),
-                     (float)((double)lr / bc1), (float)sqrt(bc2), eps, grad_scale};
-}
-}  // namespace
 
 // the eight derived floats the kernels compute with (decay, 1-beta1, beta2, 1-beta2, lr / bias-correction-1, sqrt(bias-correction-2), eps,
 // gradient scale) stored to device memory in stream order (`hyper_dev` below): the values travel as kernel arguments, so the host may call
@@ -932,13 +923,11 @@ extern "C" int bbbp_adamw_step_deferred(void* stream, float* param, const float*
             BBBP_CHECK_HIP(hipEventCreateWithFlags(&d.grads, hipEventDisableTiming));
         }
     }
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    const float decay = (float)(1.0 - (double)lr * (double)weight_decay);
+    const AdamHyper h = adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
     auto launch = [&](hipStream_t s, long a, long b) {
         if (b > a)
             hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(b - a)), dim3(256), g_bbbp_small_lds_pad, s, param + a, grad + a, exp_avg + a, exp_avg_sq + a,
-                               b - a, decay, (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), (float)((double)lr / bc1),
-                               (float)sqrt(bc2), eps, grad_scale);
+                               b - a, h);
     };
     // the gradients are final at this point of the caller's stream: the side stream starts there
     BBBP_CHECK_HIP(hipEventRecord(d.grads, st));

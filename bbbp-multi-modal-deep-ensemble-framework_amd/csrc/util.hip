@@ -81,3 +81,12 @@ extern "C" int bbbp_set_partition(int reserved_cus, size_t small_lds_pad) {
     g_bbbp_small_lds_pad = small_lds_pad;
     return prev;
 }
+
+// Op-level dropout streams keyed from device memory (round 4): every seeded entry point (bbbp_dropout, bbbp_softmax_*, bbbp_layernorm_*,
+// bbbp_linear* with output dropout, bbbp_attention_*) mixes *base into its `seed` argument when a base is set for the CALLING THREAD:
+// effective seed = *base * 0x9E3779B97F4A7C15 + seed.  A training step captured into a HIP graph thereby draws new masks on every replay
+// (the caller bumps *base before each one) although the recorded `seed` arguments are frozen.  NULL (the default) restores seed-only streams.
+extern "C" int bbbp_set_seed_base(const void* base_dev) {
+    g_bbbp_seed_base = static_cast<const unsigned long long*>(base_dev);
+    return BBBP_OK;
+}

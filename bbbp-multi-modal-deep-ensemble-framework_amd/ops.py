@@ -8,6 +8,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import threading
+
 import torch
 
 from . import _lib
@@ -15,7 +17,24 @@ from . import _lib
 ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2, 0: 0, 1: 1, 2: 2}
 
 
+_SEED_BASE = 0                  # device address of a 64-bit step counter the dropout streams are keyed from (training.GraphedTrainStep), or 0
+_tls = threading.local()
+
+
+def set_seed_base(ptr: int) -> int:
+    """Key every seeded op's dropout stream from the 64-bit integer at device address ``ptr`` (``bbbp_set_seed_base``); 0 restores the
+    default.  Process-wide on the Python side -- the library's setting is per thread and autograd runs backward nodes on its own
+    threads, so every op call re-applies it for the thread it runs on (``_stream``).  Returns the previous address."""
+    global _SEED_BASE
+    prev, _SEED_BASE = _SEED_BASE, int(ptr or 0)
+    return prev
+
+
 def _stream() -> int:
+    # every op passes here exactly once before it launches: the place to bring the calling thread's seed base up to date
+    if _SEED_BASE or getattr(_tls, "applied", 0):
+        _lib.check(_lib.lib().bbbp_set_seed_base(_SEED_BASE or None), "bbbp_set_seed_base")
+        _tls.applied = _SEED_BASE
     return torch.cuda.current_stream().cuda_stream
 
 

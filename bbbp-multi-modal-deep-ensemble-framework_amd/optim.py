@@ -36,6 +36,8 @@ class AdamW(torch.optim.Optimizer):
         self._capturable = bool(capturable)
         self._hyper = {}                # group index -> 8-float device tensor (capturable)
         self._tables = {}               # group index -> {gradient addresses: (device table, pinned host copy)}
+        self._capture_staging = {}      # group index -> pinned buffer set aside by prepare_capture()
+        self._graph_tables = []         # tables that belong to captured graphs
 
     def _hyper_of(self, gi, device):
         h = self._hyper.get(gi)
@@ -67,15 +69,36 @@ class AdamW(torch.optim.Optimizer):
         cache = self._tables.setdefault(gi, {})
         hit = cache.get(key)
         if hit is None:
-            if len(cache) >= 16 and not torch.cuda.is_current_stream_capturing():
-                cache.clear()
+            capturing = torch.cuda.is_current_stream_capturing()
             offs = [0]
             for p in params:
                 offs.append(offs[-1] + p.numel())
-            host = torch.tensor(offs + list(key), dtype=torch.int64).pin_memory()
-            hit = (host.to(params[0].device, non_blocking=True), host)
+            values = torch.tensor(offs + list(key), dtype=torch.int64)
+            if capturing:
+                # pinned memory cannot be allocated while a stream is capturing: prepare_capture() set a staging buffer aside; the upload
+                # becomes a node of the graph (replayed from that buffer, which therefore belongs to the graph from now on)
+                host = self._capture_staging.pop(gi, None)
+                if host is None or host.numel() != values.numel():
+                    raise RuntimeError("AdamW: call prepare_capture() before capturing a step (GraphedTrainStep does)")
+                host.copy_(values)
+            else:
+                if len(cache) >= 16:
+                    cache.clear()
+                host = values.pin_memory()
+            dev = torch.empty(values.numel(), dtype=torch.int64, device=params[0].device)
+            dev.copy_(host, non_blocking=True)
+            hit = (dev, host)
             cache[key] = hit
+            if capturing:
+                self._graph_tables.append(hit)            # never evicted
         return hit[0]
+
+    def prepare_capture(self) -> None:
+        """Before a step is captured into a graph: set pinned staging memory aside for the gradient-address tables the captured ``step()``
+        will upload (allocating pinned memory is not allowed during a capture)."""
+        for gi, group in enumerate(self.param_groups):
+            if group["params"]:
+                self._capture_staging[gi] = torch.empty(2 * len(group["params"]) + 1, dtype=torch.int64).pin_memory()
 
     def synchronize(self) -> None:
         """Order the current stream behind a deferred slice (see ``defer``); a no-op when nothing is pending."""

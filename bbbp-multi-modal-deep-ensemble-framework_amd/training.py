@@ -32,6 +32,80 @@ def mean_squared_error(y_true, y_pred) -> float:
     return float(((np.asarray(y_true, dtype=np.float64) - np.asarray(y_pred, dtype=np.float64)) ** 2).mean())
 
 
+class GraphedTrainStep:
+    """One training step -- forward, loss, backward, optimizer -- captured ONCE into a HIP graph and replayed (round 4).
+
+    For the models that are compositions of this package's ops at the Python level (``variants.WideDeepMixedInputModel``: ~600 launches
+    per step, each costing ~20 us of interpreter + autograd time, 13 ms per step of which the GPU is busy for half).  The flagship
+    ``MixedInputModel`` does not need it: its whole pass is one C call.  Each call is exactly one step of the reference loop's body
+    (Models/multi_input_data_regression_opt_transformer_cnn_20250113.py:186-193: ``zero_grad``, forward, ``criterion``, ``backward``,
+    ``optimizer.step``):
+
+    * the first ``eager_steps`` calls run eagerly (they are real steps, and they let every kernel set its attributes and every lazily
+      allocated buffer exist before the capture);
+    * the next call captures the step for the shapes it is given -- every later call must bring the same shapes -- copies the batch into
+      the graph's static input tensors and replays;
+    * dropout: the recorded per-site seeds are frozen, so the streams are keyed from a step counter in device memory that is bumped
+      before every replay (``bbbp_set_seed_base``): new masks every step, the same masks in a step's forward and backward;
+    * the optimizer must be ``AdamW(..., capturable=True)``: its step count / learning rate reach the kernel through device memory
+      (``advance()`` before every replay), so schedulers that rewrite ``group["lr"]`` keep working.
+
+    Returns the loss as a 0-d device tensor (the same tensor on every replay: read it before the next call)."""
+
+    def __init__(self, model, optimizer, loss_fn=None, eager_steps: int = 2):
+        if not getattr(optimizer, "_capturable", False):
+            raise ValueError("GraphedTrainStep needs optim.AdamW(..., capturable=True)")
+        self.model, self.optimizer = model, optimizer
+        self.loss_fn = loss_fn if loss_fn is not None else torch.nn.MSELoss()
+        self.eager_steps = int(eager_steps)
+        self.calls = 0
+        self.graph = None
+        self.static = None              # the graph's input tensors (*inputs, target)
+        self._seed = None
+        self._loss = None
+
+    def _body(self, inputs, target):
+        loss = self.loss_fn(self.model(*inputs).squeeze(), target)
+        loss.backward()
+        self.optimizer.step()
+        return loss
+
+    def _capture(self, inputs, target):
+        from . import ops
+        if not self.model.training:
+            raise RuntimeError("GraphedTrainStep: the model must be in train mode when the step is captured")
+        self.static = [t.clone() for t in (*inputs, target)]
+        self._seed = torch.zeros(1, dtype=torch.int64, device=target.device)
+        self.optimizer.zero_grad(set_to_none=True)          # the captured backward then WRITES the gradients (no accumulate kernels)
+        self.optimizer.prepare_capture()
+        graph = torch.cuda.CUDAGraph()
+        prev = ops.set_seed_base(self._seed.data_ptr())
+        try:
+            with torch.cuda.graph(graph):
+                loss = self._body(self.static[:-1], self.static[-1])
+        finally:
+            ops.set_seed_base(prev)
+        self.graph, self._loss = graph, loss.detach()
+
+    def __call__(self, *batch):
+        *inputs, target = batch
+        self.calls += 1
+        if self.graph is None:
+            if self.calls <= self.eager_steps:
+                self.optimizer.zero_grad(set_to_none=True)
+                return self._body(inputs, target).detach()
+            self._capture(inputs, target)
+        for s, t in zip(self.static, batch):
+            if t.shape != s.shape:
+                raise RuntimeError(f"GraphedTrainStep was captured for a batch of shape {tuple(s.shape)}, got {tuple(t.shape)}")
+            if t.data_ptr() != s.data_ptr():
+                s.copy_(t, non_blocking=True)
+        self._seed.add_(1)
+        self.optimizer.advance()
+        self.graph.replay()
+        return self._loss
+
+
 @torch.no_grad()
 def predict(model, fingerprints: torch.Tensor, images: torch.Tensor, batch_size: int = 32) -> torch.Tensor:
     """Eval-mode predictions in loader order (reference :229-237).  NOTE: the encoder attends across each mini-batch, so the

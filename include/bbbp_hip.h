@@ -212,6 +212,11 @@ int bbbp_adamw_step_multi(void* stream, float* param, float* exp_avg, float* exp
                           float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, const float* hyper_dev);
 /* stores those eight floats (derived on the host in double, as bbbp_adamw_step derives them) to device memory in stream order */
 int bbbp_adamw_hyper_store(void* stream, float* hyper_dev, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale);
+/* Op-level dropout streams keyed from device memory (round 4).  With a base set for the CALLING THREAD, every seeded entry point of this
+ * header (dropout, softmax, layernorm, linear with output dropout, attention) uses the stream  *base * 0x9E3779B97F4A7C15 + seed  instead of
+ * `seed`: a training step captured into a HIP graph draws new masks on each replay when the caller bumps the 64-bit integer at `base_dev`
+ * before it.  NULL restores the default.  Forward and backward of one step must see the same base and the same *base. */
+int bbbp_set_seed_base(const void* base_dev);
 int bbbp_param_sync(void* stream);
 void* bbbp_param_stream(void);     /* the side stream of the current device (NULL before the first deferred step) */
 int bbbp_scale(void* stream, float* x, long n, float s);

@@ -151,3 +151,114 @@ def test_pipelined_conv1_forward_in_training_plans_matches_f32_kernel(dev):
         scale = float(g0[n].abs().max())
         tol = 1e-2 if n.startswith("image_cnn.") else 5e-4           # the conv gradients: 10^6-term sums behind pooling decisions that flip at near-ties
         assert float((g0[n] - g1[n]).abs().max()) <= tol * scale + 1e-9, (n, float((g0[n] - g1[n]).abs().max()), scale)
+
+
+# ---- multi-tensor / capturable AdamW and the graph-captured step of the per-op variants -------------------------------------------------
+def _flat_params(dev, sizes, seed):
+    g = torch.Generator().manual_seed(seed)
+    flat = torch.randn(sum(int(np.prod(s)) for s in sizes), generator=g).to(dev)
+    params, off = [], 0
+    for s in sizes:
+        n = int(np.prod(s))
+        params.append(torch.nn.Parameter(flat[off:off + n].view(s)))
+        off += n
+    return flat, params
+
+
+def test_multi_tensor_adamw_is_bit_identical_to_one_launch_per_tensor(dev):
+    # odd sizes: tensors that start at offsets 1, 2, 3 mod 4 of the flat buffer, a tensor shorter than a float4, one longer than a launch wave
+    sizes = [(167,), (3, 5), (1,), (2,), (513, 167), (4,), (167, 501), (7,), (1024, 256), (3,)]
+    flat_a, pa = _flat_params(dev, sizes, 5)
+    flat_b, pb = _flat_params(dev, sizes, 5)
+    oa = AdamW(pa, lr=3e-3, weight_decay=1e-2)
+    ob = [torch.zeros_like(flat_b), torch.zeros_like(flat_b)]
+    g = torch.Generator().manual_seed(6)
+    for step in range(1, 5):
+        grads = [torch.randn(s, generator=g).to(dev) * 10.0 ** float(torch.randint(-6, 2, (1,), generator=g)) for s in sizes]
+        for p, gr in zip(pa, grads):
+            p.grad = gr.clone()                         # separate tensors: the multi-tensor launch
+        assert ops is not None
+        oa.step()
+        off = 0
+        for p, gr in zip(pb, grads):                     # the yardstick: one launch per tensor on views of flat buffers
+            n = p.numel()
+            ops.adamw_step_(p.data.view(-1), gr.contiguous().view(-1), ob[0][off:off + n], ob[1][off:off + n], step, lr=3e-3, weight_decay=1e-2)
+            off += n
+        assert torch.equal(flat_a, flat_b), f"step {step}"
+        assert torch.equal(oa._flat_state[0][0], ob[0]) and torch.equal(oa._flat_state[0][1], ob[1])
+    assert len(oa._tables[0]) >= 1                       # it did go through the table
+
+
+def test_capturable_adamw_equals_the_plain_step_and_follows_the_learning_rate(dev):
+    sizes = [(167,), (64, 167), (5,)]
+    flat_a, pa = _flat_params(dev, sizes, 8)
+    flat_b, pb = _flat_params(dev, sizes, 8)
+    oa, ob = AdamW(pa, lr=1e-3, weight_decay=1e-2, capturable=True), AdamW(pb, lr=1e-3, weight_decay=1e-2)
+    g = torch.Generator().manual_seed(9)
+    for step in range(4):
+        for o in (oa, ob):
+            o.param_groups[0]["lr"] = 1e-3 / (1 + step)           # what a scheduler does
+        grads = [torch.randn(s, generator=g).to(dev) for s in sizes]
+        for p, q, gr in zip(pa, pb, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+        assert torch.equal(flat_a, flat_b), f"step {step}"
+    assert oa.state[pa[0]]["step"] == ob.state[pb[0]]["step"] == 4
+
+
+def _no_dropout(model):
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+
+
+def _wide(dev, seed, dropout):
+    from bbbp_amd import variants
+    torch.manual_seed(seed)
+    m = variants.WideDeepMixedInputModel(64, 128).to(dev).train()
+    if not dropout:
+        _no_dropout(m)
+    return m
+
+
+def test_graph_captured_step_equals_the_eager_step(dev):
+    """Dropout off: five steps through GraphedTrainStep (two eager, capture, three replays) against five eager steps with the plain
+    optimizer, on alternating batches -- same kernels in the same order, so the same bits (compared with a float32-rounding margin)."""
+    from bbbp_amd.training import GraphedTrainStep
+    B, F = 8, 64
+    fp, img, y = (t.to(dev) for t in synth_inputs(21, 2 * B, F, 49152))
+    ma, mb = _wide(dev, 4, False), _wide(dev, 4, False)
+    oa = AdamW(ma.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True)
+    ob = AdamW(mb.parameters(), lr=1e-3, weight_decay=1e-5)
+    graphed = GraphedTrainStep(ma, oa, eager_steps=2)
+    la, lb = [], []
+    for i in range(5):
+        s = (i % 2) * B
+        la.append(float(graphed(fp[s:s + B], img[s:s + B], y[s:s + B])))
+        loss = torch.nn.MSELoss()(mb(fp[s:s + B], img[s:s + B]).squeeze(), y[s:s + B])
+        loss.backward(); ob.step(); ob.zero_grad(set_to_none=True)
+        lb.append(float(loss))
+    assert graphed.graph is not None and graphed.calls == 5
+    np.testing.assert_allclose(la, lb, rtol=1e-5)
+    pa = torch.cat([p.detach().reshape(-1) for p in ma.parameters()])
+    pb = torch.cat([p.detach().reshape(-1) for p in mb.parameters()])
+    assert float((pa - pb).abs().max()) <= 1e-6 + 1e-5 * float(pb.abs().max())
+    assert oa.state[next(iter(ma.parameters()))]["step"] == 5
+
+
+def test_graph_captured_step_draws_new_dropout_masks_on_every_replay(dev):
+    """lr = 0 and one fixed batch: the parameters never move, so the loss of a replay changes only through its dropout masks -- every
+    replay must give another loss (the recorded seeds are frozen; the device-side step counter is what moves the streams)."""
+    from bbbp_amd.training import GraphedTrainStep
+    B, F = 8, 64
+    fp, img, y = (t.to(dev) for t in synth_inputs(22, B, F, 49152))
+    m = _wide(dev, 5, True)
+    opt = AdamW(m.parameters(), lr=0.0, weight_decay=0.0, capturable=True)
+    graphed = GraphedTrainStep(m, opt, eager_steps=1)
+    losses = [float(graphed(fp, img, y)) for _ in range(6)]
+    assert graphed.graph is not None
+    assert len(set(losses[1:])) == 5, losses
+    # ... and the eager ops that run afterwards are back on seed-only streams (the base is not left set)
+    x = torch.randn(64, 64, device=dev)
+    assert torch.equal(ops.dropout(x, 0.5, 123), ops.dropout(x, 0.5, 123))
+    assert ops._SEED_BASE == 0
