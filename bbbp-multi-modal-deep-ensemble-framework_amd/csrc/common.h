@@ -121,9 +121,10 @@ int bbbp_b3_conv_dgrad(hipStream_t st, const float* gy, const uint8_t* gmask, co
 int bbbp_b3_conv2_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* y, uint8_t* mask, int B, void* workspace);
 int bbbp_b3_conv2_dgrad(hipStream_t st, const float* gy, const uint8_t* gmask, const float* w, float* dx, int B, void* workspace);
 // form: 0 dense split-bf16, 1 structured-sparse MFMA (8 waves, or 4 beside an encoder chain), 2 structured-sparse, 4 waves
-// (cin_total, cout_total, groups: the stage's channel counts and the work-groups per (32 ci, 64 co) block pair; grid = pairs * groups; 64 x 64 maps)
+// (cin_total, cout_total, groups: the stage's channel counts and the work-groups per (32 ci, 64 co) block pair; grid = pairs * groups;
+//  map: 64 x 64 maps, or 32 x 32 for the sparse forms)
 int bbbp_b3_conv2_wgrad(hipStream_t st, const float* x, const float* gy, const uint8_t* mask, float* slab, float* bslab, int B, int grid, int form,
-                        int cin_total = 32, int cout_total = 64, int groups = 0);
+                        int cin_total = 32, int cout_total = 64, int groups = 0, int map = 64);
 int bbbp_b3_last_clock(unsigned long long* shader_cycles, unsigned long long* ticks_100mhz);
 // conv_b3c1.hip: forward of the first stage (3 -> 32 @ 128x128) in the same arithmetic, channel-innermost LDS strip, no operand assembly
 size_t bbbp_b3_conv1_fwd_workspace_bytes();

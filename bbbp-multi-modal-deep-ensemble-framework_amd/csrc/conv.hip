@@ -978,6 +978,9 @@ extern "C" int bbbp_conv3x3_relu_pool_bwd_weight(void* stream, const float* x, c
         if (W == 64 && H == 64 && ((cin == 32 && cout == 64) || (cin == 64 && cout == 128)) && (winograd_mask() & 16))
             rc = bbbp_b3_conv2_wgrad(st, x, gy, mask, slab, p.bslab, B, grid, (winograd_mask() & 128) ? ((winograd_mask() & 256) ? 2 : 1) : 0,
                                      cin, cout, groups);
+        else if (W == 32 && H == 32 && cin == 128 && cout == 256 && (winograd_mask() & 16) && (winograd_mask() & 128))
+            // the variant's third stage on the structured-sparse form (16 block pairs; a stage = two pooled rows)
+            rc = bbbp_b3_conv2_wgrad(st, x, gy, mask, slab, p.bslab, B, grid, (winograd_mask() & 256) ? 2 : 1, cin, cout, groups, 32);
         else rc = cin == 32 ? launch_wgrad32<64, 32, 64>(p, grid, st)
                : cin == 64 ? launch_wgrad32<64, 64, 128>(p, grid, st) : launch_wgrad32<32, 128, 256>(p, grid, st);
         if (rc) return rc;

@@ -556,10 +556,19 @@ constexpr size_t WGS_LDS_BYTES = (size_t)(3 * WXPLANE + 2 * ASP_RR) * 2 + 64 * 8
 typedef __bf16 bf16x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 
-template <int NW>
+// IW = 64: a stage is one pooled row (k-blocks = window row x left / right half).  IW = 32 (round 4: the wide / deep variant's 128 -> 256 stage): a
+// stage is TWO pooled rows of 16 -- the same 32 pooled pixels per channel, contiguous in memory -- and six input rows of 32 pixels; k-blocks =
+// window row x pooled row, each the full width.  Everything downstream of the LDS image (fragments, positions, MFMAs) is the same code.
+template <int NW, int IW = 64>
 __global__ __launch_bounds__(64 * NW) void conv_b3_wgrad_sp_kernel(B3WgradParams p) {
+    static_assert(IW == 64 || IW == 32, "64 x 64 or 32 x 32 maps");
+    constexpr int XR = IW == 64 ? 4 : 6;                    // staged input rows
+    constexpr int XROWW = IW + 16, XCIW = XR * XROWW + 8;   // (IW = 64: XROW, XCI)
+    constexpr int QPR = IW / 8;                             // 8-pixel groups per input row
+    constexpr int NXI = 32 * XR * QPR;                      // X items per stage (1024 / 768)
+    static_assert(XCIW <= XCI, "LDS image of the 32-pixel form fits the 64-pixel allocation");
     if (p.prio >= 3) __builtin_amdgcn_s_setprio(3); else if (p.prio == 2) __builtin_amdgcn_s_setprio(2); else if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
-    constexpr int NTH = 64 * NW, NA = 512 / NTH, NX = 1024 / NTH, NKB = 8 / NW;          // items per thread, k-blocks per wave
+    constexpr int NTH = 64 * NW, NA = 512 / NTH, NX = (NXI + NTH - 1) / NTH, NKB = 8 / NW;          // items per thread, k-blocks per wave
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     uint16_t* XsW = smem;                        // [plane][ci][row 4][XROW]
     uint16_t* Asp = smem + 3 * WXPLANE;          // [row of the window 2][plane][co][slot 8][4 pooled px]
@@ -567,13 +576,13 @@ __global__ __launch_bounds__(64 * NW) void conv_b3_wgrad_sp_kernel(B3WgradParams
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
     const int mt = wave & 1, kq = wave >> 1;                 // k-group: NW = 8: one k-block (row kq >> 1, half kq & 1); NW = 4: row kq, both halves
     const int rr = NW == 8 ? kq >> 1 : kq;
-    const int nstrips = p.B * (IMG / 2);
+    const int nstrips = p.B * (IW == 64 ? 32 : 8);
     const int pair = blockIdx.x / p.groups, grp = blockIdx.x % p.groups, ncib = p.cin_total / 32;
     // this pair's channel blocks as uniform base pointers + per-image strides (scalar registers: the loaders' vector arithmetic is unchanged)
-    const float* const gyb = p.gy + (long)(pair / ncib) * 64 * (IMG / 2) * (IMG / 2);
-    const uint8_t* const mkb = p.mask + (long)(pair / ncib) * 64 * (IMG / 2) * (IMG / 2);
-    const float* const xbk = p.x + (long)(pair % ncib) * 32 * IMG * IMG;
-    const long gy_img = (long)p.cout_total * (IMG / 2) * (IMG / 2), x_img = (long)p.cin_total * IMG * IMG;
+    const float* const gyb = p.gy + (long)(pair / ncib) * 64 * (IW / 2) * (IW / 2);
+    const uint8_t* const mkb = p.mask + (long)(pair / ncib) * 64 * (IW / 2) * (IW / 2);
+    const float* const xbk = p.x + (long)(pair % ncib) * 32 * IW * IW;
+    const long gy_img = (long)p.cout_total * (IW / 2) * (IW / 2), x_img = (long)p.cin_total * IW * IW;
     for (int i = t * 8; i < 3 * WXPLANE + 2 * ASP_RR + 64 * 4; i += NTH * 8) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0, 0, 0, 0};
 
     // ---- loader: NA dY items (co, quad of 4 pooled px) and NX X items (ci, row, 8 px) per thread ----
@@ -583,21 +592,22 @@ __global__ __launch_bounds__(64 * NW) void conv_b3_wgrad_sp_kernel(B3WgradParams
     for (int i = 0; i < NA; ++i) bsum[i] = 0.f;
     uint32_t okx = 0;
     auto load_stage = [&](int strip) __attribute__((always_inline)) {
-        const int b = strip / (IMG / 2), ph = strip % (IMG / 2);
+        constexpr int SPI = IW == 64 ? 32 : 8;             // stages per image; a stage's 32 pooled pixels are contiguous in both forms
+        const int b = strip / SPI, ph = strip % SPI;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int idx = t + i * NTH, a_q = idx & 7, a_co = idx >> 3;
-            const long off = (long)b * gy_img + (a_co * (IMG / 2) + ph) * (IMG / 2) + a_q * 4;
+            const long off = (long)b * gy_img + a_co * (IW / 2) * (IW / 2) + ph * 32 + a_q * 4;
             gq[i] = *reinterpret_cast<const f32x4*>(gyb + off);
             mq[i] = *reinterpret_cast<const uint32_t*>(mkb + off);
         }
         okx = 0;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int idx = t + i * NTH, q = idx & 7, row = (idx >> 3) & 3, ci = idx >> 5;
-            const int yr = 2 * ph - 1 + row;
-            okx |= (yr >= 0 && yr < IMG ? 1u : 0u) << i;
-            const float* src = xbk + (long)b * x_img + (ci * IMG + min(max(yr, 0), IMG - 1)) * IMG + q * 8;
+            const int idx = min(t + i * NTH, NXI - 1), q = idx % QPR, row = (idx / QPR) % XR, ci = idx / (QPR * XR);
+            const int yr = (IW == 64 ? 2 : 4) * ph - 1 + row;
+            okx |= (yr >= 0 && yr < IW ? 1u : 0u) << i;
+            const float* src = xbk + (long)b * x_img + (ci * IW + min(max(yr, 0), IW - 1)) * IW + q * 8;
             xq[i][0] = *reinterpret_cast<const f32x4*>(src);
             xq[i][1] = *reinterpret_cast<const f32x4*>(src + 4);
         }
@@ -630,7 +640,8 @@ __global__ __launch_bounds__(64 * NW) void conv_b3_wgrad_sp_kernel(B3WgradParams
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int idx = t + i * NTH, q = idx & 7, row = (idx >> 3) & 3, ci = idx >> 5;
+            if (NXI % NTH != 0 && t + i * NTH >= NXI) continue;
+            const int idx = t + i * NTH, q = idx % QPR, row = (idx / QPR) % XR, ci = idx / (QPR * XR);
             const bool ok = (okx >> i) & 1u;
             uint32_t hi[4], mid[4], lo[4];
 #pragma unroll
@@ -638,7 +649,7 @@ __global__ __launch_bounds__(64 * NW) void conv_b3_wgrad_sp_kernel(B3WgradParams
                 const float a = j < 2 ? xq[i][0][2 * j] : xq[i][1][2 * j - 4], c = j < 2 ? xq[i][0][2 * j + 1] : xq[i][1][2 * j - 3];
                 split2(ok ? a : 0.f, ok ? c : 0.f, hi[j], mid[j], lo[j]);
             }
-            uint16_t* d = XsW + ci * XCI + row * XROW + 8 + q * 8;
+            uint16_t* d = XsW + ci * XCIW + row * XROWW + 8 + q * 8;
             *reinterpret_cast<u32x4*>(d) = u32x4{hi[0], hi[1], hi[2], hi[3]};
             *reinterpret_cast<u32x4*>(d + WXPLANE) = u32x4{mid[0], mid[1], mid[2], mid[3]};
             *reinterpret_cast<u32x4*>(d + 2 * WXPLANE) = u32x4{lo[0], lo[1], lo[2], lo[3]};
@@ -663,7 +674,8 @@ __global__ __launch_bounds__(64 * NW) void conv_b3_wgrad_sp_kernel(B3WgradParams
         for (int kb = 0; kb < NKB; ++kb) {
         const int xb = NW == 8 ? (kq & 1) : kb;
         const uint16_t* abase = Asp + rr * ASP_RR + co * ASP_CO + (4 * xb + 2 * h) * 4;
-        const uint16_t* bbase = XsW + r * XCI + 8 + 32 * xb + 16 * h;
+        // IW = 64: k-block xb = the left / right 32 pixels of rows rr ..; IW = 32: xb = the pooled row, all 32 pixels of rows 2 xb + rr ..
+        const uint16_t* bbase = XsW + r * XCIW + 8 + (IW == 64 ? 32 * xb : 2 * xb * XROWW) + 16 * h;
         bf16x8 a[3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(abase + pl * ASP_PLANE);
@@ -674,7 +686,7 @@ __global__ __launch_bounds__(64 * NW) void conv_b3_wgrad_sp_kernel(B3WgradParams
             u32x8 w[3]; uint32_t wm[3], wp[3];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
-                const uint16_t* src = bbase + pl * WXPLANE + (rr + dyi) * XROW;
+                const uint16_t* src = bbase + pl * WXPLANE + (rr + dyi) * XROWW;
                 const u32x4 w0 = *reinterpret_cast<const u32x4*>(src), w1 = *reinterpret_cast<const u32x4*>(src + 8);
                 w[pl] = u32x8{w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
                 wm[pl] = *reinterpret_cast<const uint32_t*>(src - 2);
@@ -998,11 +1010,23 @@ extern "C" int bbbp_conv_b3_phases(unsigned long long* phases4) {
 
 // grid work-groups, each writes slab[g][64][288] and bslab[g][64] (conv.hip: conv_wgrad32_reduce_kernel finishes)
 int bbbp_b3_conv2_wgrad(hipStream_t st, const float* x, const float* gy, const uint8_t* mask, float* slab, float* bslab, int B, int grid, int form,
-                        int cin_total, int cout_total, int groups) {
+                        int cin_total, int cout_total, int groups, int map) {
     B3WgradParams p{x, gy, mask, slab, bslab, B, conv_bwd_prio(), cin_total, cout_total, groups > 0 ? groups : grid};
+    BBBP_CHECK_ARG(map == 64 || (map == 32 && form != 0), "b3 weight gradient: 64 x 64 maps (any form) or 32 x 32 maps (structured-sparse forms), got %d / form %d", map, form);
     const bool sparse = form != 0;
     static const int waves_env = [] { const char* e = getenv("BBBP_C2_WGRAD_SPARSE_WAVES"); return e ? atoi(e) : 0; }();
     const int waves = waves_env ? waves_env : ((form == 2 || g_bbbp_conv_wgrad_beside_encoder) ? 4 : 8);
+    if (map == 32) {
+        if (waves == 8) {
+            { int rc_ = bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(conv_b3_wgrad_sp_kernel<8, 32>), WGS_LDS_BYTES); if (rc_) return rc_; }
+            hipLaunchKernelGGL((conv_b3_wgrad_sp_kernel<8, 32>), dim3(grid), dim3(512), WGS_LDS_BYTES, st, p);
+        } else {
+            { int rc_ = bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(conv_b3_wgrad_sp_kernel<4, 32>), WGS_LDS_BYTES); if (rc_) return rc_; }
+            hipLaunchKernelGGL((conv_b3_wgrad_sp_kernel<4, 32>), dim3(grid), dim3(256), WGS_LDS_BYTES, st, p);
+        }
+        BBBP_CHECK_LAUNCH();
+        return BBBP_OK;
+    }
     if (sparse && waves == 8) {
         { int rc_ = bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(conv_b3_wgrad_sp_kernel<8>), WGS_LDS_BYTES); if (rc_) return rc_; }
         hipLaunchKernelGGL(conv_b3_wgrad_sp_kernel<8>, dim3(grid), dim3(512), WGS_LDS_BYTES, st, p);

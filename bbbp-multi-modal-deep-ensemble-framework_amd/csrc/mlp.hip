@@ -252,8 +252,22 @@ __device__ __forceinline__ double block_sum16(double v, double* red) {
     return s;
 }
 
+// PROF: work-group 0's thread 0 adds the shader-clock cycles of every phase of a mini-batch to g_mlp_prof (bbbp_mlp_profile reads them): the
+// only way to see inside one persistent launch.  Slots: 0-2 forward layer l; 3 loss; 4 + 2 l delta below layer l, 5 + 2 l weight gradient + Adam of
+// layer l; 10 mini-batch tail; 11 epoch tail; 15 mini-batches counted.
+__device__ unsigned long long g_mlp_prof[16];
+
+template <bool PROF>
 __global__ __launch_bounds__(MT) void mlp_train_mfma_kernel(bbbp_mlp_model* models, const double* X, const double* y, int n_features, int epochs) {
     __shared__ double red[MW];
+    unsigned long long prof_last = PROF ? clock64() : 0ull;
+    auto mark = [&](int slot) __attribute__((always_inline)) {
+        if (PROF && blockIdx.x == 0 && threadIdx.x == 0) {
+            const unsigned long long now = clock64();
+            g_mlp_prof[slot] += now - prof_last;
+            prof_last = now;
+        }
+    };
     __shared__ double lr_shared;
     bbbp_mlp_model& M = models[blockIdx.x];
     if (M.done) return;
@@ -312,6 +326,7 @@ __global__ __launch_bounds__(MT) void mlp_train_mfma_kernel(bbbp_mlp_model* mode
                         }
                 }
                 __syncthreads();
+                mark(l);
             }
             // ---- loss: log-loss of the batch; the L2 term's sum W^2 comes out of the weight-gradient pass below (same weights) ----
             const double* prob = A + aoff[L];
@@ -325,6 +340,7 @@ __global__ __launch_bounds__(MT) void mlp_train_mfma_kernel(bbbp_mlp_model* mode
             double loss = -block_sum16(part, red) / nb;   // (its barriers also publish the output delta)
             const double lr_t = lr_shared;
             double wsq = 0.0;
+            mark(3);
             // ---- backward: per layer, top down: delta of the layer below (old weights), then weight gradient + Adam ----
             for (int l = L - 1; l >= 0; --l) {
                 const int fin = M.units[l], fout = M.units[l + 1];
@@ -360,6 +376,7 @@ __global__ __launch_bounds__(MT) void mlp_train_mfma_kernel(bbbp_mlp_model* mode
                             }
                     }
                     __syncthreads();      // every wave is done READING W[l] (and the delta below is complete) before anybody updates W[l]
+                    mark(4 + 2 * l);
                 }
                 // dW[k][j] = (sum_r a[l][r][k] delta[l+1][r][j] + alpha W[k][j]) / nb, then Adam in place; 32 x 32 wave tiles, K = batch rows
                 {
@@ -406,11 +423,14 @@ __global__ __launch_bounds__(MT) void mlp_train_mfma_kernel(bbbp_mlp_model* mode
                         bp[j] += -lr_t * m / (sqrt(v) + adam_eps);
                     }
                 }
+                mark(5 + 2 * l);
             }
             loss += 0.5 * alpha * block_sum16(wsq, red) / nb;      // sum over all layers of ||W||^2 (the weights the forward pass used)
             accumulated += loss * nb;
             if (t == 0) M.t = M.t + 1;
             __syncthreads();              // the update is complete before the next mini-batch reads the parameters
+            mark(10);
+            if (PROF && blockIdx.x == 0 && t == 0) g_mlp_prof[15] += 1;
         }
         if (t == 0) {
             const double loss_epoch = accumulated / n;
@@ -421,6 +441,7 @@ __global__ __launch_bounds__(MT) void mlp_train_mfma_kernel(bbbp_mlp_model* mode
             if (M.no_improve > M.n_iter_no_change || M.n_iter >= M.max_iter) M.done = 1;
         }
         __syncthreads();
+        mark(11);
     }
 }
 
@@ -451,6 +472,8 @@ __global__ __launch_bounds__(NT) void mlp_predict_kernel(const bbbp_mlp_model* m
     for (int r = t; r < nb; r += NT) out[r0 + r] = buf[(L - 1) & 1][r];
 }
 
+bool g_mlp_profile_on = false;
+
 }  // namespace
 
 extern "C" int bbbp_mlp_train_epochs(void* stream, bbbp_mlp_model* models_dev, int n_models, const double* X, const double* y,
@@ -462,9 +485,23 @@ extern "C" int bbbp_mlp_train_epochs(void* stream, bbbp_mlp_model* models_dev, i
     const char* e = getenv("BBBP_MLP_SCALAR");
     if (e && atoi(e) != 0)
         hipLaunchKernelGGL(mlp_train_scalar_kernel, dim3(n_models), dim3(NT), 0, static_cast<hipStream_t>(stream), models_dev, X, y, n_features, epochs);
+    else if (g_mlp_profile_on)
+        hipLaunchKernelGGL(mlp_train_mfma_kernel<true>, dim3(n_models), dim3(MT), 0, static_cast<hipStream_t>(stream), models_dev, X, y, n_features, epochs);
     else
-        hipLaunchKernelGGL(mlp_train_mfma_kernel, dim3(n_models), dim3(MT), 0, static_cast<hipStream_t>(stream), models_dev, X, y, n_features, epochs);
+        hipLaunchKernelGGL(mlp_train_mfma_kernel<false>, dim3(n_models), dim3(MT), 0, static_cast<hipStream_t>(stream), models_dev, X, y, n_features, epochs);
     BBBP_CHECK_LAUNCH();
+    return BBBP_OK;
+}
+
+// Phase profile of the trainer (see g_mlp_prof): on != 0 selects the instrumented kernel for later bbbp_mlp_train_epochs calls and clears the
+// counters; cycles16 (host, nullable) receives the 16 counters accumulated so far (synchronises the device).
+extern "C" int bbbp_mlp_profile(int on, unsigned long long* cycles16) {
+    if (cycles16) BBBP_CHECK_HIP(hipMemcpyFromSymbol(cycles16, HIP_SYMBOL(g_mlp_prof), sizeof(unsigned long long) * 16));
+    if (on) {
+        static const unsigned long long zeros[16] = {};
+        BBBP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_prof), zeros, sizeof(zeros)));
+    }
+    g_mlp_profile_on = on != 0;
     return BBBP_OK;
 }
 

@@ -90,3 +90,13 @@ extern "C" int bbbp_set_seed_base(const void* base_dev) {
     g_bbbp_seed_base = static_cast<const unsigned long long*>(base_dev);
     return BBBP_OK;
 }
+
+// The conv2-family weight gradient has two structured-sparse forms (conv_b3.hip): 8 waves (fastest alone) and 4 waves (one wave per SIMD: the
+// form to run while ANOTHER branch's small kernels share the GPU).  bbbp_mixed_backward picks by itself; a caller that composes the model
+// op by op and overlaps its branches on two streams says so for the calling thread around its bbbp_conv3x3_relu_pool_bwd_weight call.
+// Returns the previous setting.
+extern "C" int bbbp_set_conv_wgrad_beside_encoder(int on) {
+    const int prev = g_bbbp_conv_wgrad_beside_encoder;
+    g_bbbp_conv_wgrad_beside_encoder = on ? 1 : 0;
+    return prev;
+}

@@ -240,22 +240,34 @@ class _ConvReluPool(torch.autograd.Function):
     """Conv2d(k3,s1,p1) + ReLU + MaxPool2d(2,2) as one fused HIP op with its data / weight gradients."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, beside):
         y, mask = ops.conv3x3_relu_pool_fwd(x, weight, bias)
         ctx.save_for_backward(x, weight, mask)
+        ctx.beside = beside
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, weight, mask = ctx.saved_tensors
         gy = gy.contiguous()
-        dw, db = ops.conv3x3_relu_pool_bwd_weight(x, gy, mask)
+        if ctx.beside:
+            # another branch's kernels run beside this one on a second stream: the one-wave-per-SIMD form of the weight gradient (set for
+            # this thread -- autograd's -- around the call)
+            L = _lib.lib()
+            prev = L.bbbp_set_conv_wgrad_beside_encoder(1)
+            try:
+                dw, db = ops.conv3x3_relu_pool_bwd_weight(x, gy, mask)
+            finally:
+                L.bbbp_set_conv_wgrad_beside_encoder(prev)
+        else:
+            dw, db = ops.conv3x3_relu_pool_bwd_weight(x, gy, mask)
         dx = ops.conv3x3_relu_pool_bwd_data(gy, mask, weight) if ctx.needs_input_grad[0] else None
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def conv3x3_relu_pool(x, conv: "torch.nn.Conv2d"):
-    return _ConvReluPool.apply(x.contiguous(), conv.weight, conv.bias)
+def conv3x3_relu_pool(x, conv: "torch.nn.Conv2d", beside_other_branch: bool = False):
+    """``beside_other_branch``: the caller runs another branch of the model on a second stream at the same time (variants.py)."""
+    return _ConvReluPool.apply(x.contiguous(), conv.weight, conv.bias, bool(beside_other_branch))
 
 
 class _EncoderLayer(torch.autograd.Function):

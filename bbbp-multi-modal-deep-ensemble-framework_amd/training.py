@@ -36,21 +36,27 @@ class GraphedTrainStep:
     """One training step -- forward, loss, backward, optimizer -- captured ONCE into a HIP graph and replayed (round 4).
 
     For the models that are compositions of this package's ops at the Python level (``variants.WideDeepMixedInputModel``: ~600 launches
-    per step, each costing ~20 us of interpreter + autograd time, 13 ms per step of which the GPU is busy for half).  The flagship
+    per step, each costing ~20 us of interpreter + autograd time: 12.5-16.5 ms per step eagerly, 6.3 replayed).  The flagship
     ``MixedInputModel`` does not need it: its whole pass is one C call.  Each call is exactly one step of the reference loop's body
     (Models/multi_input_data_regression_opt_transformer_cnn_20250113.py:186-193: ``zero_grad``, forward, ``criterion``, ``backward``,
     ``optimizer.step``):
 
-    * the first ``eager_steps`` calls run eagerly (they are real steps, and they let every kernel set its attributes and every lazily
-      allocated buffer exist before the capture);
-    * the next call captures the step for the shapes it is given -- every later call must bring the same shapes -- copies the batch into
-      the graph's static input tensors and replays;
+    * a graph belongs to a (batch shapes, ``model.training``) pair -- the published loop trains in eval mode from epoch 2 on, and its last
+      batch of an epoch is ragged: each pair gets its own capture; the first ``eager_steps`` calls of a pair run eagerly (they are real
+      steps, and they let every kernel set its attributes and every lazily allocated buffer exist before the capture), the next call
+      captures, copies the batch into the graph's static input tensors and replays, as does every later one;
     * dropout: the recorded per-site seeds are frozen, so the streams are keyed from a step counter in device memory that is bumped
       before every replay (``bbbp_set_seed_base``): new masks every step, the same masks in a step's forward and backward;
     * the optimizer must be ``AdamW(..., capturable=True)``: its step count / learning rate reach the kernel through device memory
       (``advance()`` before every replay), so schedulers that rewrite ``group["lr"]`` keep working.
 
-    Returns the loss as a 0-d device tensor (the same tensor on every replay: read it before the next call)."""
+    Returns the loss as a 0-d device tensor (replays of one graph return the same tensor: read or accumulate it before the next call)."""
+
+    class _Entry:
+        __slots__ = ("calls", "graph", "static", "loss")
+
+        def __init__(self):
+            self.calls, self.graph, self.static, self.loss = 0, None, None, None
 
     def __init__(self, model, optimizer, loss_fn=None, eager_steps: int = 2):
         if not getattr(optimizer, "_capturable", False):
@@ -59,10 +65,14 @@ class GraphedTrainStep:
         self.loss_fn = loss_fn if loss_fn is not None else torch.nn.MSELoss()
         self.eager_steps = int(eager_steps)
         self.calls = 0
-        self.graph = None
-        self.static = None              # the graph's input tensors (*inputs, target)
+        self.entries = {}
         self._seed = None
-        self._loss = None
+
+    @property
+    def graph(self):
+        """The most recently captured graph (None before the first capture)."""
+        got = [e.graph for e in self.entries.values() if e.graph is not None]
+        return got[-1] if got else None
 
     def _body(self, inputs, target):
         loss = self.loss_fn(self.model(*inputs).squeeze(), target)
@@ -70,40 +80,43 @@ class GraphedTrainStep:
         self.optimizer.step()
         return loss
 
-    def _capture(self, inputs, target):
+    def _capture(self, entry, inputs, target):
         from . import ops
-        if not self.model.training:
-            raise RuntimeError("GraphedTrainStep: the model must be in train mode when the step is captured")
-        self.static = [t.clone() for t in (*inputs, target)]
-        self._seed = torch.zeros(1, dtype=torch.int64, device=target.device)
+        entry.static = [t.clone() for t in (*inputs, target)]
+        if self._seed is None:
+            self._seed = torch.zeros(1, dtype=torch.int64, device=target.device)
         self.optimizer.zero_grad(set_to_none=True)          # the captured backward then WRITES the gradients (no accumulate kernels)
         self.optimizer.prepare_capture()
         graph = torch.cuda.CUDAGraph()
         prev = ops.set_seed_base(self._seed.data_ptr())
         try:
             with torch.cuda.graph(graph):
-                loss = self._body(self.static[:-1], self.static[-1])
+                loss = self._body(entry.static[:-1], entry.static[-1])
         finally:
             ops.set_seed_base(prev)
-        self.graph, self._loss = graph, loss.detach()
+        self.optimizer.zero_grad(set_to_none=True)          # the graph keeps its own gradient buffers; eager steps allocate theirs
+        entry.graph, entry.loss = graph, loss.detach()
 
     def __call__(self, *batch):
         *inputs, target = batch
         self.calls += 1
-        if self.graph is None:
-            if self.calls <= self.eager_steps:
+        key = (bool(self.model.training),) + tuple(tuple(t.shape) for t in batch)
+        entry = self.entries.get(key)
+        if entry is None:
+            entry = self.entries[key] = GraphedTrainStep._Entry()
+        entry.calls += 1
+        if entry.graph is None:
+            if entry.calls <= self.eager_steps:
                 self.optimizer.zero_grad(set_to_none=True)
                 return self._body(inputs, target).detach()
-            self._capture(inputs, target)
-        for s, t in zip(self.static, batch):
-            if t.shape != s.shape:
-                raise RuntimeError(f"GraphedTrainStep was captured for a batch of shape {tuple(s.shape)}, got {tuple(t.shape)}")
+            self._capture(entry, inputs, target)
+        for s, t in zip(entry.static, batch):
             if t.data_ptr() != s.data_ptr():
                 s.copy_(t, non_blocking=True)
         self._seed.add_(1)
         self.optimizer.advance()
-        self.graph.replay()
-        return self._loss
+        entry.graph.replay()
+        return entry.loss
 
 
 @torch.no_grad()
@@ -123,7 +136,7 @@ def predict(model, fingerprints: torch.Tensor, images: torch.Tensor, batch_size:
 def train_fold(model, train, test=None, *, epochs: int = 50, batch_size: int = 32, lr: float = 1e-4, weight_decay: float = 1e-5,
                faithful_mode: bool = True, shuffle: bool = True, generator: Optional[torch.Generator] = None,
                optimizer=None, batch_orders: Optional[List[np.ndarray]] = None, scheduler=None,
-               early_stopping_patience: Optional[int] = None) -> Dict[str, list]:
+               early_stopping_patience: Optional[int] = None, graph_steps: bool = False) -> Dict[str, list]:
     """Train ``model`` on ``train = (fingerprints[N,F], images[N,49152], labels[N])`` (device tensors).  Returns the per-epoch
     mean training / validation losses like the reference's ``train_losses`` / ``val_losses`` lists.  ``batch_orders``
     (one permutation per epoch) overrides the shuffling for reproducible comparisons.
@@ -145,8 +158,11 @@ def train_fold(model, train, test=None, *, epochs: int = 50, batch_size: int = 3
     if optimizer is not None:
         opt = optimizer
     else:
-        opt = AdamW(model.parameters(), lr=lr, weight_decay=weight_decay)      # (optim.AdamW(defer=...) is opt-in: measured slower on one GPU)
+        opt = AdamW(model.parameters(), lr=lr, weight_decay=weight_decay, capturable=graph_steps)      # (optim.AdamW(defer=...) is opt-in: measured slower on one GPU)
     crit = MSELoss()                      # nn.MSELoss semantics, fused value + gradient kernel
+    # graph_steps (round 4): every step replays a HIP graph captured per (batch shape, train / eval mode) -- for the variants that are per-op
+    # compositions (GraphedTrainStep); pointless for MixedInputModel, whose pass is one C call
+    stepper = GraphedTrainStep(model, opt, crit) if graph_steps else None
     N = fp.shape[0]
     if scheduler == "cosine_warm_restarts":
         scheduler = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=10, T_mult=2)
@@ -168,6 +184,10 @@ def train_fold(model, train, test=None, *, epochs: int = 50, batch_size: int = 3
         nb = 0
         for i in range(0, N, batch_size):
             idx = order[i:i + batch_size]
+            if stepper is not None:
+                total += stepper(fp[idx], img[idx], y[idx])
+                nb += 1
+                continue
             opt.zero_grad(set_to_none=True)
             pred = model(fp[idx], img[idx]).squeeze()
             loss = crit(pred, y[idx])

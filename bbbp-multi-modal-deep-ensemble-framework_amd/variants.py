@@ -234,9 +234,9 @@ class WideDeepMixedInputModel(nn.Module):
             fp_out = run_sequential(self.fingerprint_fc, x)
         img = image.float().contiguous().view(-1, 3, 128, 128)
         cnn = self.image_cnn
-        h = conv3x3_relu_pool(img, cnn[0])
-        h = conv3x3_relu_pool(h, cnn[3])
-        h = conv3x3_relu_pool(h, cnn[6])
+        h = conv3x3_relu_pool(img, cnn[0], side is not None)
+        h = conv3x3_relu_pool(h, cnn[3], side is not None)
+        h = conv3x3_relu_pool(h, cnn[6], side is not None)
         img_out = run_sequential(nn.Sequential(*list(cnn)[10:]), h.flatten(1))
         if side is not None:
             cur.wait_stream(side)

@@ -212,6 +212,11 @@ int bbbp_adamw_step_multi(void* stream, float* param, float* exp_avg, float* exp
                           float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, const float* hyper_dev);
 /* stores those eight floats (derived on the host in double, as bbbp_adamw_step derives them) to device memory in stream order */
 int bbbp_adamw_hyper_store(void* stream, float* hyper_dev, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale);
+/* The structured-sparse weight gradient of the 32->64 / 64->128 / 128->256 stages has an 8-wave form (fastest alone) and a 4-wave form (one
+ * wave per SIMD: faster when another branch's small kernels share the GPU).  bbbp_mixed_backward chooses by itself; a caller composing the
+ * model op by op with its branches on two streams sets this for the CALLING THREAD around bbbp_conv3x3_relu_pool_bwd_weight.  Returns the
+ * previous setting. */
+int bbbp_set_conv_wgrad_beside_encoder(int on);
 /* Op-level dropout streams keyed from device memory (round 4).  With a base set for the CALLING THREAD, every seeded entry point of this
  * header (dropout, softmax, layernorm, linear with output dropout, attention) uses the stream  *base * 0x9E3779B97F4A7C15 + seed  instead of
  * `seed`: a training step captured into a HIP graph draws new masks on each replay when the caller bumps the 64-bit integer at `base_dev`
@@ -319,6 +324,11 @@ int bbbp_mlp_train_epochs(void* stream, bbbp_mlp_model* models_dev, int n_models
 /* out[i] = P(class 1 | X[i]) under models_dev[model]; hidden layers up to 256 units */
 int bbbp_mlp_predict_proba(void* stream, const bbbp_mlp_model* models_dev, int model, const double* X, int n, int n_features,
                            int max_units, double* out);
+/* Phase profile of the trainer's persistent kernel: on != 0 selects an instrumented build of the kernel for later bbbp_mlp_train_epochs calls
+ * (work-group 0 adds the shader-clock cycles of each phase of every mini-batch to 16 counters) and clears them; cycles16 (host, nullable) gets
+ * the counters accumulated so far: 0-2 forward layer l, 3 loss, 4 + 2 l / 5 + 2 l delta / weight gradient + Adam of layer l, 10 mini-batch
+ * tail, 11 epoch tail, 15 mini-batches. */
+int bbbp_mlp_profile(int on, unsigned long long* cycles16);
 
 /* ---- random-forest regression inference (rf base learner of the stack, ...20250113.py:262-266, 394-403) -------------
  * scikit-learn's semantics: float32 X, go left when (double)x[feature] <= threshold, leaf value in float64, mean over

@@ -262,3 +262,19 @@ def test_graph_captured_step_draws_new_dropout_masks_on_every_replay(dev):
     x = torch.randn(64, 64, device=dev)
     assert torch.equal(ops.dropout(x, 0.5, 123), ops.dropout(x, 0.5, 123))
     assert ops._SEED_BASE == 0
+
+
+def test_train_fold_on_graph_steps_follows_the_eager_loop(dev):
+    """The published loop's shape -- train mode in epoch 1 only, a ragged last batch -- through ``train_fold(graph_steps=True)``: one graph
+    per (batch shape, mode), eager steps before each capture; dropout off, so the loss history must be the eager loop's."""
+    from bbbp_amd.training import train_fold
+    N, F, bs = 20, 64, 8
+    fp, img, y = (t.to(dev) for t in synth_inputs(31, N + 6, F, 49152))
+    train, test = (fp[:N], img[:N], y[:N]), (fp[N:], img[N:], y[N:])
+    orders = [np.random.RandomState(e).permutation(N) for e in range(5)]
+    hist = []
+    for graph in (False, True):
+        m = _wide(dev, 6, False)
+        hist.append(train_fold(m, train, test, epochs=5, batch_size=bs, lr=1e-3, batch_orders=orders, graph_steps=graph))
+    np.testing.assert_allclose(hist[1]["train_loss"], hist[0]["train_loss"], rtol=2e-4)
+    np.testing.assert_allclose(hist[1]["val_loss"], hist[0]["val_loss"], rtol=2e-4)
