@@ -124,6 +124,7 @@ _SIGNATURES = {
     "bbbp_adamw_hyper_store": (c_int, [c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float, c_int, c_float]),
     "bbbp_set_seed_base": (c_int, [c_void_p]),
     "bbbp_mlp_profile": (c_int, [c_int, c_void_p]),
+    "bbbp_mlp_profile_groups": (c_int, [c_void_p, c_int]),
     "bbbp_set_conv_wgrad_beside_encoder": (c_int, [c_int]),
     "bbbp_adamw_step_deferred": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_long, c_float, c_float, c_float, c_float, c_float, c_int, c_float]),
     "bbbp_param_sync": (c_int, [c_void_p]),

@@ -256,11 +256,14 @@ __device__ __forceinline__ double block_sum16(double v, double* red) {
 // only way to see inside one persistent launch.  Slots: 0-2 forward layer l; 3 loss; 4 + 2 l delta below layer l, 5 + 2 l weight gradient + Adam of
 // layer l; 10 mini-batch tail; 11 epoch tail; 15 mini-batches counted.
 __device__ unsigned long long g_mlp_prof[16];
+__device__ unsigned long long g_mlp_wall[3 * 1024];          // per work-group (PROF): 100 MHz wall ticks at start and end, shader cycles in between
 
 template <bool PROF>
 __global__ __launch_bounds__(MT) void mlp_train_mfma_kernel(bbbp_mlp_model* models, const double* X, const double* y, int n_features, int epochs) {
     __shared__ double red[MW];
     unsigned long long prof_last = PROF ? clock64() : 0ull;
+    const unsigned long long prof_c0 = prof_last;
+    if (PROF && threadIdx.x == 0 && blockIdx.x < 1024) g_mlp_wall[3 * blockIdx.x] = wall_clock64();
     auto mark = [&](int slot) __attribute__((always_inline)) {
         if (PROF && blockIdx.x == 0 && threadIdx.x == 0) {
             const unsigned long long now = clock64();
@@ -288,6 +291,10 @@ __global__ __launch_bounds__(MT) void mlp_train_mfma_kernel(bbbp_mlp_model* mode
         for (int b0 = 0; b0 < n; b0 += bs) {
             const int nb = min(bs, n - b0);
             const int mtiles = (nb + 15) >> 4;
+            // gradient / n_b: for a power of two (every full batch of the reference grid: 32 / 64 / 128) the product with 1 / n_b IS the
+            // quotient, bit for bit, and saves one float64 division (~12 instructions) per parameter and update
+            const bool nb_pow2 = (nb & (nb - 1)) == 0;
+            const double inv_nb = 1.0 / nb;
             // Adam's step size for this update: one lane, while the forward pass runs (read after several barriers)
             if (t == MT - 1) {
                 const double step = (double)(M.t + 1);
@@ -392,8 +399,20 @@ __global__ __launch_bounds__(MT) void mlp_train_mfma_kernel(bbbp_mlp_model* mode
 #pragma unroll
                             for (int un = 0; un < 2; ++un) acc[um][un] = f64x4{0.0, 0.0, 0.0, 0.0};
                         mfma_product<2, 2, true, true>(Aop, Bop, mt * 32, nt * 32, nb, acc);
+                        // Adam where the accumulators sit.  The loads (parameter + two moments) of eight elements are issued before
+                        // their first store: element by element, every load waited a full L2 round trip behind the previous element's stores
+                        // (the phase profile, bbbp_mlp_profile: 64 % of a mini-batch in this epilogue).
 #pragma unroll
-                        for (int um = 0; um < 2; ++um)
+                        for (int um = 0; um < 2; ++um) {             // (two batches of 24 loads: all 48 at once spill)
+                            double wv[2][4], mv[2][4], vv[2][4];
+#pragma unroll
+                            for (int un = 0; un < 2; ++un)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int k = mt * 32 + um * 16 + kq + 4 * r, j = nt * 32 + un * 16 + q;
+                                    const long i = (long)min(k, fin - 1) * fout + min(j, fout - 1);
+                                    wv[un][r] = W[i]; mv[un][r] = mW[i]; vv[un][r] = vW[i];
+                                }
 #pragma unroll
                             for (int un = 0; un < 2; ++un)
 #pragma unroll
@@ -401,22 +420,24 @@ __global__ __launch_bounds__(MT) void mlp_train_mfma_kernel(bbbp_mlp_model* mode
                                     const int k = mt * 32 + um * 16 + kq + 4 * r, j = nt * 32 + un * 16 + q;
                                     if (k < fin && j < fout) {
                                         const long i = (long)k * fout + j;
-                                        const double w = W[i];
+                                        const double w = wv[un][r];
                                         wsq += w * w;
-                                        const double g = (acc[um][un][r] + alpha * w) / nb;
-                                        const double m = beta1 * mW[i] + (1.0 - beta1) * g;
-                                        const double v = beta2 * vW[i] + (1.0 - beta2) * (g * g);
+                                        const double gs = acc[um][un][r] + alpha * w;
+                                        const double g = nb_pow2 ? gs * inv_nb : gs / nb;
+                                        const double m = beta1 * mv[un][r] + (1.0 - beta1) * g;
+                                        const double v = beta2 * vv[un][r] + (1.0 - beta2) * (g * g);
                                         mW[i] = m; vW[i] = v;
                                         W[i] = w + -lr_t * m / (sqrt(v) + adam_eps);
                                     }
                                 }
+                        }
                     }
                     // bias gradient db[j] = sum_r delta[l+1][r][j] / nb (rows in order) + Adam
                     double* bp = P + boff[l]; double* mb = Am + boff[l]; double* vb = Av + boff[l];
                     for (int j = t; j < fout; j += MT) {
                         double s = 0.0;
                         for (int r = 0; r < nb; ++r) s += dl[(long)r * fout + j];
-                        const double g = s / nb;
+                        const double g = nb_pow2 ? s * inv_nb : s / nb;
                         const double m = beta1 * mb[j] + (1.0 - beta1) * g;
                         const double v = beta2 * vb[j] + (1.0 - beta2) * (g * g);
                         mb[j] = m; vb[j] = v;
@@ -442,6 +463,10 @@ __global__ __launch_bounds__(MT) void mlp_train_mfma_kernel(bbbp_mlp_model* mode
         }
         __syncthreads();
         mark(11);
+    }
+    if (PROF && threadIdx.x == 0 && blockIdx.x < 1024) {
+        g_mlp_wall[3 * blockIdx.x + 1] = wall_clock64();
+        g_mlp_wall[3 * blockIdx.x + 2] = clock64() - prof_c0;
     }
 }
 
@@ -495,6 +520,12 @@ extern "C" int bbbp_mlp_train_epochs(void* stream, bbbp_mlp_model* models_dev, i
 
 // Phase profile of the trainer (see g_mlp_prof): on != 0 selects the instrumented kernel for later bbbp_mlp_train_epochs calls and clears the
 // counters; cycles16 (host, nullable) receives the 16 counters accumulated so far (synchronises the device).
+extern "C" int bbbp_mlp_profile_groups(unsigned long long* out, int n_groups) {
+    BBBP_CHECK_ARG(out && n_groups >= 0 && n_groups <= 1024, "mlp_profile_groups: up to 1024 work-groups");
+    if (n_groups) BBBP_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_wall), sizeof(unsigned long long) * 3 * n_groups));
+    return BBBP_OK;
+}
+
 extern "C" int bbbp_mlp_profile(int on, unsigned long long* cycles16) {
     if (cycles16) BBBP_CHECK_HIP(hipMemcpyFromSymbol(cycles16, HIP_SYMBOL(g_mlp_prof), sizeof(unsigned long long) * 16));
     if (on) {

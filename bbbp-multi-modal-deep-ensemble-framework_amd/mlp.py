@@ -166,13 +166,16 @@ class GridMLPTrainer:
         staging = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
         copy_stream = torch.cuda.Stream(device=dev)
 
-        def draw(half, live_slots):
-            """the next E epochs' visiting orders of the live fits, from each estimator's own RandomState stream, into half `half`"""
+        def draw(half, live_slots, n_epochs):
+            """the next n_epochs epochs' visiting orders of the live fits, from each estimator's own RandomState stream, into half `half`
+            (never more than a fit has left to run)"""
             buf = orders_host[half].numpy()
             for k in live_slots:
                 h = host[slot_of[k]]
                 n_train = h["n_train"]
-                for e in range(E):
+                todo = min(n_epochs, h["cfg"].max_iter - h["drawn"])
+                h["drawn"] += max(todo, 0)
+                for e in range(todo):
                     # == sample_idx = sklearn.utils.shuffle(sample_idx, random_state=rs): resample() shuffles arange(n)
                     # with the RandomState and indexes the array with it
                     perm = np.arange(n_train)
@@ -182,8 +185,13 @@ class GridMLPTrainer:
             with torch.cuda.stream(copy_stream):
                 orders_dev[half].copy_(orders_host[half], non_blocking=True)
 
+        # chunk sizes 1, 2, 4, ... E epochs: only the FIRST chunk's orders are drawn with the GPU idle (16 ms per epoch of the reference grid on
+        # the host against 45 ms on the GPU: a chunk twice as long as the one being trained is still drawn in its shadow)
         live = list(range(nm))
-        draw(0, live)
+        for h in host:
+            h["drawn"] = 0
+        chunk = 1
+        draw(0, live, chunk)
         copy_stream.synchronize()
         half = 0
         while live:
@@ -193,8 +201,9 @@ class GridMLPTrainer:
             models_dev.copy_(staging, non_blocking=False)
             torch.cuda.current_stream(dev).wait_stream(copy_stream)
             _lib.check(L.bbbp_mlp_train_epochs(ops._stream(), models_dev.data_ptr(), nm, self.X.data_ptr(), self.y.data_ptr(),
-                                               self.n_features, E), "bbbp_mlp_train_epochs")
-            draw(half ^ 1, live)                           # host work + the copy run beside the kernel (fits that finish in this chunk: wasted, harmless)
+                                               self.n_features, chunk), "bbbp_mlp_train_epochs")
+            chunk = min(E, 2 * chunk)
+            draw(half ^ 1, live, chunk)                    # host work + the copy run beside the kernel (fits that finish in this chunk: wasted, harmless)
             staging.copy_(models_dev)                      # synchronises with the kernel
             ctypes.memmove(ctypes.addressof(structs), staging.data_ptr(), nbytes)
             live = [k for k in live if not structs[k].done]

@@ -329,6 +329,9 @@ int bbbp_mlp_predict_proba(void* stream, const bbbp_mlp_model* models_dev, int m
  * the counters accumulated so far: 0-2 forward layer l, 3 loss, 4 + 2 l / 5 + 2 l delta / weight gradient + Adam of layer l, 10 mini-batch
  * tail, 11 epoch tail, 15 mini-batches. */
 int bbbp_mlp_profile(int on, unsigned long long* cycles16);
+/* ... and per work-group (= per fit, in device-array order) of the last instrumented launch: out[3 g] / out[3 g + 1] = 100 MHz wall ticks at its
+ * start / end, out[3 g + 2] = shader cycles in between (who finishes last, and at which clock) */
+int bbbp_mlp_profile_groups(unsigned long long* out, int n_groups);
 
 /* ---- random-forest regression inference (rf base learner of the stack, ...20250113.py:262-266, 394-403) -------------
  * scikit-learn's semantics: float32 X, go left when (double)x[feature] <= threshold, leaf value in float64, mean over

@@ -43,6 +43,17 @@ print(f"{len(cfgs)} fits x {epochs} epochs with the instrumented kernel: {dt * 1
 for k in range(12):
     if c[k]:
         print(f"  {names[k]:38s} {c[k] / mb:9.0f} cycles / mini-batch  {100.0 * c[k] / tot:5.1f} %")
+ng = len(cfgs)
+w = (ctypes.c_ulonglong * (3 * ng))()
+_lib.check(L.bbbp_mlp_profile_groups(ctypes.cast(w, ctypes.c_void_p), ng), "bbbp_mlp_profile_groups")
+w = np.array(list(w), dtype=np.float64).reshape(ng, 3)
+t_first = w[:, 0].min()
+start, end, cyc = (w[:, 0] - t_first) / 100.0, (w[:, 1] - t_first) / 100.0, w[:, 2]          # us
+ghz = cyc / np.maximum(end - start, 1e-9) / 1e3
+order_end = np.argsort(-end)
+print(f"work-groups: launch span {end.max() / 1e3:.1f} ms; started late (> 1 ms): {(start > 1000).sum()}; clock while running: median {np.median(ghz):.2f} GHz, min {ghz.min():.2f}, max {ghz.max():.2f}")
+print("  last to finish (slot: start ms -> end ms, GHz):", ", ".join(f"{g}: {start[g] / 1e3:.1f} -> {end[g] / 1e3:.1f}, {ghz[g]:.2f}" for g in order_end[:8]))
+print("  slot 0:", f"{start[0] / 1e3:.1f} -> {end[0] / 1e3:.1f} ms, {ghz[0]:.2f} GHz;  quartiles of end (ms):", np.round(np.percentile(end, [25, 50, 75, 100]) / 1e3, 1))
 _lib.check(L.bbbp_mlp_profile(0, None), "bbbp_mlp_profile")
 torch.cuda.synchronize(); t0 = time.perf_counter()
 trainer.fit(cfgs, epochs_per_launch=epochs)
