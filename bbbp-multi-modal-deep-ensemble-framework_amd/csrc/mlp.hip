@@ -398,21 +398,21 @@ __global__ __launch_bounds__(MT) void mlp_train_mfma_kernel(bbbp_mlp_model* mode
                         for (int um = 0; um < 2; ++um)
 #pragma unroll
                             for (int un = 0; un < 2; ++un) acc[um][un] = f64x4{0.0, 0.0, 0.0, 0.0};
-                        mfma_product<2, 2, true, true>(Aop, Bop, mt * 32, nt * 32, nb, acc);
-                        // Adam where the accumulators sit.  The loads (parameter + two moments) of eight elements are issued before
-                        // their first store: element by element, every load waited a full L2 round trip behind the previous element's stores
-                        // (the phase profile, bbbp_mlp_profile: 64 % of a mini-batch in this epilogue).
-#pragma unroll
-                        for (int um = 0; um < 2; ++um) {             // (two batches of 24 loads: all 48 at once spill)
-                            double wv[2][4], mv[2][4], vv[2][4];
+                        // Adam where the accumulators sit.  The state of this lane's 16 elements (parameter + two moments) comes in two batches
+                        // of 24 loads issued ahead of their stores -- element by element, every load waited a full round trip to the memory-side
+                        // cache behind the previous element's stores (bbbp_mlp_profile: 64 % of a mini-batch was this epilogue).
+                        double wv[2][2][4], mv[2][2][4], vv[2][2][4];
+                        auto load_state = [&](int um) __attribute__((always_inline)) {
 #pragma unroll
                             for (int un = 0; un < 2; ++un)
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     const int k = mt * 32 + um * 16 + kq + 4 * r, j = nt * 32 + un * 16 + q;
                                     const long i = (long)min(k, fin - 1) * fout + min(j, fout - 1);
-                                    wv[un][r] = W[i]; mv[un][r] = mW[i]; vv[un][r] = vW[i];
+                                    wv[um][un][r] = W[i]; mv[um][un][r] = mW[i]; vv[um][un][r] = vW[i];
                                 }
+                        };
+                        auto update = [&](int um) __attribute__((always_inline)) {
 #pragma unroll
                             for (int un = 0; un < 2; ++un)
 #pragma unroll
@@ -420,17 +420,24 @@ __global__ __launch_bounds__(MT) void mlp_train_mfma_kernel(bbbp_mlp_model* mode
                                     const int k = mt * 32 + um * 16 + kq + 4 * r, j = nt * 32 + un * 16 + q;
                                     if (k < fin && j < fout) {
                                         const long i = (long)k * fout + j;
-                                        const double w = wv[un][r];
+                                        const double w = wv[um][un][r];
                                         wsq += w * w;
                                         const double gs = acc[um][un][r] + alpha * w;
                                         const double g = nb_pow2 ? gs * inv_nb : gs / nb;
-                                        const double m = beta1 * mv[un][r] + (1.0 - beta1) * g;
-                                        const double v = beta2 * vv[un][r] + (1.0 - beta2) * (g * g);
+                                        const double m = beta1 * mv[um][un][r] + (1.0 - beta1) * g;
+                                        const double v = beta2 * vv[um][un][r] + (1.0 - beta2) * (g * g);
                                         mW[i] = m; vW[i] = v;
                                         W[i] = w + -lr_t * m / (sqrt(v) + adam_eps);
                                     }
                                 }
-                        }
+                        };
+                        // (issuing batch 0 before the product, or both batches at once, measured the same 525 k cycles per mini-batch with 38 - 60
+                        // spilled registers instead of 10: profiles/r04_mlp_phases.txt)
+                        mfma_product<2, 2, true, true>(Aop, Bop, mt * 32, nt * 32, nb, acc);
+                        load_state(0);
+                        update(0);
+                        load_state(1);
+                        update(1);
                     }
                     // bias gradient db[j] = sum_r delta[l+1][r][j] / nb (rows in order) + Adam
                     double* bp = P + boff[l]; double* mb = Am + boff[l]; double* vb = Av + boff[l];

@@ -105,7 +105,7 @@ class GridMLPTrainer:
             return []
         dev = self.device
         E = int(epochs_per_launch)
-        host = []
+        host, streams = [], {}
         for i, cfg in enumerate(configs):
             if cfg.activation not in _ACT:
                 raise ValueError(f"activation {cfg.activation!r}: the reference grid uses relu and tanh")
@@ -115,11 +115,20 @@ class GridMLPTrainer:
             rows = np.arange(self.n) if cfg.train_rows is None else np.asarray(cfg.train_rows, dtype=np.int64)
             n_train = len(rows)
             units = [self.n_features] + hidden + [1]
-            rs = np.random.RandomState(cfg.random_state)
-            p0 = self._init_params(cfg, units, rs)
+            # Fits that share (integer random_state, layer sizes, number of training rows) -- in the reference grid all folds, activations,
+            # learning rates and batch sizes of one hidden_layer_sizes value: 90 of 270 -- consume ONE and the same RandomState stream:
+            # identical initial parameters and identical shuffles.  The stream is run once per group (init: 270 -> 3 draws of up to 40 k
+            # uniforms, 68 ms -> 1 ms on the bench box; shuffles: 270 -> 3 per epoch) and every member indexes its own rows with it.
+            shared = isinstance(cfg.random_state, (int, np.integer))
+            skey = (int(cfg.random_state), tuple(units), n_train) if shared else ("own", i)
+            st = streams.get(skey)
+            if st is None:
+                rs = np.random.RandomState(cfg.random_state)
+                st = streams[skey] = dict(rs=rs, p0=self._init_params(cfg, units, rs), idx=np.arange(n_train), orders={}, made=0)
+            p0 = st["p0"]
             bs = min(int(cfg.batch_size), n_train)
             cost = -(-n_train // bs) * (len(p0) + 4000)          # mini-batches per epoch x (parameters + a per-update constant)
-            host.append(dict(cfg=cfg, rows=rows, rs=rs, idx=np.arange(n_train), units=units, p0=p0, bs=bs, n_train=n_train, cost=cost))
+            host.append(dict(cfg=cfg, rows=rows, stream=st, units=units, p0=p0, bs=bs, n_train=n_train, cost=cost))
         slot_of = np.argsort([-h["cost"] for h in host], kind="stable")      # slot k of the device array holds fit slot_of[k]
         # one device buffer for every fit's visiting orders, two halves (the chunk being trained / the chunk being drawn)
         offs, tot = [], 0
@@ -174,14 +183,27 @@ class GridMLPTrainer:
                 h = host[slot_of[k]]
                 n_train = h["n_train"]
                 todo = min(n_epochs, h["cfg"].max_iter - h["drawn"])
-                h["drawn"] += max(todo, 0)
+                st = h["stream"]
                 for e in range(todo):
-                    # == sample_idx = sklearn.utils.shuffle(sample_idx, random_state=rs): resample() shuffles arange(n)
-                    # with the RandomState and indexes the array with it
-                    perm = np.arange(n_train)
-                    h["rs"].shuffle(perm)
-                    h["idx"] = h["idx"][perm]
-                    buf[offs[k] + e * n_train: offs[k] + (e + 1) * n_train] = h["rows"][h["idx"]]
+                    ae = h["drawn"] + e                       # absolute epoch of this fit = position in its group's stream
+                    while st["made"] <= ae:
+                        # == sample_idx = sklearn.utils.shuffle(sample_idx, random_state=rs): resample() shuffles arange(n)
+                        # with the RandomState and indexes the array with it
+                        perm = np.arange(n_train)
+                        st["rs"].shuffle(perm)
+                        st["idx"] = st["idx"][perm]
+                        st["orders"][st["made"]] = st["idx"]
+                        st["made"] += 1
+                    buf[offs[k] + e * n_train: offs[k] + (e + 1) * n_train] = h["rows"][st["orders"][ae]]
+                h["drawn"] += max(todo, 0)
+            floors = {}
+            for k in live_slots:                              # drop the epochs every live member of a group has passed
+                h = host[slot_of[k]]
+                floors[id(h["stream"])] = min(floors.get(id(h["stream"]), h["drawn"]), h["drawn"])
+            for st in streams.values():
+                floor = floors.get(id(st), st["made"])
+                for ae in [a for a in st["orders"] if a < floor]:
+                    del st["orders"][ae]
             with torch.cuda.stream(copy_stream):
                 orders_dev[half].copy_(orders_host[half], non_blocking=True)
 
