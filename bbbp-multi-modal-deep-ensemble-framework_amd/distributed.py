@@ -12,6 +12,8 @@ from __future__ import annotations
 import os
 from typing import Iterable, List, Optional
 
+import threading
+
 import torch
 import torch.distributed as dist
 
@@ -95,6 +97,10 @@ def allreduce_gradients(module_or_params, average: bool = True, group=None, buck
     return n_coll
 
 
+_LIVE = {"count": 0, "graphs_before": 0}          # live OverlappedGradAllReduce objects and the graph mode the first one found
+_LIVE_LOCK = threading.Lock()
+
+
 class OverlappedGradAllReduce:
     """Gradient all-reduce for the fused engine models (``MixedInputModel`` and its concat variants) that starts before the
     backward pass has finished.
@@ -120,7 +126,13 @@ class OverlappedGradAllReduce:
         self.model, self.group, self.min_world = model, group, int(min_world)
         self.comm = None
         L = _lib.lib()
-        self._graphs_before = L.bbbp_set_graphs(0)        # restored by close(): graph replay is off only while a reducer exists
+        # graph replay is off while ANY reducer exists: the first one remembers the process's mode, the last one to close restores it
+        with _LIVE_LOCK:
+            if _LIVE["count"] == 0:
+                _LIVE["graphs_before"] = L.bbbp_set_graphs(0)
+            else:
+                L.bbbp_set_graphs(0)
+            _LIVE["count"] += 1
         self.pipelined_step = bool(pipelined_step)
         self._release_before = L.bbbp_set_release_events(1) if self.pipelined_step else None
         self._closed = False
@@ -162,7 +174,10 @@ class OverlappedGradAllReduce:
             self._closed = True
             try:
                 from . import _lib
-                _lib.lib().bbbp_set_graphs(self._graphs_before)
+                with _LIVE_LOCK:
+                    _LIVE["count"] -= 1
+                    if _LIVE["count"] == 0:
+                        _lib.lib().bbbp_set_graphs(_LIVE["graphs_before"])
                 if self._release_before is not None:
                     _lib.lib().bbbp_set_release_events(self._release_before)
             except Exception:      # noqa: BLE001  (interpreter shutdown)

@@ -80,3 +80,24 @@ def test_overlapped_reducer_schedule_tiles_the_flat_gradient_buffer():
         if layers:
             per_layer = sum(p.numel() for p in m.fingerprint_transformer.layers[0].parameters())
             assert all(hi - lo == per_layer for _, b, lo, hi in sched if b is not None and b >= 2)
+
+
+def test_graph_replay_stays_off_while_any_reducer_is_alive():
+    """closing one reducer must not switch HIP-graph replay back on under another live reducer -- the first reducer
+    remembers the process's mode, the LAST one to close restores it (host side only: bbbp_set_graphs is a flag)."""
+    import bbbp_amd
+    from bbbp_amd import _lib, distributed as D
+    L = _lib.lib()
+    before = L.bbbp_set_graphs(1)                     # pretend the process runs with replay on
+    try:
+        m = bbbp_amd.TwoBranchConcatModel(167, 128)
+        a, b = D.OverlappedGradAllReduce(m), D.OverlappedGradAllReduce(m)
+        assert L.bbbp_set_graphs(0) == 0              # off while both live (the query sets 0, which is what it already is)
+        a.close()
+        assert L.bbbp_set_graphs(0) == 0              # still off: b is alive
+        b.close()
+        assert L.bbbp_set_graphs(1) == 1              # restored by the last close
+        a.close(); b.close()                          # idempotent
+        assert D._LIVE["count"] == 0
+    finally:
+        L.bbbp_set_graphs(before)

@@ -14,6 +14,8 @@ rm -rf $O/r04_trace3
 python3 tools/step_timeline.py > $O/r04_step_timeline.txt 2>&1
 python3 tools/exp_b3db_r2.py > $O/r04_b3db_r2.log 2>&1 || tail -5 $O/r04_b3db_r2.log
 python3 tools/bench_wide_deep.py > $O/r04_wide_deep.log 2>&1
-BBBP_WIDE_OVERLAP=0 BBBP_CONV_WINOGRAD=224 python3 tools/bench_wide_deep.py >> $O/r04_wide_deep.log 2>&1
+BBBP_WIDE_GRAPH=1 python3 tools/bench_wide_deep.py >> $O/r04_wide_deep.log 2>&1
+BBBP_WIDE_GRAPH=1 BBBP_WIDE_OVERLAP=0 python3 tools/bench_wide_deep.py >> $O/r04_wide_deep.log 2>&1
+python3 tools/mlp_phases.py 4 > $O/r04_mlp_phases.log 2>&1
 for B in 32 64 128; do python3 bench.py --batch $B --no-cpu-baseline --no-isolated > $O/r04_bench_batch$B.log 2>&1 && tail -1 $O/r04_bench_batch$B.log > $O/r04_bench_batch$B.json; done
 tail -5 $O/r04_stall_outliers.txt; tail -3 $O/r04_wide_deep.log
