@@ -118,15 +118,15 @@ _SIGNATURES = {
     "bbbp_fusion_combine_fwd": (c_int, [c_void_p, _FP, _FP, _PP, _PP, _FP, _FP, c_int, c_int, c_int, c_int]),
     "bbbp_fusion_combine_bwd": (c_int, [c_void_p, _FP, _FP, _FP, _FP, _PP, _FP, _FP, _FP, c_int, c_int, c_int, c_int]),
     "bbbp_mse": (c_int, [c_void_p, _FP, _FP, _FP, _FP, c_int, c_float]),
-    "bbbp_adamw_step": (c_int, [c_void_p, _FP, _FP, _FP, _FP, c_long, c_float, c_float, c_float, c_float, c_float, c_int,
-                                c_float]),
-    "bbbp_adamw_step_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
-    "bbbp_adamw_hyper_store": (c_int, [c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float, c_int, c_float]),
+    "bbbp_adamw_step": (c_int, [c_void_p, _FP, _FP, _FP, _FP, c_long, c_double, c_double, c_double, c_double, c_double, c_int,
+                                c_double]),
+    "bbbp_adamw_step_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_int, c_double, c_double, c_double, c_double, c_double, c_int, c_double, c_void_p]),
+    "bbbp_adamw_hyper_store": (c_int, [c_void_p, c_void_p, c_double, c_double, c_double, c_double, c_double, c_int, c_double]),
     "bbbp_set_seed_base": (c_int, [c_void_p]),
     "bbbp_mlp_profile": (c_int, [c_int, c_void_p]),
     "bbbp_mlp_profile_groups": (c_int, [c_void_p, c_int]),
     "bbbp_set_conv_wgrad_beside_encoder": (c_int, [c_int]),
-    "bbbp_adamw_step_deferred": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_long, c_float, c_float, c_float, c_float, c_float, c_int, c_float]),
+    "bbbp_adamw_step_deferred": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_long, c_double, c_double, c_double, c_double, c_double, c_int, c_double]),
     "bbbp_param_sync": (c_int, [c_void_p]),
     "bbbp_param_stream": (c_void_p, []),
     "bbbp_scale": (c_int, [c_void_p, _FP, c_long, c_float]),

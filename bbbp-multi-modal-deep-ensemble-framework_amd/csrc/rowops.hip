@@ -537,24 +537,38 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* pred, const float
 // ---------------------------------------------------------------------------------------------
 // AdamW, torch.optim.AdamW arithmetic (decoupled decay, no amsgrad): one flat launch.
 // ---------------------------------------------------------------------------------------------
-// One element of the update.  Every rounding is spelled out (no contraction left to the compiler) so that all launch forms of the step --
-// flat, sliced, multi-tensor, vectorised or not -- produce the same bits for the same element.
+// One element of the update.  Every rounding is spelled out (no contraction left to the compiler), for two reasons: all launch forms of the
+// step -- flat, sliced, multi-tensor, vectorised or not -- produce the same bits for the same element, and the sequence is the one
+// torch.optim.AdamW executes on the CPU in float32 (the reference's optimizer, R:172; probed op by op against torch 2.10's single-tensor
+// path: exp_avg.lerp_ is one fused multiply-add, exp_avg_sq.mul_().addcmul_() rounds value * g, then fuses (value g) g + beta2 v,
+// addcdiv_ rounds (-step_size m), divides, adds): tests/test_gpu_round4.py holds the kernel to <= 1 ulp on < 0.1 % of the elements
+// against torch's own step.
 struct AdamHyper { float decay, omb1, beta2, omb2, step_size, bc2_sqrt, eps, gscale; };
 
 __device__ __forceinline__ void adamw_element(float& p, float g, float& m, float& v, const AdamHyper& h) {
-    const float gi = __fmul_rn(g, h.gscale);
-    const float pi = __fmul_rn(p, h.decay);
-    const float mi = __fmaf_rn(h.omb1, __fsub_rn(gi, m), m);
-    const float vi = __fmaf_rn(v, h.beta2, __fmul_rn(__fmul_rn(h.omb2, gi), gi));
-    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), h.bc2_sqrt), h.eps);
-    p = __fmaf_rn(-h.step_size, __fdiv_rn(mi, denom), pi);
+    // (HIP's __fmul_rn / __fadd_rn are plain operators the compiler may still contract: the pragma is what pins the roundings)
+#pragma clang fp contract(off)
+    const float gi = g * h.gscale;
+    const float pi = p * h.decay;                                                   // param.mul_(1 - lr * weight_decay)
+    const float mi = __builtin_fmaf(h.omb1, gi - m, m);                             // exp_avg.lerp_(grad, 1 - beta1)
+    const float t = h.omb2 * gi;
+    const float vb = v * h.beta2;
+    const float vi = __builtin_fmaf(t, gi, vb);                                     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float sq = __builtin_sqrtf(vi) / h.bc2_sqrt;
+    const float denom = sq + h.eps;                                                 // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+    const float num = -h.step_size * mi;
+    const float q = num / denom;
+    p = pi + q;                                                                     // param.addcdiv_(exp_avg, denom, value=-step_size)
     m = mi; v = vi;
 }
 
-AdamHyper adam_hyper(float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale) {
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    return AdamHyper{(float)(1.0 - (double)lr * (double)weight_decay), (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2),
-                     (float)((double)lr / bc1), (float)sqrt(bc2), eps, grad_scale};
+// The float32 constants of a step, derived in DOUBLE from double hyper-parameters exactly as torch.optim.AdamW derives its Python floats
+// (1 - lr * weight_decay, 1 - beta1, 1 - beta2, lr / (1 - beta1^t), (1 - beta2^t) ** 0.5) and rounded to float32 once, where torch's
+// kernels round them: float hyper-parameters at this boundary (rounds 1-3) put 1 - 0.999f = 0.00099998713 where torch has 0.001f.
+AdamHyper adam_hyper(double lr, double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale) {
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    return AdamHyper{(float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                     (float)(lr / bc1), (float)pow(bc2, 0.5), (float)eps, (float)grad_scale};
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, long n, AdamHyper h) {
@@ -851,7 +865,7 @@ bool bbbp_param_pending_elsewhere(const void* ptr) {
 }
 
 extern "C" int bbbp_adamw_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
-                               float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale) {
+                               double lr, double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale) {
     BBBP_CHECK_ARG(step >= 1, "adamw: step is 1-based, got %d", step);
     if (n == 0) return BBBP_OK;
     (void)bbbp_param_wait(static_cast<hipStream_t>(stream), nullptr);     // a deferred slice of an earlier step is ordered before this update
@@ -864,8 +878,8 @@ extern "C" int bbbp_adamw_step(void* stream, float* param, const float* grad, fl
 // the eight derived floats the kernels compute with (decay, 1-beta1, beta2, 1-beta2, lr / bias-correction-1, sqrt(bias-correction-2), eps,
 // gradient scale) stored to device memory in stream order (`hyper_dev` below): the values travel as kernel arguments, so the host may call
 // this again for the next step at once
-extern "C" int bbbp_adamw_hyper_store(void* stream, float* hyper_dev, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                                      float grad_scale) {
+extern "C" int bbbp_adamw_hyper_store(void* stream, float* hyper_dev, double lr, double beta1, double beta2, double eps, double weight_decay, int step,
+                                      double grad_scale) {
     BBBP_CHECK_ARG(step >= 1 && hyper_dev, "adamw_hyper_store: step is 1-based (got %d), hyper_dev must not be null", step);
     hipLaunchKernelGGL(adamw_hyper_store_kernel, dim3(1), dim3(64), 0, ST, hyper_dev, adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale));
     BBBP_CHECK_LAUNCH();
@@ -876,7 +890,7 @@ extern "C" int bbbp_adamw_hyper_store(void* stream, float* hyper_dev, float lr, 
 // by the caller, read on `stream`): long offsets[n_tensors + 1] followed by const float* grads[n_tensors].  `hyper_dev` (nullable): eight
 // floats in device memory as bbbp_adamw_hyper_store writes them -- then lr ... grad_scale are ignored and `step` is not checked.
 extern "C" int bbbp_adamw_step_multi(void* stream, float* param, float* exp_avg, float* exp_avg_sq, long n, const void* table_dev, int n_tensors,
-                                     float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                                     double lr, double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale,
                                      const float* hyper_dev) {
     BBBP_CHECK_ARG(hyper_dev || step >= 1, "adamw_multi: step is 1-based, got %d", step);
     BBBP_CHECK_ARG(n >= 0 && n_tensors >= 1, "adamw_multi: n = %ld, n_tensors = %d", n, n_tensors);
@@ -902,7 +916,7 @@ extern "C" int bbbp_scale(void* stream, float* x, long n, float s) {
 }
 
 extern "C" int bbbp_adamw_step_deferred(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, long lo, long hi,
-                                        float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale) {
+                                        double lr, double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale) {
     BBBP_CHECK_ARG(step >= 1, "adamw: step is 1-based, got %d", step);
     BBBP_CHECK_ARG(n >= 0 && lo >= 0 && lo <= hi && hi <= n, "adamw_deferred: slice [%ld, %ld) of %ld", lo, hi, n);
     BBBP_CHECK_ARG(n == 0 || (param && grad && exp_avg && exp_avg_sq), "adamw_deferred: null pointer");

@@ -191,8 +191,11 @@ int bbbp_fusion_combine_bwd(void* stream, const float* dout, const float* combin
 
 /* ---- nn.MSELoss (R:143,189) and its gradient; optim.AdamW.step (R:172,191) -------------------- */
 int bbbp_mse(void* stream, const float* pred, const float* target, float* loss, float* dpred, int n, float grad_scale);
+/* AdamW: the hyper-parameters are DOUBLES, as torch.optim.AdamW holds them (Python floats): the step's float32 constants are derived in
+ * double the way torch derives them and rounded once, and the kernel executes torch's float32 op sequence with every rounding pinned --
+ * the moments are torch's bits, the parameters torch's bits on > 99 % of the elements (tests/test_gpu_round4.py). */
 int bbbp_adamw_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
-                    float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale);
+                    double lr, double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale);
 /* The same step with the slice [lo, hi) of the flat buffers updated on a library-owned side stream (round 4).  Everything else is updated on
  * `stream`; the slice starts once the gradients are final (an event on `stream`) and runs beside whatever `stream` does next.  Readers are
  * ordered behind it by the library: bbbp_mixed_forward waits right before its first read of a tensor inside the slice (the image-FC weight:
@@ -201,7 +204,7 @@ int bbbp_adamw_step(void* stream, float* param, const float* grad, float* exp_av
  * reading parameters outside this library: state_dict(), checkpoints).  Element-wise arithmetic: the result is bit-identical to
  * bbbp_adamw_step's.  Inside a stream capture, or with an empty slice, it IS bbbp_adamw_step. */
 int bbbp_adamw_step_deferred(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, long lo, long hi,
-                             float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale);
+                             double lr, double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale);
 /* Multi-tensor form (round 4): parameters and moments are ONE flat buffer of n elements, the gradients are n_tensors separate device tensors
  * (what autograd leaves behind for a per-op model: torch.optim.AdamW's foreach path, here one launch).  `table_dev`: device memory owned by the
  * caller and read on `stream` -- long offsets[n_tensors + 1] (element offsets into the flat buffer, offsets[0] = 0, offsets[n_tensors] = n)
@@ -209,9 +212,9 @@ int bbbp_adamw_step_deferred(void* stream, float* param, const float* grad, floa
  * lr ... grad_scale are ignored -- a step captured into a HIP graph replays with whatever the caller stored there before the launch.
  * Same per-element expressions as bbbp_adamw_step: bit-identical to n_tensors single launches. */
 int bbbp_adamw_step_multi(void* stream, float* param, float* exp_avg, float* exp_avg_sq, long n, const void* table_dev, int n_tensors,
-                          float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, const float* hyper_dev);
+                          double lr, double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale, const float* hyper_dev);
 /* stores those eight floats (derived on the host in double, as bbbp_adamw_step derives them) to device memory in stream order */
-int bbbp_adamw_hyper_store(void* stream, float* hyper_dev, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale);
+int bbbp_adamw_hyper_store(void* stream, float* hyper_dev, double lr, double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale);
 /* The structured-sparse weight gradient of the 32->64 / 64->128 / 128->256 stages has an 8-wave form (fastest alone) and a 4-wave form (one
  * wave per SIMD: faster when another branch's small kernels share the GPU).  bbbp_mixed_backward chooses by itself; a caller composing the
  * model op by op with its branches on two streams sets this for the CALLING THREAD around bbbp_conv3x3_relu_pool_bwd_weight.  Returns the

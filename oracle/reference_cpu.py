@@ -322,10 +322,12 @@ def adamw_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor,
                weight_decay: float = 1e-5) -> None:
     """In-place single-tensor AdamW step, ``step`` is the 1-based step count.
     p *= 1 - lr*wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
-    p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)."""
+    p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).
+    The op sequence is torch.optim.adamw._single_tensor_adamw's (torch 2.x: the first moment is a lerp_), so that in float32 the
+    roundings are torch's own -- tests/test_oracle_golden.py holds it bit for bit against torch.optim.AdamW."""
     b1, b2 = betas
     param.mul_(1 - lr * weight_decay)
-    exp_avg.mul_(b1).add_(grad, alpha=1 - b1)
+    exp_avg.lerp_(grad, 1 - b1)
     exp_avg_sq.mul_(b2).addcmul_(grad, grad, value=1 - b2)
     bc1 = 1 - b1 ** step
     bc2 = 1 - b2 ** step

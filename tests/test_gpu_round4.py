@@ -278,3 +278,66 @@ def test_train_fold_on_graph_steps_follows_the_eager_loop(dev):
         hist.append(train_fold(m, train, test, epochs=5, batch_size=bs, lr=1e-3, batch_orders=orders, graph_steps=graph))
     np.testing.assert_allclose(hist[1]["train_loss"], hist[0]["train_loss"], rtol=2e-4)
     np.testing.assert_allclose(hist[1]["val_loss"], hist[0]["val_loss"], rtol=2e-4)
+
+
+@pytest.mark.parametrize("name,F,I", [("DenseMLPModel", 167, 768), ("PCAFusionModel", 64, 128)])
+def test_graph_captured_step_of_the_mlp_variants(dev, name, F, I):
+    """The dense and the PCA-fusion variants (BatchNorm running statistics, several dropout sites) through GraphedTrainStep against the
+    eager loop, dropout off: same losses, same parameters, same running statistics after six steps."""
+    from bbbp_amd import variants
+    from bbbp_amd.training import GraphedTrainStep
+    B = 16
+    fp, img, y = (t.to(dev) for t in synth_inputs(41, 2 * B, F, I))
+    models, opts = [], []
+    for capt in (True, False):
+        torch.manual_seed(7)
+        m = getattr(variants, name)(F, I).to(dev).train()
+        _no_dropout(m)
+        models.append(m); opts.append(AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5, capturable=capt))
+    graphed = GraphedTrainStep(models[0], opts[0], eager_steps=2)
+    for i in range(6):
+        s = (i % 2) * B
+        la = float(graphed(fp[s:s + B], img[s:s + B], y[s:s + B]))
+        loss = torch.nn.MSELoss()(models[1](fp[s:s + B], img[s:s + B]).squeeze(), y[s:s + B])
+        loss.backward(); opts[1].step(); opts[1].zero_grad(set_to_none=True)
+        assert abs(la - float(loss)) <= 1e-5 * max(1.0, abs(float(loss))), (i, la, float(loss))
+    assert graphed.graph is not None
+    for (k, a), (_, b) in zip(models[0].state_dict().items(), models[1].state_dict().items()):
+        if a.dtype.is_floating_point:
+            assert float((a - b).abs().max()) <= 1e-6 + 1e-5 * float(b.abs().max()), k
+        else:
+            assert torch.equal(a, b), k
+
+
+def test_adamw_kernel_follows_torch_optim_adamw_to_the_ulp(dev):
+    """The reference's optimizer IS torch.optim.AdamW (R:172).  Same parameters, same gradients (magnitudes over eight decades), three
+    steps with a changing learning rate: torch's float32 CPU step against the HIP kernel -- the kernel spells out torch's own sequence
+    of roundings, so the moments are torch's bits and the parameters are torch's bits on > 99 % of the elements, a few units in the last place of
+    the update's operands elsewhere."""
+    n = 200_000
+    g = torch.Generator().manual_seed(12)
+    p0 = torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    ropt = torch.optim.AdamW([ref], lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, foreach=False)
+    mine = torch.nn.Parameter(p0.clone().to(dev))
+    opt = AdamW([mine], lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    prev = p0.clone()
+    for step in range(3):
+        grad = torch.randn(n, generator=g) * 10.0 ** torch.randint(-6, 2, (n,), generator=g).float()
+        for o in (ropt, opt):
+            o.param_groups[0]["lr"] = 3e-3 / (1 + step)
+        ref.grad, mine.grad = grad.clone(), grad.clone().to(dev)
+        ropt.step(); opt.step()
+        a, b = mine.detach().cpu(), ref.detach()
+        # one unit in the last place AT THE SCALE OF THE OPERANDS of the final addition (p * decay + update: where the two cancel, one
+        # ulp of an operand is many ulps of the small result)
+        scale = torch.maximum(prev.abs(), b.abs())
+        err = (a - b).abs() / (scale * 2.0 ** -23 + 1e-45)
+        # torch's own bits depend on the host's vector ISA (tools/adamw_ulp_probe.py: its AVX2 addcdiv kernel agrees with this sequence on
+        # all but 1e-4 of the elements, its AVX-512 kernel on all but 2.4e-3, each time by one unit in the last place of an operand)
+        assert float(err.max()) <= 4.0 * (1 + step), (step, float(err.max()))
+        assert float((a != b).float().mean()) < 1e-2 * (1 + step), (step, float((a != b).float().mean()))
+        prev = b.clone()
+        st = ropt.state[ref]
+        assert torch.equal(opt.state[mine]["exp_avg"].cpu(), st["exp_avg"]), step         # the moments depend on the gradients only
+        assert torch.equal(opt.state[mine]["exp_avg_sq"].cpu(), st["exp_avg_sq"]), step

@@ -403,3 +403,22 @@ def test_opt_more_golden():
     for k, v in st.items():
         if "running" in k:
             assert_close(v.numpy(), g[f"train/B6/bn/{k}"], rtol=1e-5, what=k)
+
+
+def test_oracle_adamw_is_torch_optim_adamw_bit_for_bit():
+    """The reference's optimizer is torch.optim.AdamW (...20250113.py:172); the oracle's single-tensor restatement runs the same tensor
+    ops in the same order, so in float32 it must produce torch's bits (the HIP kernel is held to <= 1 ulp of the same thing in
+    tests/test_gpu_round4.py)."""
+    n = 50_000
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    ropt = torch.optim.AdamW([ref], lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, foreach=False)
+    p, m, v = p0.clone(), torch.zeros(n), torch.zeros(n)
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g) * 10.0 ** torch.randint(-6, 2, (n,), generator=g).float()
+        ref.grad = grad.clone()
+        ropt.step()
+        oracle.adamw_step(p, grad, m, v, step, lr=3e-3, weight_decay=1e-2)
+        assert torch.equal(p, ref.detach()), step
+        assert torch.equal(m, ropt.state[ref]["exp_avg"]) and torch.equal(v, ropt.state[ref]["exp_avg_sq"]), step
