@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* pred, const float
 // path: exp_avg.lerp_ is one fused multiply-add, exp_avg_sq.mul_().addcmul_() rounds value * g, then fuses (value g) g + beta2 v,
 // addcdiv_ rounds (-step_size m), divides, adds): tests/test_gpu_round4.py holds the kernel to <= 1 ulp on < 0.1 % of the elements
 // against torch's own step.
-struct AdamHyper { float decay, omb1, beta2, omb2, step_size, bc2_sqrt, eps, gscale; };
+struct AdamHyper { float decay, omb1, beta2, omb2, step_size, bc2_sqrt, eps, gscale; int low_prio; };
 
 __device__ __forceinline__ void adamw_element(float& p, float g, float& m, float& v, const AdamHyper& h) {
     // (HIP's __fmul_rn / __fadd_rn are plain operators the compiler may still contract: the pragma is what pins the roundings)
@@ -562,17 +562,24 @@ __device__ __forceinline__ void adamw_element(float& p, float g, float& m, float
     m = mi; v = vi;
 }
 
+// BBBP_ADAMW_BACKGROUND=n (experiment, default 0 = off): launches of the step use at most n work-groups and no raised wave priority -- an
+// update that runs BESIDE compute (the optimizer pipelined into the backward pass) should trickle through HBM, not evict the GEMMs.
+int adamw_background() {
+    static const int v = [] { const char* e = getenv("BBBP_ADAMW_BACKGROUND"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 // The float32 constants of a step, derived in DOUBLE from double hyper-parameters exactly as torch.optim.AdamW derives its Python floats
 // (1 - lr * weight_decay, 1 - beta1, 1 - beta2, lr / (1 - beta1^t), (1 - beta2^t) ** 0.5) and rounded to float32 once, where torch's
 // kernels round them: float hyper-parameters at this boundary (rounds 1-3) put 1 - 0.999f = 0.00099998713 where torch has 0.001f.
 AdamHyper adam_hyper(double lr, double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale) {
     const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
     return AdamHyper{(float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
-                     (float)(lr / bc1), (float)pow(bc2, 0.5), (float)eps, (float)grad_scale};
+                     (float)(lr / bc1), (float)pow(bc2, 0.5), (float)eps, (float)grad_scale, adamw_background() > 0 ? 1 : 0};
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, long n, AdamHyper h) {
-    BBBP_HIGH_PRIO();
+    if (!h.low_prio) BBBP_HIGH_PRIO();
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         float pi = p[i], mi = m[i], vi = v[i];
         adamw_element(pi, g[i], mi, vi, h);
@@ -627,9 +634,9 @@ __global__ __launch_bounds__(256) void scale_kernel(float* x, long n, float s) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] *= s;
 }
 
-inline int grid_for(long n) {
+inline int grid_for(long n, int background = 0) {
     long g = (n + 255) / 256;
-    long cap = (long)bbbp_num_cus() * 8;
+    long cap = background > 0 ? background : (long)bbbp_num_cus() * 8;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
@@ -869,7 +876,7 @@ extern "C" int bbbp_adamw_step(void* stream, float* param, const float* grad, fl
     BBBP_CHECK_ARG(step >= 1, "adamw: step is 1-based, got %d", step);
     if (n == 0) return BBBP_OK;
     (void)bbbp_param_wait(static_cast<hipStream_t>(stream), nullptr);     // a deferred slice of an earlier step is ordered before this update
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), g_bbbp_small_lds_pad, ST, param, grad, exp_avg, exp_avg_sq, n,
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, adamw_background())), dim3(256), g_bbbp_small_lds_pad, ST, param, grad, exp_avg, exp_avg_sq, n,
                        adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale));
     BBBP_CHECK_LAUNCH();
     return BBBP_OK;
