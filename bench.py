@@ -253,7 +253,7 @@ def comm_report(world, dev, dist, collectives_per_step):
 
 
 def comm_diagnostics(dist, rank, world, fence, step_overlapped, step_no_collective, allreduce_only, set_comm_cus, grad_bytes,
-                     candidates=(0, 8), steps=5, warmup=2, reduce_device=None):
+                     candidates=(0, 8), steps=5, warmup=2, reduce_device=None, step_plain=None, set_schedule=None):
     """The self-diagnosing part of an N-rank line: an UNTIMED pass every rank takes, before the timed region,
     that prices the communication of one training step:
       step_no_collective_ms   the step with its gradient collectives skipped (what the GPU needs by itself),
@@ -262,7 +262,11 @@ def comm_diagnostics(dist, rank, world, fence, step_overlapped, step_no_collecti
       overlapped_ms[c]        the step with the overlapped bucket schedule while c CUs are kept out of every persistent grid
                               (bbbp_set_comm_cus: room for the collective library's kernels beside the conv work-groups),
       comm_cus_chosen         the candidate with the smallest overlapped step (rank 0 decides, broadcast; left set for the timed region),
-      exposed_ms              overlapped_ms[chosen] - step_no_collective_ms: the communication the backward pass does NOT hide.
+      plain_step_ms           (with ``step_plain``) the step with ONE all-reduce of the whole buffer after the backward pass instead of
+                              the overlapped buckets; schedule_chosen = "overlapped" or "plain", whichever was faster -- left selected
+                              for the timed region through ``set_schedule`` (a fabric on which many small collectives cost more than
+                              the overlap hides must not sink the one N-rank run there is),
+      exposed_ms              (chosen schedule's step) - step_no_collective_ms: the communication the backward pass does NOT hide.
     Every time is the MAX over ranks of a (fence, `steps` calls, fence) host interval.  All callables take the step index."""
     import torch as _torch
 
@@ -283,13 +287,23 @@ def comm_diagnostics(dist, rank, world, fence, step_overlapped, step_no_collecti
     for c in candidates:
         set_comm_cus(c)
         per[c] = timed(step_overlapped)
-    pick = [min(per, key=per.get)]
+    plain_ms = None
+    if step_plain is not None:
+        set_comm_cus(0)
+        plain_ms = timed(step_plain)
+    best_c = min(per, key=per.get)
+    pick = [best_c, "plain" if (plain_ms is not None and plain_ms < per[best_c]) else "overlapped"]
     dist.broadcast_object_list(pick, src=0)
-    chosen = int(pick[0])
-    set_comm_cus(chosen)
+    chosen, schedule = int(pick[0]), str(pick[1])
+    set_comm_cus(chosen if schedule == "overlapped" else 0)
+    if set_schedule is not None:
+        set_schedule(schedule)
+    best_ms = per[chosen] if schedule == "overlapped" else plain_ms
     secs = out["plain_allreduce_ms"] * 1e-3
-    out.update(overlapped_ms={str(c): round(v, 4) for c, v in per.items()}, comm_cus_chosen=chosen,
-               exposed_ms=round(per[chosen] - out["step_no_collective_ms"], 4), bytes=int(grad_bytes),
+    if plain_ms is not None:
+        out.update(plain_step_ms=round(plain_ms, 4), schedule_chosen=schedule)
+    out.update(overlapped_ms={str(c): round(v, 4) for c, v in per.items()}, comm_cus_chosen=chosen if schedule == "overlapped" else 0,
+               exposed_ms=round(best_ms - out["step_no_collective_ms"], 4), bytes=int(grad_bytes),
                algbw_GBps=round(grad_bytes / secs / 1e9, 2) if secs > 0 else None,
                busbw_GBps=round(grad_bytes / secs / 1e9 * 2 * (world - 1) / world, 2) if secs > 0 else None,
                steps_per_measurement=steps, note="untimed diagnostic pass before the timed region; MAX over ranks of host intervals between fences")
@@ -358,6 +372,7 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
         reducer = D.OverlappedGradAllReduce(model, pipelined_step=pipelined)
     pipelined = pipelined and reducer is not None
 
+    schedule = ["overlapped"]             # N > 1: "overlapped" buckets or one "plain" all-reduce after the pass (the diagnostic pass decides)
     opt_events = []                       # (start, end) around the optimizer step, only while `time_opt` is set (untimed pass)
     time_opt = [False]
     n_coll = [0]                          # collectives the last step issued (N > 1)
@@ -392,7 +407,7 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
             return loss
         if world > 1 and collective:
             # the 1/world of the mean is folded into AdamW (grad_scale)
-            if reducer is not None:
+            if reducer is not None and schedule[0] == "overlapped" and collective != "plain":
                 n_coll[0] = reducer(params, average=False)
             else:
                 n_coll[0] = D.allreduce_gradients(params, average=False)
@@ -420,7 +435,9 @@ def bench_model(args, cfg_id, rank, world, dev, dist):
         comm_diag = comm_diagnostics(dist, rank, world, fence, lambda i: step(i), lambda i: step(i, collective=False),
                                      allreduce_only, L.bbbp_set_comm_cus,
                                      sum(q.numel() for q in params) * 4, reduce_device=dev,
-                                     candidates=tuple(int(v) for v in os.environ.get("BBBP_BENCH_COMM_CUS", "0,8").split(",")))
+                                     candidates=tuple(int(v) for v in os.environ.get("BBBP_BENCH_COMM_CUS", "0,8").split(",")),
+                                     step_plain=(lambda i: step(i, collective="plain")) if reducer is not None else None,
+                                     set_schedule=lambda name: schedule.__setitem__(0, name))
         opt.zero_grad(set_to_none=True)
     nsec = L.bbbp_profile_num_sections()
     names = [L.bbbp_profile_section_name(i).decode() for i in range(nsec)]

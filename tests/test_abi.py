@@ -101,3 +101,31 @@ def test_graph_replay_stays_off_while_any_reducer_is_alive():
         assert D._LIVE["count"] == 0
     finally:
         L.bbbp_set_graphs(before)
+
+
+def test_round4_entry_points_validate_their_arguments_before_touching_the_gpu():
+    """Argument errors are reported as BBBP_ERR_ARG with a message, before any HIP call (so: testable without a GPU)."""
+    import ctypes
+    from bbbp_amd import _lib
+    L = _lib.lib()
+    ERR_ARG = 1
+    fake = ctypes.c_void_p(4096)                         # never dereferenced: validation comes first
+    # multi-tensor AdamW: tensor count, null pointers, alignment of the flat buffers, 1-based step
+    assert L.bbbp_adamw_step_multi(None, fake, fake, fake, 16, fake, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None) == ERR_ARG
+    assert b"n_tensors" in L.bbbp_last_error()
+    assert L.bbbp_adamw_step_multi(None, fake, fake, fake, 16, None, 2, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None) == ERR_ARG
+    assert L.bbbp_adamw_step_multi(None, ctypes.c_void_p(4100), fake, fake, 16, fake, 2, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None) == ERR_ARG
+    assert b"aligned" in L.bbbp_last_error()
+    assert L.bbbp_adamw_step_multi(None, fake, fake, fake, 16, fake, 2, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, 1.0, None) == ERR_ARG
+    assert L.bbbp_adamw_step_multi(None, fake, fake, fake, 0, None, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None) == 0          # empty: nothing to do
+    assert L.bbbp_adamw_hyper_store(None, None, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0) == ERR_ARG
+    assert L.bbbp_adamw_step(None, fake, fake, fake, fake, 16, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, 1.0) == ERR_ARG
+    assert L.bbbp_adamw_step_deferred(None, fake, fake, fake, fake, 16, 8, 4, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0) == ERR_ARG   # lo > hi
+    # per-thread setters are plain flags
+    assert L.bbbp_set_seed_base(None) == 0
+    prev = L.bbbp_set_conv_wgrad_beside_encoder(1)
+    assert L.bbbp_set_conv_wgrad_beside_encoder(prev) == 1
+    # MLP profile: group count bound
+    buf = (ctypes.c_ulonglong * 3)()
+    assert L.bbbp_mlp_profile_groups(ctypes.cast(buf, ctypes.c_void_p), 5000) == ERR_ARG
+    assert L.bbbp_mlp_profile_groups(None, 1) == ERR_ARG

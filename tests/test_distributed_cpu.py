@@ -193,9 +193,19 @@ def _comm_diag_worker(rank, world, port):
 
     out = bench.comm_diagnostics(dist, rank, world, dist.barrier, overlapped, no_coll, lambda i: dist.all_reduce(grads.clone()), set_cus,
                                  grads.numel() * 4, candidates=(0, 8), steps=3, warmup=1)
+    # the same pass with a plain-schedule candidate that beats both overlapped ones: the schedule switches, the CUs go back to 0
+    state2 = {"cus": -1, "calls": [], "schedule": None}
+
+    def set_cus2(c):
+        state2["cus"] = c; state2["calls"].append(c)
+        return 0
+
+    out2 = bench.comm_diagnostics(dist, rank, world, dist.barrier, overlapped, no_coll, lambda i: dist.all_reduce(grads.clone()), set_cus2,
+                                  grads.numel() * 4, candidates=(0, 8), steps=3, warmup=1,
+                                  step_plain=lambda i: time.sleep(0.006), set_schedule=lambda name: state2.__setitem__("schedule", name))
     dist.barrier()
     dist.destroy_process_group()
-    return rank, out, state
+    return rank, out, state, out2, state2
 
 
 def test_bench_comm_diagnostics_fields_and_rank0_choice_on_gloo_world2():
@@ -204,7 +214,7 @@ def test_bench_comm_diagnostics_fields_and_rank0_choice_on_gloo_world2():
     by rank 0 and left set on EVERY rank, exposed = overlapped[chosen] - step without collectives."""
     from helpers import run_ranks
     res = sorted(run_ranks(_comm_diag_worker, 2, timeout=180), key=lambda r: r[0])
-    (_, a, sa), (_, b, sb) = res
+    (_, a, sa, a2, sa2), (_, b, sb, b2, sb2) = res
     for k in ("exposed_ms", "step_no_collective_ms", "plain_allreduce_ms", "comm_cus_chosen", "bytes", "algbw_GBps", "busbw_GBps", "overlapped_ms"):
         assert k in a and k in b, k
     assert a == b                                        # MAX over ranks + rank 0's broadcast choice: the same object everywhere
@@ -213,3 +223,8 @@ def test_bench_comm_diagnostics_fields_and_rank0_choice_on_gloo_world2():
     assert a["overlapped_ms"]["0"] > a["overlapped_ms"]["8"] > a["step_no_collective_ms"] >= 3.9
     assert abs(a["exposed_ms"] - (a["overlapped_ms"]["8"] - a["step_no_collective_ms"])) < 1e-3
     assert 9.0 <= a["exposed_ms"] <= 20.0                # rank 1 sleeps 10 ms more than the collective-free step
+    assert "schedule_chosen" not in a                    # no plain candidate offered: the overlapped schedule is not in question
+    # with a plain-schedule candidate (6 ms) that beats the best overlapped one (14 ms): chosen everywhere, reserved CUs back to 0
+    assert a2 == b2 and a2["schedule_chosen"] == "plain" and a2["comm_cus_chosen"] == 0 and 5.9 <= a2["plain_step_ms"] <= 12.0
+    assert sa2["schedule"] == sb2["schedule"] == "plain" and sa2["cus"] == sb2["cus"] == 0
+    assert abs(a2["exposed_ms"] - (a2["plain_step_ms"] - a2["step_no_collective_ms"])) < 1e-3
