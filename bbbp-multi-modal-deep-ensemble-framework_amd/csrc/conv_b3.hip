@@ -129,6 +129,15 @@ __device__ __forceinline__ void conv_b3_body(const B3Params& p) {
     // instead of 0.37, and the STEP gets slower: 2.453-2.474 -> 2.487-2.496 ms (profiles/r04_dgrad_registers.txt).  Time-slicing this one
     // kernel against the chain beats co-running them; the stall is the better schedule, so the twelve registers stay.
     constexpr bool RECOMPUTE = false;
+    // EARLY_LOADS (round 4; the schedule of the MFMA block below): the data gradient's kernel gains 9 % alone (0.39 -> 0.355 ms at B = 512; its
+    // 48 loads per stage -- gradients + mask bytes -- were the longest issue phase), the forward kernel LOSES 4 % at B = 4096 (3.15 -> 3.29 ms:
+    // 24 loads, and 52 more live registers through its two unrolled chunk copies) -- measured A/B on one box, profiles/r04_conv2_early_loads.txt.
+    // -DB3_EARLY_LOADS=0 / 1 forces it off / on for both.
+#ifdef B3_EARLY_LOADS
+    constexpr bool EARLY_LOADS = B3_EARLY_LOADS != 0;
+#else
+    constexpr bool EARLY_LOADS = MODE == B3_DGRAD;
+#endif
     int goff[NIT], loff[NIT], irow[NIT], ipar[NIT];
     auto item = [&](int tt, int i, int& g, int& l, int& rw, int& pr) __attribute__((always_inline)) {
         const int idx = RAGGED ? min(tt + i * 256, ITEMS - 1) : tt + i * 256;        // (clamped: a ragged item loads valid memory and is never stored)
@@ -146,32 +155,42 @@ __device__ __forceinline__ void conv_b3_body(const B3Params& p) {
     uint32_t mr[NIT][2];                                     // DGRAD: the eight mask bytes of an item
     u32x4 wr[WIT];
     uint32_t okbits = 0;
-    auto load_stage = [&](int strip, int chunk) __attribute__((always_inline)) {
-        const int b = strip / (IMG / R), h0 = (strip % (IMG / R)) * R;
-        const char* xb = reinterpret_cast<const char*>(p.x + ((long)b * KIN + chunk * CH) * SRC_PLANE);
-        const uint8_t* mbp = MODE == B3_DGRAD ? p.xmask + ((long)b * KIN + chunk * CH) * SRC_PLANE : nullptr;
+    // a stage's loads come in NIT + 1 pieces -- item i of every thread (8 dword loads; DGRAD: + 8 mask bytes), then the filter stage --
+    // so that the MFMA block can place one piece per tap (below)
+    const char* ld_xb = nullptr; const uint8_t* ld_mb = nullptr; int ld_h0 = 0; const u32x4* ld_w = nullptr;
+    auto load_begin = [&](int strip, int chunk) __attribute__((always_inline)) {
+        const int b = strip / (IMG / R);
+        ld_h0 = (strip % (IMG / R)) * R;
+        ld_xb = reinterpret_cast<const char*>(p.x + ((long)b * KIN + chunk * CH) * SRC_PLANE);
+        ld_mb = MODE == B3_DGRAD ? p.xmask + ((long)b * KIN + chunk * CH) * SRC_PLANE : nullptr;
+        ld_w = reinterpret_cast<const u32x4*>(p.wp + (size_t)(mb * NCHUNK + chunk) * WSTAGE);
         okbits = 0;
-        const int tl = RECOMPUTE ? opaque_t() : t;
+    };
+    auto load_item = [&](int i) __attribute__((always_inline)) {
+        int gi = 0, li = 0, ri = 0, pi = 0;
+        if (RECOMPUTE) item(opaque_t(), i, gi, li, ri, pi); else { gi = goff[i]; ri = irow[i]; }
+        const int yr = ld_h0 - 1 + ri;
+        const int yy = min(max(yr, 0), IMG - 1);
+        okbits |= (yr >= 0 && yr < IMG ? 1u : 0u) << i;
+        const unsigned o = gi + (MODE == B3_FWD ? yy * IMG : (yy >> 1) * (IMG / 2));
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            int gi = 0, li = 0, ri = 0, pi = 0;
-            if (RECOMPUTE) item(tl, i, gi, li, ri, pi); else { gi = goff[i]; ri = irow[i]; }
-            const int yr = h0 - 1 + ri;
-            const int yy = min(max(yr, 0), IMG - 1);
-            okbits |= (yr >= 0 && yr < IMG ? 1u : 0u) << i;
-            const unsigned o = gi + (MODE == B3_FWD ? yy * IMG : (yy >> 1) * (IMG / 2));
+        for (int j = 0; j < 8; ++j) xr[i][j] = *reinterpret_cast<const float*>(ld_xb + (size_t)(4u * (o + j * SRC_PLANE)));
+        if (MODE == B3_DGRAD) {
+            uint32_t m0 = 0, m1 = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xr[i][j] = *reinterpret_cast<const float*>(xb + (size_t)(4u * (o + j * SRC_PLANE)));
-            if (MODE == B3_DGRAD) {
-                uint32_t m0 = 0, m1 = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { m0 |= (uint32_t)mbp[o + j * SRC_PLANE] << (8 * j); m1 |= (uint32_t)mbp[o + (j + 4) * SRC_PLANE] << (8 * j); }
-                mr[i][0] = m0; mr[i][1] = m1;
-            }
+            for (int j = 0; j < 4; ++j) { m0 |= (uint32_t)ld_mb[o + j * SRC_PLANE] << (8 * j); m1 |= (uint32_t)ld_mb[o + (j + 4) * SRC_PLANE] << (8 * j); }
+            mr[i][0] = m0; mr[i][1] = m1;
         }
-        const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.wp + (size_t)(mb * NCHUNK + chunk) * WSTAGE);
+    };
+    auto load_filters = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < WIT; ++i) wr[i] = wsrc[min(t + i * 256, WPIECES - 1)];
+        for (int i = 0; i < WIT; ++i) wr[i] = ld_w[min(t + i * 256, WPIECES - 1)];
+    };
+    auto load_stage = [&](int strip, int chunk) __attribute__((always_inline)) {
+        load_begin(strip, chunk);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) load_item(i);
+        load_filters();
     };
     auto store_stage = [&](int strip) __attribute__((always_inline)) {
         const int h0 = (strip % (IMG / R)) * R;
@@ -235,7 +254,14 @@ __device__ __forceinline__ void conv_b3_body(const B3Params& p) {
             // the next stage's global loads are in flight under this stage's MFMAs; its split and LDS writes follow the block.
             // ONE LDS image per work-group (66 KB): two work-groups share a CU, and while one splits and stores the other
             // one's waves keep the matrix pipe busy (a bf16 MFMA holds the vector issue for only 8 of its 32 cycles)
-            if (have_next) load_stage(nstrip, nchunk);
+            // Round 4: the next stage's loads are issued UNCONDITIONALLY (the last stage of a work-group re-reads its own strip and never
+            // stores it) and piece by piece INSIDE the MFMA block: item i in tap i, the filter stage in tap FTAP -- each tap is one
+            // scheduling region (sched_barrier) whose pattern puts the loads into the MFMA gaps.  Left to itself the compiler placed all
+            // of them behind the 89th of 108 MFMAs (chunk 0: their latency then lay open in front of the split) or in a block of their
+            // own before the MFMAs (chunk 1: ~30 issue slots nothing overlapped).
+            constexpr int FTAP = 6;
+            if (EARLY_LOADS) load_begin(have_next ? nstrip : strip, have_next ? nchunk : chunk);
+            else if (have_next) load_stage(nstrip, nchunk);
             mark(0);
             // fragments of tap t + 1 are fetched while the MFMAs of tap t run
             bf16x8 a[2][3], bq[2][2][3];
@@ -250,10 +276,13 @@ __device__ __forceinline__ void conv_b3_body(const B3Params& p) {
                         bq[slot][nt][pl] = *reinterpret_cast<const bf16x8*>(xs + pl * XPLANE + ((y0 + nt + dy + 1) * PXW + (cb + r + dx + 1)) * CH);
             };
             fetch(0, 0);
+            if (EARLY_LOADS) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int sl = tap & 1;
                 if (tap + 1 < 9) fetch(tap + 1, sl ^ 1);
+                if (EARLY_LOADS && tap < NIT) load_item(tap);
+                if (EARLY_LOADS && tap == FTAP) load_filters();
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     // small terms first, the leading product last
@@ -264,17 +293,25 @@ __device__ __forceinline__ void conv_b3_body(const B3Params& p) {
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sl][0], bq[sl][nt][1], acc[nt], 0, 0, 0);
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sl][0], bq[sl][nt][0], acc[nt], 0, 0, 0);
                 }
-                // issue order of this tap: one LDS read of the next tap's fragments in each of the first nine MFMA gaps
+                // issue order of this tap: one LDS read of the next tap's fragments in each of the first nine MFMA gaps, and this tap's
+                // piece of the next stage's loads (VPG per gap, behind the vector adds of their offsets)
+                constexpr int VPG = MODE == B3_DGRAD ? 2 : 1;
+                const bool piece = EARLY_LOADS && (tap < NIT || tap == FTAP);
                 if (tap + 1 < 9) {
 #pragma unroll
                     for (int k = 0; k < 9; ++k) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        if (piece) {
+                            __builtin_amdgcn_sched_group_barrier(0x002, 2 * VPG, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x020, VPG, 0);
+                        }
                     }
                     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
                 } else {
                     __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
                 }
+                if (EARLY_LOADS) __builtin_amdgcn_sched_barrier(0);
             }
             mark(1);
             __syncthreads();                                 // every wave is done reading this stage
@@ -325,8 +362,12 @@ __device__ __forceinline__ void conv_b3_body(const B3Params& p) {
     if (blockIdx.x == 0 && t == 0) { g_b3_clock[0] = __builtin_readcyclecounter() - clk_begin; g_b3_clock[1] = wall_clock64() - wall_begin; }
 }
 
+// The data gradient (loads inside its MFMA block: more live registers) is held to two waves per SIMD = two work-groups per CU by the launch
+// bound (232 registers; unbounded the compiler took 314 and halved the occupancy).  The forward kernel keeps NO bound: it settles at
+// 187 + 32, which leaves every SIMD the 64 registers of one encoder-chain wave beside two of its own -- under the bound it grew to 254 and
+// shut the chain out for the whole forward conv (the chain is the forward half's critical path).
 template <int MODE, class G = GeomFlagship>
-__global__ __launch_bounds__(256) void conv_b3_kernel(B3Params p) { conv_b3_body<MODE, false, G>(p); }
+__global__ __launch_bounds__(256, (MODE == B3_DGRAD ? 2 : 1)) void conv_b3_kernel(B3Params p) { conv_b3_body<MODE, false, G>(p); }
 template <int MODE>
 __global__ __launch_bounds__(256) void conv_b3_probe_kernel(B3Params p) { conv_b3_body<MODE, true, GeomFlagship>(p); }
 
