@@ -97,3 +97,23 @@ def test_mlp_errors(dev):
     with pytest.raises(ValueError):
         GridMLPTrainer(X, y, device=dev).fit([MLPConfig(activation="logistic")])
     assert GridMLPTrainer(X, y, device=dev).fit([]) == []
+
+
+def test_fits_that_share_a_random_stream_equal_the_same_fits_run_alone(dev):
+    """Round 4: fits with the same (integer seed, layer sizes, number of training rows) consume ONE RandomState stream on the host (initial
+    weights and shuffles drawn once per group).  Five such fits -- other folds, batch sizes, learning rates, epoch counts -- in one call
+    must give, bit for bit, what each gives when it is the only fit of a call (where it owns its stream)."""
+    X, y = make_data(400, 100, 9)
+    rs = np.random.RandomState(1)
+    cfgs = []
+    for i, (bs, lr, epochs) in enumerate([(32, 0.01, 5), (64, 0.01, 3), (128, 0.1, 7), (32, 0.001, 2), (64, 0.1, 6)]):
+        rows = np.sort(rs.choice(400, 320, replace=False))
+        cfgs.append(MLPConfig(hidden_layer_sizes=(100, 50), activation="relu", learning_rate_init=lr, batch_size=bs, max_iter=epochs, tol=0.0,
+                              n_iter_no_change=10 ** 9, random_state=0, train_rows=rows))
+    together = GridMLPTrainer(X, y, device=dev).fit(cfgs, epochs_per_launch=4)
+    for cfg, got in zip(cfgs, together):
+        alone = GridMLPTrainer(X, y, device=dev).fit([cfg], epochs_per_launch=4)[0]
+        assert got.n_iter_ == alone.n_iter_ == cfg.max_iter
+        assert got.loss_curve_ == alone.loss_curve_
+        for a, b in zip(got.coefs_ + got.intercepts_, alone.coefs_ + alone.intercepts_):
+            assert np.array_equal(a, b)

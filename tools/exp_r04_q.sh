@@ -1,4 +1,4 @@
 #!/bin/bash
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"
-timeout -k 10 300 python3 tools/adamw_ulp_probe.py 2>&1 | grep -v amdgpu.ids | cut -c1-400
+timeout -k 10 300 python3 -m pytest tests/test_gpu_mlp.py -q -m gpu 2>&1 | tail -5
