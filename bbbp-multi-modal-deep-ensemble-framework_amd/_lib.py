@@ -126,6 +126,7 @@ _SIGNATURES = {
     "bbbp_mlp_profile": (c_int, [c_int, c_void_p]),
     "bbbp_mlp_profile_groups": (c_int, [c_void_p, c_int]),
     "bbbp_set_conv_wgrad_beside_encoder": (c_int, [c_int]),
+    "bbbp_set_conv2_fwd_pipe": (c_int, [c_int]),
     "bbbp_adamw_step_deferred": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_long, c_double, c_double, c_double, c_double, c_double, c_int, c_double]),
     "bbbp_param_sync": (c_int, [c_void_p]),
     "bbbp_param_stream": (c_void_p, []),

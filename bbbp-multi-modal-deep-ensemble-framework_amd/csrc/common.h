@@ -61,6 +61,9 @@ extern thread_local int g_bbbp_conv1_fwd_per_cu;
 // of 256 registers per SIMD) and a 4-wave form that leaves ~200 registers per lane slot to the fingerprint branch's kernels; the engine
 // asks for the latter while an encoder chain runs beside the image branch (0 = no preference: 8 waves)
 extern thread_local int g_bbbp_conv_wgrad_beside_encoder;
+// conv_b3.hip, forward of the 64 x 64-map stages: 1 = the software-pipelined one-work-group-per-CU kernel (what the engine asks for while an encoder
+// chain runs beside the image branch: slower alone, but it leaves the chain three quarters of every SIMD), 0 = two work-groups per CU
+extern thread_local int g_bbbp_conv2_fwd_pipe;
 extern thread_local int g_bbbp_wino_side_cus;      // CUs the Winograd conv grids leave free while the engine overlaps its branches
 // head.hip: fused fusion-block + regression-head forward (two launches); `partial`: ceil(B/16) * 2 * 256 floats
 int bbbp_head_forward_fused(hipStream_t st, const float* comb, const float* const* fw1, const float* const* fb1,

@@ -372,6 +372,219 @@ template <int MODE>
 __global__ __launch_bounds__(256) void conv_b3_probe_kernel(B3Params p) { conv_b3_body<MODE, true, GeomFlagship>(p); }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// Round 4: the FORWARD kernel software-pipelined inside a wave, ONE work-group per CU (g_bbbp_conv2_fwd_pipe: training plans beside an
+// encoder chain; BBBP_C2_PIPE=0 / 1 overrides).
+// conv_b3_kernel's waves spend ~40 % of their time in the MFMA block and the rest issuing loads, splitting, writing LDS, waiting at two
+// barriers per stage and in the epilogue; a second work-group on the CU fills those gaps (matrix pipe ~60 % busy).  Here a stage's LDS
+// image is DOUBLE-buffered (2 x 65.7 KB: one work-group per CU) and every wave carries, inside the 108 MFMAs of stage q:
+//   taps 0-2  the split + LDS writes of stage q + 1's three items into the other buffer (loaded during stage q - 1),
+//   tap  3    its filter stage's LDS writes,
+//   taps 4-6  the global loads of stage q + 2's items, tap 7 its filter loads (same registers, free again after tap 3),
+//   taps 0-7  (first chunk of a strip) the pooling epilogue of the PREVIOUS strip from a copy of its accumulators,
+// one barrier per stage.  Each tap is one scheduling region; the pattern puts one LDS read, a few vector instructions and one memory
+// operation behind every MFMA.  Loads and writes are unconditional: past the last stage they re-read / re-write data nobody uses.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <class G, bool MASK>
+__global__ __launch_bounds__(256) void conv_b3p_fwd_kernel(B3Params p) {
+    constexpr int IMG = G::IMGS, R = 256 / IMG, ROWS = R + 2, PXW = IMG + 2, XPLANE = ROWS * PXW * CH, XBUF = 3 * XPLANE;
+    constexpr int KIN = G::CIN, NCHUNK = KIN / CH, NMB = G::COUT / 32, NOUT = G::COUT, SRC_PLANE = IMG * IMG;
+    constexpr int STAGE = XBUF + WSTAGE;                     // bf16 elements of one buffer
+    static_assert(IMG == 64, "the pipelined form is written for the 64 x 64 maps");
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    const bool pairs = NMB == 2 && (gridDim.x & 15) == 0;
+    const int mb = NMB == 1 ? 0 : pairs ? (blockIdx.x >> 3) & 1 : blockIdx.x % NMB;
+    const int nstrips = p.B * (IMG / R);
+    const int stride = gridDim.x / NMB;
+    const int first = NMB == 1 ? xcd_adjacent(blockIdx.x, gridDim.x)
+                    : pairs ? ((stride & 7) ? (blockIdx.x & 7) + 8 * (blockIdx.x >> 4) : (blockIdx.x & 7) * (stride >> 3) + (blockIdx.x >> 4))
+                    : blockIdx.x / NMB;
+    for (int i = t * 8; i < 2 * STAGE; i += 256 * 8) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0, 0, 0, 0};
+
+    constexpr int ITEMS = 2 * ROWS * IMG, NIT = ITEMS / 256;
+    static_assert(ITEMS % 256 == 0 && NIT == 3, "three items per thread and stage");
+    constexpr int WPIECES = WSTAGE * 2 / 16, WIT = (WPIECES + 255) / 256;
+    int goff[NIT], loff[NIT], irow[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int idx = t + i * 256, px = idx % IMG, row = (idx / IMG) % ROWS, cg = idx / (IMG * ROWS);
+        goff[i] = cg * 8 * SRC_PLANE + px;
+        loff[i] = (row * PXW + px + 1) * CH + cg * 8;
+        irow[i] = row;
+    }
+    float xr[NIT][8];
+    u32x4 wr[WIT];
+    uint32_t okbits = 0, oknext = 0;
+    const char* ld_xb = nullptr; int ld_h0 = 0; const u32x4* ld_w = nullptr;
+    auto load_begin = [&](int strip, int chunk) __attribute__((always_inline)) {
+        const int b = strip / (IMG / R);
+        ld_h0 = (strip % (IMG / R)) * R;
+        ld_xb = reinterpret_cast<const char*>(p.x + ((long)b * KIN + chunk * CH) * SRC_PLANE);
+        ld_w = reinterpret_cast<const u32x4*>(p.wp + (size_t)(mb * NCHUNK + chunk) * WSTAGE);
+        oknext = 0;
+    };
+    auto load_item = [&](int i) __attribute__((always_inline)) {
+        const int yr = ld_h0 - 1 + irow[i];
+        const int yy = min(max(yr, 0), IMG - 1);
+        oknext |= (yr >= 0 && yr < IMG ? 1u : 0u) << i;
+        const unsigned o = goff[i] + yy * IMG;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xr[i][j] = *reinterpret_cast<const float*>(ld_xb + (size_t)(4u * (o + j * SRC_PLANE)));
+    };
+    auto load_filters = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < WIT; ++i) wr[i] = ld_w[min(t + i * 256, WPIECES - 1)];
+    };
+    auto store_item = [&](uint16_t* Xd, int i) __attribute__((always_inline)) {
+        const bool ok = (okbits >> i) & 1u;
+        uint32_t hi[4], mid[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split2(ok ? xr[i][2 * j] : 0.f, ok ? xr[i][2 * j + 1] : 0.f, hi[j], mid[j], lo[j]);
+        uint16_t* d = Xd + loff[i];
+        *reinterpret_cast<u32x4*>(d) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+        *reinterpret_cast<u32x4*>(d + XPLANE) = u32x4{mid[0], mid[1], mid[2], mid[3]};
+        *reinterpret_cast<u32x4*>(d + 2 * XPLANE) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+    };
+    auto store_filters = [&](uint16_t* Wd) __attribute__((always_inline)) {
+        u32x4* wd = reinterpret_cast<u32x4*>(Wd);
+#pragma unroll
+        for (int i = 0; i < WIT; ++i) wd[min(t + i * 256, WPIECES - 1)] = wr[i];      // (clamped like the load: the tail lanes rewrite the last piece with itself)
+    };
+    // stage counter of this work-group: stage q = (strip first + (q / NCHUNK) * stride, chunk q % NCHUNK); clamped to the last one
+    const int nmine = first < nstrips ? (nstrips - first + stride - 1) / stride : 0;
+    const int nq = nmine * NCHUNK;
+    auto strip_of = [&](int q) { return first + (min(q, nq - 1) / NCHUNK) * stride; };
+    auto chunk_of = [&](int q) { return min(q, nq - 1) % NCHUNK; };
+    if (nq == 0) return;
+
+    constexpr int WPR = IMG / 32;
+    const int y0 = (wave / WPR) * 2, cb = (wave % WPR) * 32;
+    const int odd = lane & 1, x = cb + r;
+    __syncthreads();                                         // the zero fill of both buffers
+    // prologue: stage 0 into buffer 0, stage 1's loads in flight
+    load_begin(strip_of(0), chunk_of(0));
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) load_item(i);
+    load_filters();
+    okbits = oknext;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) store_item(smem, i);
+    store_filters(smem + XBUF);
+    load_begin(strip_of(1), chunk_of(1));
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) load_item(i);
+    load_filters();
+
+    f32x16 acc[2], eacc[2];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { eacc[0][q] = 0.f; eacc[1][q] = 0.f; }
+    int eb = strip_of(0) / (IMG / R), eh0 = (strip_of(0) % (IMG / R)) * R;          // the strip eacc belongs to (first pass: the first strip, rewritten later)
+    float bv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) bv[q] = p.bias[mb * 32 + mfma_row(q, lane)];
+    // one output of the pooling epilogue (k = 0 .. 7) of the strip in eacc
+    auto epilogue_piece = [&](int k) __attribute__((always_inline)) {
+        const int mine = 2 * k + odd;
+        // (opaque copies: the compiler otherwise rewrites "odd ? v[2k] : v[2k + 1]" into v[(2k + 1) ^ odd], a per-lane register-array index
+        // that it lowers to a chain of 15 compares and selects per access -- 780 of this kernel's first version's 1120 vector instructions)
+        float e00 = eacc[0][2 * k], e01 = eacc[0][2 * k + 1], e10 = eacc[1][2 * k], e11 = eacc[1][2 * k + 1];
+        asm volatile("" : "+v"(e00), "+v"(e01), "+v"(e10), "+v"(e11));
+        const float s0 = odd ? e00 : e01, s1 = odd ? e10 : e11;
+        const float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+        const float m0 = odd ? e01 : e00, m1 = odd ? e11 : e10;
+        const float v0 = odd ? r0 : m0, v1 = odd ? m0 : r0, v2 = odd ? r1 : m1, v3 = odd ? m1 : r1;
+        float best = v0; int arg = 0;
+        if (v1 > best) { best = v1; arg = 1; }
+        if (v2 > best) { best = v2; arg = 2; }
+        if (v3 > best) { best = v3; arg = 3; }
+        const bool act = best > 0.f;
+        const int co = mb * 32 + mfma_row(mine, lane);
+        const long o = (((long)eb * NOUT + co) * (IMG / 2) + ((eh0 + y0) >> 1)) * (IMG / 2) + (x >> 1);
+        p.y[o] = act ? best : 0.f;
+        if (MASK) p.ymask[o] = act ? (uint8_t)arg : (uint8_t)4;          // (a template parameter: a branch here would cut the tap's scheduling region)
+    };
+
+    for (int q0 = 0; q0 < nq; q0 += NCHUNK) {
+#pragma unroll
+        for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+            const int q = q0 + chunk;
+            uint16_t* cur = smem + ((q & 1) ? STAGE : 0);
+            uint16_t* nxt = smem + ((q & 1) ? 0 : STAGE);
+            const uint16_t* xs = cur + 8 * h;
+            const uint16_t* ws = cur + XBUF + (h * 32 + r) * 8;
+            __syncthreads();                                 // buffer `cur` is complete; everybody is done reading `nxt` (stage q - 1)
+            if (chunk == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { acc[0][i] = bv[i]; acc[1][i] = bv[i]; }
+            }
+            okbits = oknext;                                  // validity of the rows held in xr (stage q + 1)
+            bf16x8 a[2][3], bq[2][2][3];
+            auto fetch = [&](int tap, int slot) __attribute__((always_inline)) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[slot][pl] = *reinterpret_cast<const bf16x8*>(ws + (tap * 3 + pl) * (2 * 32 * 8));
+#if defined(B3P_ABLATE_DX)
+                // ABLATION (wrong results): the dx = +-1 taps reuse the dx = 0 fragments -- what the kernel would cost without 36 of its 81 LDS reads
+                if (dx != 0) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) bq[slot][nt][pl] = bq[slot ^ 1][nt][pl];
+                    return;
+                }
+#endif
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        bq[slot][nt][pl] = *reinterpret_cast<const bf16x8*>(xs + pl * XPLANE + ((y0 + nt + dy + 1) * PXW + (cb + r + dx + 1)) * CH);
+            };
+            fetch(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int sl = tap & 1;
+                if (tap + 1 < 9) fetch(tap + 1, sl ^ 1);
+                if (tap < NIT) store_item(nxt, tap);                              // stage q + 1 -> the other buffer
+                if (tap == NIT) { store_filters(nxt + XBUF); load_begin(strip_of(q + 2), chunk_of(q + 2)); }
+                if (tap > NIT && tap <= 2 * NIT) load_item(tap - NIT - 1);        // stage q + 2 -> the registers stage q + 1 just left
+                if (tap == 2 * NIT + 1) load_filters();
+                if (chunk == 0 && tap < 8) epilogue_piece(tap);                   // the previous strip's pooled outputs
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sl][1], bq[sl][nt][1], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sl][2], bq[sl][nt][0], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sl][0], bq[sl][nt][2], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sl][1], bq[sl][nt][0], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sl][0], bq[sl][nt][1], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sl][0], bq[sl][nt][0], acc[nt], 0, 0, 0);
+                }
+                // per MFMA gap: one LDS read of the next tap's fragments, up to six vector instructions, one memory operation
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (tap + 1 < 9 && k < 9) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (chunk == NCHUNK - 1) {
+                // hand the strip's accumulators to the epilogue that runs inside the next strip's first stage
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { eacc[0][i] = acc[0][i]; eacc[1][i] = acc[1][i]; }
+                const int sp = strip_of(q);
+                eb = sp / (IMG / R); eh0 = (sp % (IMG / R)) * R;
+            }
+        }
+    }
+    // the last strip's epilogue
+#pragma unroll
+    for (int k = 0; k < 8; ++k) epilogue_piece(k);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // Weight gradient of the same stage: dW[co][ci][tap] = sum_{b, y, x} dY[b][co][y][x] X[b][ci][y + dy][x + dx] with dY the pooled
 // gradient expanded through the arg-max mask; db[co] = sum dY.  GEMM view: M = co (2 tiles of 32), N = (tap, ci) (9 tiles of 32),
 // K = pixels, 16 per MFMA.  Both operands sit in LDS pixel-INNERMOST, split in three bf16 planes: a lane's A fragment is 8
@@ -982,6 +1195,24 @@ template <int MODE, class G>
 int launch_b3(const B3Params& p, hipStream_t st) {
     static const int probe = [] { const char* e = getenv("BBBP_B3_PROBE"); return e ? atoi(e) : 0; }();
     constexpr bool flagship = G::CIN == 32 && G::COUT == 64 && G::IMGS == 64;
+    if constexpr (MODE == B3_FWD && G::IMGS == 64) {
+        static const int pipe_env = [] { const char* e = getenv("BBBP_C2_PIPE"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+        const int pipe = pipe_env >= 0 ? pipe_env : g_bbbp_conv2_fwd_pipe;
+        if (pipe && !probe) {
+            auto pk = p.ymask ? conv_b3p_fwd_kernel<G, true> : conv_b3p_fwd_kernel<G, false>;
+            constexpr size_t plds = (size_t)2 * (3 * (256 / G::IMGS + 2) * (G::IMGS + 2) * CH + WSTAGE) * 2;
+            { int rc_ = bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(pk), plds); if (rc_) return rc_; }
+            constexpr int NMBP = G::COUT / 32;
+            const int nworkp = p.B * (G::IMGS / (256 / G::IMGS)) * NMBP;
+            int gridp = bbbp_num_cus();
+            if (gridp >= 8 * NMBP) gridp -= gridp % (8 * NMBP);
+            if (gridp > nworkp) gridp = nworkp - nworkp % NMBP;
+            if (gridp < NMBP) gridp = NMBP;
+            hipLaunchKernelGGL(pk, dim3(gridp), dim3(256), plds, st, p);
+            BBBP_CHECK_LAUNCH();
+            return BBBP_OK;
+        }
+    }
     auto kernel = conv_b3_kernel<MODE, G>;
     if constexpr (flagship) { if (probe) kernel = conv_b3_probe_kernel<MODE>; }
     constexpr int IMGL = G::IMGS, RL = 256 / IMGL;

@@ -663,8 +663,15 @@ static int forward_enqueue(void* stream, const bbbp_mixed_desc* d, const float* 
     }
     {
         Section s2(c.st, SEC_CONV2_FWD);
-        TRY(bbbp_conv3x3_relu_pool_fwd(c.st, pool1, P[ix.c2_w()], P[ix.c2_b()], pool2, plan.inference ? nullptr : c.u8(plan.mask2), B, C1, C2, IMG / 2,
-                                       IMG / 2, c.scratch(), c.scratch_bytes()));
+        // round 4: beside a training step's encoder chain the software-pipelined one-work-group-per-CU kernel (conv_b3.hip): 0.40 instead of
+        // 0.387 ms alone, but the chain -- the forward half's critical path -- keeps three quarters of every SIMD: step 2.41 -> 2.34 ms
+        // (profiles/r04_conv2_pipe.txt).  BBBP_C2_TRAIN=0: the two-work-group kernel there too.  Bit-identical outputs either way.
+        static const int c2_train = [] { const char* e = getenv("BBBP_C2_TRAIN"); return e ? atoi(e) : 1; }();
+        g_bbbp_conv2_fwd_pipe = (!plan.inference && plan.L > 0 && c2_train) ? 1 : 0;
+        const int rc2 = bbbp_conv3x3_relu_pool_fwd(c.st, pool1, P[ix.c2_w()], P[ix.c2_b()], pool2, plan.inference ? nullptr : c.u8(plan.mask2), B, C1, C2, IMG / 2,
+                                                   IMG / 2, c.scratch(), c.scratch_bytes());
+        g_bbbp_conv2_fwd_pipe = 0;
+        TRY(rc2);
     }
     {
         Section s3(c.st, SEC_IMGFC_FWD);

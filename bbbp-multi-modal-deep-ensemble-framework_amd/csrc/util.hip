@@ -16,6 +16,7 @@ thread_local int g_bbbp_wino_side_cus = 0;
 thread_local int g_bbbp_conv1_fwd_f32 = 0;
 thread_local int g_bbbp_conv1_fwd_per_cu = 0;
 thread_local int g_bbbp_conv_wgrad_beside_encoder = 0;
+thread_local int g_bbbp_conv2_fwd_pipe = 0;
 thread_local const unsigned long long* g_bbbp_seed_base = nullptr;
 
 // More than 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize per (kernel, DEVICE): code objects are loaded
@@ -98,5 +99,15 @@ extern "C" int bbbp_set_seed_base(const void* base_dev) {
 extern "C" int bbbp_set_conv_wgrad_beside_encoder(int on) {
     const int prev = g_bbbp_conv_wgrad_beside_encoder;
     g_bbbp_conv_wgrad_beside_encoder = on ? 1 : 0;
+    return prev;
+}
+
+// Forward of the 32 -> 64 / 64 -> 128 stages on 64 x 64 maps: 1 selects, for the calling thread, the software-pipelined kernel that runs ONE
+// work-group per CU (conv_b3.hip: conv_b3p_fwd_kernel) -- 3 % slower alone, but beside an encoder chain the step is 2.8 % faster
+// (bbbp_mixed_forward sets it by itself for training plans with an encoder).  Same arithmetic in the same order: bit-identical outputs
+// and decisions.  Returns the previous setting.  BBBP_C2_PIPE=0 / 1 overrides every caller.
+extern "C" int bbbp_set_conv2_fwd_pipe(int on) {
+    const int prev = g_bbbp_conv2_fwd_pipe;
+    g_bbbp_conv2_fwd_pipe = on ? 1 : 0;
     return prev;
 }

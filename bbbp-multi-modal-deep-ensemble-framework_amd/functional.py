@@ -241,7 +241,16 @@ class _ConvReluPool(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, beside):
-        y, mask = ops.conv3x3_relu_pool_fwd(x, weight, bias)
+        if beside:
+            # another branch runs beside this one: the one-work-group-per-CU forward kernel where there is one (64 x 64 maps)
+            L = _lib.lib()
+            prev = L.bbbp_set_conv2_fwd_pipe(1)
+            try:
+                y, mask = ops.conv3x3_relu_pool_fwd(x, weight, bias)
+            finally:
+                L.bbbp_set_conv2_fwd_pipe(prev)
+        else:
+            y, mask = ops.conv3x3_relu_pool_fwd(x, weight, bias)
         ctx.save_for_backward(x, weight, mask)
         ctx.beside = beside
         return y

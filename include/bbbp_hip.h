@@ -220,6 +220,10 @@ int bbbp_adamw_hyper_store(void* stream, float* hyper_dev, double lr, double bet
  * model op by op with its branches on two streams sets this for the CALLING THREAD around bbbp_conv3x3_relu_pool_bwd_weight.  Returns the
  * previous setting. */
 int bbbp_set_conv_wgrad_beside_encoder(int on);
+/* Forward of the 32->64 / 64->128 stages on 64 x 64 maps: 1 selects, for the CALLING THREAD, the software-pipelined kernel that runs one
+ * work-group per CU (slower alone, faster for a step whose encoder chain runs beside it; bbbp_mixed_forward chooses by itself).  Outputs and
+ * decisions are bit-identical.  Returns the previous setting. */
+int bbbp_set_conv2_fwd_pipe(int on);
 /* Op-level dropout streams keyed from device memory (round 4).  With a base set for the CALLING THREAD, every seeded entry point of this
  * header (dropout, softmax, layernorm, linear with output dropout, attention) uses the stream  *base * 0x9E3779B97F4A7C15 + seed  instead of
  * `seed`: a training step captured into a HIP graph draws new masks on each replay when the caller bumps the 64-bit integer at `base_dev`

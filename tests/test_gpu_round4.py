@@ -341,3 +341,28 @@ def test_adamw_kernel_follows_torch_optim_adamw_to_the_ulp(dev):
         st = ropt.state[ref]
         assert torch.equal(opt.state[mine]["exp_avg"].cpu(), st["exp_avg"]), step         # the moments depend on the gradients only
         assert torch.equal(opt.state[mine]["exp_avg_sq"].cpu(), st["exp_avg_sq"]), step
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 64), (64, 128)])
+@pytest.mark.parametrize("keep_mask", [True, False])
+def test_pipelined_conv2_forward_is_bit_identical_to_the_two_work_group_kernel(dev, cin, cout, keep_mask):
+    """conv_b3p_fwd_kernel (one work-group per CU, software-pipelined: what training plans run beside the encoder chain) performs the same
+    products in the same order as conv_b3_kernel: outputs and pooling decisions must be the same bits -- incl. a batch that leaves some
+    work-groups without a strip and one that gives every work-group several."""
+    L = _lib.lib()
+    for B in (1, 3, 40):
+        g = torch.Generator().manual_seed(100 + B)
+        x = torch.randn(B, cin, 64, 64, generator=g).to(dev)
+        w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).to(dev)
+        b = torch.randn(cout, generator=g).to(dev)
+        outs = []
+        for pipe in (0, 1):
+            prev = L.bbbp_set_conv2_fwd_pipe(pipe)
+            try:
+                outs.append(ops.conv3x3_relu_pool_fwd(x, w, b, keep_mask=keep_mask))
+            finally:
+                L.bbbp_set_conv2_fwd_pipe(prev)
+        (y0, m0), (y1, m1) = outs
+        assert torch.equal(y0, y1), B
+        if keep_mask:
+            assert torch.equal(m0, m1), B
