@@ -384,10 +384,14 @@ __global__ __launch_bounds__(256) void conv_b3_probe_kernel(B3Params p) { conv_b
 // one barrier per stage.  Each tap is one scheduling region; the pattern puts one LDS read, a few vector instructions and one memory
 // operation behind every MFMA.  Loads and writes are unconditional: past the last stage they re-read / re-write data nobody uses.
 // ------------------------------------------------------------------------------------------------------------------------------
-template <class G, bool MASK>
-__global__ __launch_bounds__(256) void conv_b3p_fwd_kernel(B3Params p) {
+// (MODE = B3_DGRAD, round 4, experimental -- BBBP_C2_DGRAD_PIPE=1: the data gradient in the same form: the loader expands the pooled gradient
+// through the decisions, the epilogue stores two full-resolution rows of 32 pixels x 32 channels per wave.)
+template <int MODE, class G, bool MASK>
+__global__ __launch_bounds__(256) void conv_b3p_kernel(B3Params p) {
     constexpr int IMG = G::IMGS, R = 256 / IMG, ROWS = R + 2, PXW = IMG + 2, XPLANE = ROWS * PXW * CH, XBUF = 3 * XPLANE;
-    constexpr int KIN = G::CIN, NCHUNK = KIN / CH, NMB = G::COUT / 32, NOUT = G::COUT, SRC_PLANE = IMG * IMG;
+    constexpr int KIN = MODE == B3_FWD ? G::CIN : G::COUT, NCHUNK = KIN / CH, NMB = (MODE == B3_FWD ? G::COUT : G::CIN) / 32, NOUT = NMB * 32;
+    constexpr int SRC_PLANE = MODE == B3_FWD ? IMG * IMG : (IMG / 2) * (IMG / 2);
+    static_assert(NCHUNK % 2 == 0, "the buffer parity of a stage is its chunk's parity");
     constexpr int STAGE = XBUF + WSTAGE;                     // bf16 elements of one buffer
     static_assert(IMG == 64, "the pipelined form is written for the 64 x 64 maps");
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
@@ -405,21 +409,24 @@ __global__ __launch_bounds__(256) void conv_b3p_fwd_kernel(B3Params p) {
     static_assert(ITEMS % 256 == 0 && NIT == 3, "three items per thread and stage");
     constexpr int WPIECES = WSTAGE * 2 / 16, WIT = (WPIECES + 255) / 256;
     int goff[NIT], loff[NIT], irow[NIT];
+    const int ipar = t & 1;                                  // (px & 1: the same for the three items of a thread)
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
         const int idx = t + i * 256, px = idx % IMG, row = (idx / IMG) % ROWS, cg = idx / (IMG * ROWS);
-        goff[i] = cg * 8 * SRC_PLANE + px;
+        goff[i] = cg * 8 * SRC_PLANE + (MODE == B3_FWD ? px : px >> 1);
         loff[i] = (row * PXW + px + 1) * CH + cg * 8;
         irow[i] = row;
     }
     float xr[NIT][8];
+    uint32_t mr[NIT][2];                                     // DGRAD: the eight decision bytes of an item
     u32x4 wr[WIT];
     uint32_t okbits = 0, oknext = 0;
-    const char* ld_xb = nullptr; int ld_h0 = 0; const u32x4* ld_w = nullptr;
+    const char* ld_xb = nullptr; const uint8_t* ld_mb = nullptr; int ld_h0 = 0, st_h0 = 0; const u32x4* ld_w = nullptr;
     auto load_begin = [&](int strip, int chunk) __attribute__((always_inline)) {
         const int b = strip / (IMG / R);
         ld_h0 = (strip % (IMG / R)) * R;
         ld_xb = reinterpret_cast<const char*>(p.x + ((long)b * KIN + chunk * CH) * SRC_PLANE);
+        ld_mb = MODE == B3_DGRAD ? p.xmask + ((long)b * KIN + chunk * CH) * SRC_PLANE : nullptr;
         ld_w = reinterpret_cast<const u32x4*>(p.wp + (size_t)(mb * NCHUNK + chunk) * WSTAGE);
         oknext = 0;
     };
@@ -427,9 +434,15 @@ __global__ __launch_bounds__(256) void conv_b3p_fwd_kernel(B3Params p) {
         const int yr = ld_h0 - 1 + irow[i];
         const int yy = min(max(yr, 0), IMG - 1);
         oknext |= (yr >= 0 && yr < IMG ? 1u : 0u) << i;
-        const unsigned o = goff[i] + yy * IMG;
+        const unsigned o = goff[i] + (MODE == B3_FWD ? yy * IMG : (yy >> 1) * (IMG / 2));
 #pragma unroll
         for (int j = 0; j < 8; ++j) xr[i][j] = *reinterpret_cast<const float*>(ld_xb + (size_t)(4u * (o + j * SRC_PLANE)));
+        if (MODE == B3_DGRAD) {
+            uint32_t m0 = 0, m1 = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { m0 |= (uint32_t)ld_mb[o + j * SRC_PLANE] << (8 * j); m1 |= (uint32_t)ld_mb[o + (j + 4) * SRC_PLANE] << (8 * j); }
+            mr[i][0] = m0; mr[i][1] = m1;
+        }
     };
     auto load_filters = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -437,9 +450,18 @@ __global__ __launch_bounds__(256) void conv_b3p_fwd_kernel(B3Params p) {
     };
     auto store_item = [&](uint16_t* Xd, int i) __attribute__((always_inline)) {
         const bool ok = (okbits >> i) & 1u;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (MODE == B3_FWD) v[j] = ok ? xr[i][j] : 0.f;
+            else {
+                const uint32_t want = (uint32_t)(((st_h0 - 1 + irow[i]) & 1) * 2 + ipar);
+                v[j] = (ok && ((mr[i][j >> 2] >> (8 * (j & 3))) & 0xff) == want) ? xr[i][j] : 0.f;
+            }
+        }
         uint32_t hi[4], mid[4], lo[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) split2(ok ? xr[i][2 * j] : 0.f, ok ? xr[i][2 * j + 1] : 0.f, hi[j], mid[j], lo[j]);
+        for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], hi[j], mid[j], lo[j]);
         uint16_t* d = Xd + loff[i];
         *reinterpret_cast<u32x4*>(d) = u32x4{hi[0], hi[1], hi[2], hi[3]};
         *reinterpret_cast<u32x4*>(d + XPLANE) = u32x4{mid[0], mid[1], mid[2], mid[3]};
@@ -466,7 +488,7 @@ __global__ __launch_bounds__(256) void conv_b3p_fwd_kernel(B3Params p) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) load_item(i);
     load_filters();
-    okbits = oknext;
+    okbits = oknext; st_h0 = ld_h0;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) store_item(smem, i);
     store_filters(smem + XBUF);
@@ -481,9 +503,21 @@ __global__ __launch_bounds__(256) void conv_b3p_fwd_kernel(B3Params p) {
     int eb = strip_of(0) / (IMG / R), eh0 = (strip_of(0) % (IMG / R)) * R;          // the strip eacc belongs to (first pass: the first strip, rewritten later)
     float bv[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) bv[q] = p.bias[mb * 32 + mfma_row(q, lane)];
+    for (int q = 0; q < 16; ++q) bv[q] = MODE == B3_FWD ? p.bias[mb * 32 + mfma_row(q, lane)] : 0.f;
     // one output of the pooling epilogue (k = 0 .. 7) of the strip in eacc
     auto epilogue_piece = [&](int k) __attribute__((always_inline)) {
+        if (MODE == B3_DGRAD) {
+            // two accumulator registers of both row tiles: full-resolution rows eh0 + y0 (+ 1), channel mfma_row(q), pixel x (128-byte rows)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int q = 2 * k + e;
+                    const int ci = mb * 32 + mfma_row(q, lane);
+                    p.y[(((long)eb * NOUT + ci) * IMG + (eh0 + y0 + nt)) * IMG + x] = eacc[nt][q];
+                }
+            return;
+        }
         const int mine = 2 * k + odd;
         // (opaque copies: the compiler otherwise rewrites "odd ? v[2k] : v[2k + 1]" into v[(2k + 1) ^ odd], a per-lane register-array index
         // that it lowers to a chain of 15 compares and selects per access -- 780 of this kernel's first version's 1120 vector instructions)
@@ -517,7 +551,7 @@ __global__ __launch_bounds__(256) void conv_b3p_fwd_kernel(B3Params p) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { acc[0][i] = bv[i]; acc[1][i] = bv[i]; }
             }
-            okbits = oknext;                                  // validity of the rows held in xr (stage q + 1)
+            okbits = oknext; st_h0 = ld_h0;                   // validity / strip row of the rows held in xr (stage q + 1)
             bf16x8 a[2][3], bq[2][2][3];
             auto fetch = [&](int tap, int slot) __attribute__((always_inline)) {
                 const int dy = tap / 3 - 1, dx = tap % 3 - 1;
@@ -1195,14 +1229,15 @@ template <int MODE, class G>
 int launch_b3(const B3Params& p, hipStream_t st) {
     static const int probe = [] { const char* e = getenv("BBBP_B3_PROBE"); return e ? atoi(e) : 0; }();
     constexpr bool flagship = G::CIN == 32 && G::COUT == 64 && G::IMGS == 64;
-    if constexpr (MODE == B3_FWD && G::IMGS == 64) {
+    if constexpr (G::IMGS == 64) {
         static const int pipe_env = [] { const char* e = getenv("BBBP_C2_PIPE"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
-        const int pipe = pipe_env >= 0 ? pipe_env : g_bbbp_conv2_fwd_pipe;
+        static const int dpipe_env = [] { const char* e = getenv("BBBP_C2_DGRAD_PIPE"); return e ? (atoi(e) != 0 ? 1 : 0) : 0; }();
+        const int pipe = MODE == B3_FWD ? (pipe_env >= 0 ? pipe_env : g_bbbp_conv2_fwd_pipe) : dpipe_env;
         if (pipe && !probe) {
-            auto pk = p.ymask ? conv_b3p_fwd_kernel<G, true> : conv_b3p_fwd_kernel<G, false>;
+            auto pk = MODE == B3_FWD ? (p.ymask ? conv_b3p_kernel<MODE, G, true> : conv_b3p_kernel<MODE, G, false>) : conv_b3p_kernel<MODE, G, false>;
             constexpr size_t plds = (size_t)2 * (3 * (256 / G::IMGS + 2) * (G::IMGS + 2) * CH + WSTAGE) * 2;
             { int rc_ = bbbp_ensure_dyn_lds(reinterpret_cast<const void*>(pk), plds); if (rc_) return rc_; }
-            constexpr int NMBP = G::COUT / 32;
+            constexpr int NMBP = (MODE == B3_FWD ? G::COUT : G::CIN) / 32;
             const int nworkp = p.B * (G::IMGS / (256 / G::IMGS)) * NMBP;
             int gridp = bbbp_num_cus();
             if (gridp >= 8 * NMBP) gridp -= gridp % (8 * NMBP);

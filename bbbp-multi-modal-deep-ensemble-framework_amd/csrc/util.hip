@@ -103,7 +103,7 @@ extern "C" int bbbp_set_conv_wgrad_beside_encoder(int on) {
 }
 
 // Forward of the 32 -> 64 / 64 -> 128 stages on 64 x 64 maps: 1 selects, for the calling thread, the software-pipelined kernel that runs ONE
-// work-group per CU (conv_b3.hip: conv_b3p_fwd_kernel) -- 3 % slower alone, but beside an encoder chain the step is 2.8 % faster
+// work-group per CU (conv_b3.hip: conv_b3p_kernel) -- 3 % slower alone, but beside an encoder chain the step is 2.8 % faster
 // (bbbp_mixed_forward sets it by itself for training plans with an encoder).  Same arithmetic in the same order: bit-identical outputs
 // and decisions.  Returns the previous setting.  BBBP_C2_PIPE=0 / 1 overrides every caller.
 extern "C" int bbbp_set_conv2_fwd_pipe(int on) {

@@ -346,7 +346,7 @@ def test_adamw_kernel_follows_torch_optim_adamw_to_the_ulp(dev):
 @pytest.mark.parametrize("cin,cout", [(32, 64), (64, 128)])
 @pytest.mark.parametrize("keep_mask", [True, False])
 def test_pipelined_conv2_forward_is_bit_identical_to_the_two_work_group_kernel(dev, cin, cout, keep_mask):
-    """conv_b3p_fwd_kernel (one work-group per CU, software-pipelined: what training plans run beside the encoder chain) performs the same
+    """conv_b3p_kernel<FWD> (one work-group per CU, software-pipelined: what training plans run beside the encoder chain) performs the same
     products in the same order as conv_b3_kernel: outputs and pooling decisions must be the same bits -- incl. a batch that leaves some
     work-groups without a strip and one that gives every work-group several."""
     L = _lib.lib()

@@ -75,8 +75,8 @@ def test_rocprof_kernel_table_agrees_with_the_bench_line(config):
     d = bench(config)
     r = d["roofline"]
     # (round 4: the kernel is templated over its geometry -- "conv_b3_kernel<0, B3Geom<32, 64, 64> >")
-    # (round 4, late: training plans with an encoder run the forward as "conv_b3p_fwd_kernel<B3Geom<32, 64, 64>, true>")
-    pattern = {"conv2_wgrad": "conv_b3_wgrad_", "conv2_fwd": "conv_b3_kernel<0" if config in (2, 5) else "conv_b3p_fwd_kernel<",
+    # (round 4, late: training plans with an encoder run the forward as "conv_b3p_kernel<0, B3Geom<32, 64, 64>, true>")
+    pattern = {"conv2_wgrad": "conv_b3_wgrad_", "conv2_fwd": "conv_b3_kernel<0" if config in (2, 5) else "conv_b3p_kernel<0",
                "conv2_dgrad": "conv_b3_kernel<1"}[r["kernel"]]
     rows = [x for x in csv.DictReader(open(os.path.join(PROF, f"{ROUND}_kernel_stats_config{config}.csv"))) if pattern in x["Name"]]
     assert len(rows) == 1

@@ -23,8 +23,8 @@ def sources_sha():
     return h.hexdigest()[:16]
 
 KERNELS = {            # a section maps to whichever of its kernels ran (direct f32, Winograd or split-bf16 form)
-    "conv2_fwd": ("conv3x3_kernel<32, 64, 64, 0>", "wino_conv_kernel<0>", "conv_b3_kernel<0", "conv_b3p_fwd_kernel<"),
-    "conv2_dgrad": ("conv3x3_kernel<64, 32, 64, 1>", "wino_conv_kernel<1>", "conv_b3_kernel<1"),
+    "conv2_fwd": ("conv3x3_kernel<32, 64, 64, 0>", "wino_conv_kernel<0>", "conv_b3_kernel<0", "conv_b3p_kernel<0"),
+    "conv2_dgrad": ("conv3x3_kernel<64, 32, 64, 1>", "wino_conv_kernel<1>", "conv_b3_kernel<1", "conv_b3p_kernel<1"),
     "conv2_wgrad": ("conv_wgrad32_kernel<64, 64, 32, 64>", "conv_b3_wgrad_kernel", "conv_b3_wgrad_sp_kernel"),
     "conv1_fwd": ("conv3x3_kernel<3, 32, 128, 0>", "conv1_b3_fwd_kernel", "conv1_b3p_fwd_kernel"),
     "conv1_wgrad": ("conv_wgrad3_kernel<128>", "conv_b3_wgrad3_kernel"),
